@@ -1,0 +1,156 @@
+// capi_host.cpp -- host half of the C ABI (include/glome_hip.h): the scene builder (one call per glome
+// constructor), the transform helpers and the host-side inspection calls.  No HIP here.
+#include <cstring>
+
+#include "../../include/glome_hip.h"
+#include "capi_shared.hpp"
+
+using namespace glome;
+
+namespace {
+D3 d3(const double* p) { return D3{p[0], p[1], p[2]}; }
+Xf xf_from(const double* m) { Xf x; for (int k = 0; k < 12; k++) { x.f.m[k] = m[k]; x.i.m[k] = m[12 + k]; } return x; }
+void xf_to(const Xf& x, double* out) { for (int k = 0; k < 12; k++) { out[k] = x.f.m[k]; out[12 + k] = x.i.m[k]; } }
+
+template <class F> int32_t guard(glome_sb* sb, F f) {
+  if (!sb) return GLOME_E_INVALID;
+  try { return (int32_t)f(); }
+  catch (const scene_error& e) { sb->err = e.what(); return GLOME_E_SCENE; }
+  catch (const limit_error& e) { sb->err = e.what(); return GLOME_E_LIMIT; }
+  catch (const std::invalid_argument& e) { sb->err = e.what(); return GLOME_E_INVALID; }
+  catch (const std::exception& e) { sb->err = e.what(); return GLOME_E_INVALID; }
+}
+template <class F> int xguard(F f) {
+  try { f(); return 0; } catch (...) { return GLOME_E_SCENE; }
+}
+std::vector<int> ids_of(const int32_t* ids, int n) {
+  if (n < 0 || (n > 0 && !ids)) throw std::invalid_argument("bad id list");
+  return std::vector<int>(ids, ids + n);
+}
+}  // namespace
+
+extern "C" {
+
+void glome_render_params_default(glome_render_params* p) {
+  if (!p) return;
+  memset(p, 0, sizeof(*p));
+  p->width = 720; p->height = 480;         // Glome.hs:112-113
+  p->mode = GLOME_MODE_TILE;
+  p->blocksize = 65;                       // Glome.hs:116
+  p->maxdepth = 3;                         // Glome.hs:25
+  p->thresholds[0] = 0.14f; p->thresholds[1] = 0.15f; p->thresholds[2] = 0.16f; p->thresholds[3] = 0.18f;  // Glome.hs:221-224
+  p->tile_first = 0; p->tile_stride = 1;
+}
+
+int glome_xfm_translate(const double v[3], double out[24]) { return xguard([&] { xf_to(xf_translate(d3(v)), out); }); }
+int glome_xfm_scale(const double v[3], double out[24]) { return xguard([&] { xf_to(xf_scale(d3(v)), out); }); }
+int glome_xfm_rotate(const double axis[3], double angle, double out[24]) { return xguard([&] { xf_to(xf_rotate(d3(axis), angle), out); }); }
+int glome_xfm_xyz_to_uvw(const double u[3], const double v[3], const double w[3], double out[24]) { return xguard([&] { xf_to(xf_xyz_to_uvw(d3(u), d3(v), d3(w)), out); }); }
+int glome_xfm_compose(const double* xfms, int n, double out[24]) {
+  return xguard([&] { std::vector<Xf> xs; for (int k = 0; k < n; k++) xs.push_back(xf_from(xfms + 24 * k)); xf_to(xf_compose(xs), out); });
+}
+int glome_camera_lookat(const double pos[3], const double at[3], const double up[3], double angle_deg, glome_camera* out) {  // Scene.hs:48-57
+  if (!out) return GLOME_E_INVALID;
+  D3 p = d3(pos);
+  D3 fwd = normalize(d3(at) - p);
+  D3 right = normalize(cross(d3(up), fwd));
+  D3 up_ = normalize(cross(fwd, right));
+  double cam_scale = std::tan((M_PI / 180) * (angle_deg / 2));
+  D3 u = up_ * cam_scale, r = right * cam_scale;
+  const D3 v[4] = {p, fwd, u, r};
+  float* o = out->pos;
+  for (int k = 0; k < 4; k++) { o[3 * k] = (float)v[k].x; o[3 * k + 1] = (float)v[k].y; o[3 * k + 2] = (float)v[k].z; }
+  return 0;
+}
+
+glome_sb* glome_sb_new(void) { return new glome_sb(); }
+void glome_sb_free(glome_sb* sb) { delete sb; }
+const char* glome_sb_last_error(const glome_sb* sb) { return sb ? sb->err.c_str() : "null builder"; }
+
+int32_t glome_sb_sphere(glome_sb* sb, const double c[3], double r) { return guard(sb, [&] { return sb->graph.sphere(d3(c), r); }); }
+int32_t glome_sb_triangle(glome_sb* sb, const double p[9]) { return guard(sb, [&] { return sb->graph.triangle(d3(p), d3(p + 3), d3(p + 6)); }); }
+int32_t glome_sb_trianglenorm(glome_sb* sb, const double p[9], const double n[9]) {
+  return guard(sb, [&] { return sb->graph.trianglenorm(d3(p), d3(p + 3), d3(p + 6), d3(n), d3(n + 3), d3(n + 6)); });
+}
+int32_t glome_sb_box(glome_sb* sb, const double a[3], const double b[3]) { return guard(sb, [&] { return sb->graph.box(d3(a), d3(b)); }); }
+int32_t glome_sb_plane(glome_sb* sb, const double pt[3], const double n[3]) { return guard(sb, [&] { return sb->graph.plane(d3(pt), d3(n)); }); }
+int32_t glome_sb_plane_offset(glome_sb* sb, const double n[3], double off) { return guard(sb, [&] { return sb->graph.plane_offset(d3(n), off); }); }
+int32_t glome_sb_disc(glome_sb* sb, const double pos[3], const double n[3], double r) { return guard(sb, [&] { return sb->graph.disc(d3(pos), d3(n), r); }); }
+int32_t glome_sb_cylinder(glome_sb* sb, const double p1[3], const double p2[3], double r) { return guard(sb, [&] { return sb->graph.cylinder(d3(p1), d3(p2), r); }); }
+int32_t glome_sb_cone(glome_sb* sb, const double p1[3], double r1, const double p2[3], double r2) { return guard(sb, [&] { return sb->graph.cone(d3(p1), r1, d3(p2), r2); }); }
+int32_t glome_sb_group(glome_sb* sb, const int32_t* ids, int n) { return guard(sb, [&] { return sb->graph.group(ids_of(ids, n)); }); }
+int32_t glome_sb_transform(glome_sb* sb, int32_t id, const double* xfms, int n) {
+  return guard(sb, [&] {
+    if (n < 0 || (n > 0 && !xfms)) throw std::invalid_argument("bad transform list");
+    std::vector<Xf> xs;
+    for (int k = 0; k < n; k++) xs.push_back(xf_from(xfms + 24 * k));
+    return sb->graph.transform(id, xs);
+  });
+}
+int32_t glome_sb_difference(glome_sb* sb, int32_t a, int32_t b) { return guard(sb, [&] { return sb->graph.difference(a, b); }); }
+int32_t glome_sb_intersection(glome_sb* sb, const int32_t* ids, int n) { return guard(sb, [&] { return sb->graph.intersection(ids_of(ids, n)); }); }
+int32_t glome_sb_bih(glome_sb* sb, const int32_t* ids, int n) { return guard(sb, [&] { return sb->graph.bih(ids_of(ids, n)); }); }
+int32_t glome_sb_mesh(glome_sb* sb, const double* verts, int nv, const double* norms, int nn, const int32_t* tris, int nt, const int32_t* mats, int nm) {
+  return guard(sb, [&] {
+    if (nv < 0 || nn < 0 || nt < 0 || nm < 0 || (nv && !verts) || (nn && !norms) || (nt && !tris) || (nm && !mats)) throw std::invalid_argument("bad mesh arrays");
+    std::vector<D3> V, N;
+    for (int k = 0; k < nv; k++) V.push_back(d3(verts + 3 * k));
+    for (int k = 0; k < nn; k++) N.push_back(d3(norms + 3 * k));
+    std::vector<MeshTri> T;
+    for (int k = 0; k < nt; k++) { const int32_t* t = tris + 8 * k; T.push_back(MeshTri{t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]}); }
+    return sb->graph.mesh(std::move(V), std::move(N), std::move(T), std::vector<int>(mats, mats + nm));
+  });
+}
+int32_t glome_sb_tex(glome_sb* sb, int32_t id, int32_t material) { return guard(sb, [&] { return sb->graph.wrap(K_TEX, id, material); }); }
+int32_t glome_sb_tag(glome_sb* sb, int32_t id) { return guard(sb, [&] { return sb->graph.wrap(K_TAG, id); }); }
+int32_t glome_sb_noshadow(glome_sb* sb, int32_t id) { return guard(sb, [&] { return sb->graph.wrap(K_NOSHADOW, id); }); }
+int32_t glome_sb_onlyshadow(glome_sb* sb, int32_t id) { return guard(sb, [&] { return sb->graph.wrap(K_ONLYSHADOW, id); }); }
+int32_t glome_sb_bound_object(glome_sb* sb, int32_t a, int32_t b) { return guard(sb, [&] { return sb->graph.bound_object(a, b, false); }); }
+int32_t glome_sb_innerbound(glome_sb* sb, int32_t a, int32_t b) { return guard(sb, [&] { return sb->graph.bound_object(a, b, true); }); }
+int32_t glome_sb_flatten_transform(glome_sb* sb, int32_t id) { return guard(sb, [&] { return sb->graph.flatten_transform_item(id); }); }
+int32_t glome_sb_tolist(glome_sb* sb, int32_t id) { return guard(sb, [&] { return sb->graph.tolist_node(id); }); }
+
+int32_t glome_sb_material_surface(glome_sb* sb, const double color[3], double alpha, double amb, double kd, double ks, double shine) {
+  return guard(sb, [&] { Mat m; m.kind = MAT_SURFACE; m.color[0] = color[0]; m.color[1] = color[1]; m.color[2] = color[2]; m.alpha = alpha; m.amb = amb; m.kd = kd; m.ks = ks; m.shine = shine; return sb->graph.add_mat(m); });
+}
+int32_t glome_sb_material_reflect(glome_sb* sb, double refl) { return guard(sb, [&] { Mat m; m.kind = MAT_REFLECT; m.refl = refl; return sb->graph.add_mat(m); }); }
+int32_t glome_sb_material_refract(glome_sb* sb, double refl, double refr, double ior) {
+  return guard(sb, [&] { Mat m; m.kind = MAT_REFRACT; m.refl = refl; m.refr = refr; m.ior = ior; return sb->graph.add_mat(m); });
+}
+int32_t glome_sb_material_layers(glome_sb* sb, const int32_t* mats, int n) {
+  return guard(sb, [&] { Mat m; m.kind = MAT_LAYERS; m.kids = ids_of(mats, n); for (int k : m.kids) sb->graph.check_mat(k); return sb->graph.add_mat(m); });
+}
+int32_t glome_sb_material_blend(glome_sb* sb, int32_t a, int32_t b, double weight) {
+  return guard(sb, [&] { sb->graph.check_mat(a); sb->graph.check_mat(b); Mat m; m.kind = MAT_BLEND; m.a = a; m.b = b; m.weight = weight; return sb->graph.add_mat(m); });
+}
+
+int glome_sb_primcount(glome_sb* sb, int32_t id, long out3[3]) {
+  return guard(sb, [&] { out3[0] = out3[1] = out3[2] = 0; sb->graph.primcount(id, out3); return 0; });
+}
+int glome_sb_bound(glome_sb* sb, int32_t id, double out6[6]) {
+  return guard(sb, [&] { Box3 b = sb->graph.bound(id); out6[0] = b.lo.x; out6[1] = b.lo.y; out6[2] = b.lo.z; out6[3] = b.hi.x; out6[4] = b.hi.y; out6[5] = b.hi.z; return 0; });
+}
+long glome_sb_bih_dump(glome_sb* sb, int32_t id, long cap, double* lsplit, double* rsplit, int* axis, int* nleaf, int32_t* leaf_prims, long cap_prims) {
+  if (!sb) return GLOME_E_INVALID;
+  try {
+    const Node& n = sb->graph.at(id);
+    if (n.kind != K_BIH) throw std::invalid_argument("not a Bih");
+    const BihTree& T = *n.bih;
+    long cnt = 0, np = 0;
+    std::vector<int> st{0};
+    while (!st.empty()) {  // preorder, left before right
+      const BihTree::Node& bn = T.nodes[st.back()];
+      st.pop_back();
+      if (cnt < cap) {
+        axis[cnt] = bn.leaf ? -1 : bn.axis; nleaf[cnt] = bn.leaf ? (int)bn.items.size() : 0;
+        lsplit[cnt] = bn.leaf ? 0 : bn.lsplit; rsplit[cnt] = bn.leaf ? 0 : bn.rsplit;
+      }
+      cnt++;
+      if (bn.leaf) { for (int it : bn.items) { if (np < cap_prims) leaf_prims[np] = it; np++; } }
+      else { st.push_back(bn.right); st.push_back(bn.left); }
+    }
+    return cnt;
+  } catch (const std::exception& e) { sb->err = e.what(); return GLOME_E_INVALID; }
+}
+
+}  // extern "C"

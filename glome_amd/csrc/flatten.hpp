@@ -1,0 +1,359 @@
+// flatten.hpp -- turn the host scene graph (host_graph.hpp) into the packed pools of rt_types.h.
+// This is the "Haskell host flattens the scene graph to packed SoA device buffers" step; it is pure host
+// code (no HIP) so the layout can be inspected and tested without a GPU.
+#pragma once
+#include <cstring>
+#include <map>
+#include <unordered_map>
+
+#include "host_graph.hpp"
+#include "rt_types.h"
+
+namespace glome {
+
+struct FlatScene {
+  std::vector<U4> recs;
+  std::vector<F4> spheres, tris, trinorms, boxes, planes, discs, quadrics, xfms, bihhdr, bihnodes, meshhdr, meshnodes, mtris, mats;
+  std::vector<U4> mtrimeta, entries;
+  std::vector<uint32_t> matkids;
+  uint32_t root_rec = 0;
+  uint32_t tier = 1;
+  int nesting_depth = 0, max_bih_depth = 0, max_mesh_depth = 0;
+  int64_t n_other_prims = 0;
+  std::string why_generic;  // why the flat tier was not chosen
+};
+
+inline float f32(double d) { return (float)d; }
+inline float as_float_bits(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+inline F4 mk4(double x, double y, double z, double w) { return F4{f32(x), f32(y), f32(z), f32(w)}; }
+inline F4 mk4u(double x, double y, double z, uint32_t w) { return F4{f32(x), f32(y), f32(z), as_float_bits(w)}; }
+// split planes are rounded outward so that an fp32 plane never cuts into the objects it bounds
+inline float round_up(double d) { float f = (float)d; return ((double)f < d) ? std::nextafterf(f, INFINITY) : f; }
+inline float round_down(double d) { float f = (float)d; return ((double)f > d) ? std::nextafterf(f, -INFINITY) : f; }
+
+class Flattener {
+ public:
+  Flattener(const Graph& g, FlatScene& out) : G(g), F(out) {}
+
+  void run(int root) {
+    emit_materials();
+    // generic representation: always built (the per-ray batch seams and the generic tier use it)
+    U4 r = emit(root);
+    F.root_rec = (uint32_t)F.recs.size();
+    F.recs.push_back(r);
+    F.nesting_depth = depth_of(root);
+    if (F.nesting_depth > kGenericDepth) throw limit_error("scene nests composites deeper than the device interpreter supports (" + std::to_string(F.nesting_depth) + " > " + std::to_string(kGenericDepth) + ")");
+    // flat tier: root program of simple entries
+    F.tier = 0;
+    collect_entries(root, 0, 0, 0);
+    if (F.tier == 0 && F.max_bih_depth > kFlatStack) { F.tier = 1; F.why_generic = "BIH deeper than the LDS stack"; }
+    if (F.tier == 0 && F.max_mesh_depth > kFlatStack) { F.tier = 1; F.why_generic = "Mesh BVH deeper than the LDS stack"; }
+    if (F.tier != 0) F.entries.clear();
+    pad();
+  }
+
+ private:
+  const Graph& G;
+  FlatScene& F;
+  std::unordered_map<int, U4> memo;  // host node id -> record value (shared subtrees are emitted once)
+
+  static bool is_prim(int k) { return k >= K_SPHERE && k <= K_CONE; }
+
+  void pad() {  // never hand a null pool to a kernel
+    auto p4 = [](std::vector<F4>& v) { if (v.empty()) v.push_back(F4{0, 0, 0, 0}); };
+    p4(F.spheres); p4(F.tris); p4(F.trinorms); p4(F.boxes); p4(F.planes); p4(F.discs); p4(F.quadrics); p4(F.xfms);
+    p4(F.bihhdr); p4(F.bihnodes); p4(F.meshhdr); p4(F.meshnodes); p4(F.mtris); p4(F.mats);
+    if (F.mtrimeta.empty()) F.mtrimeta.push_back(U4{0, 0, 0, 0});
+    if (F.entries.empty()) F.entries.push_back(U4{0, 0, 0, 0});
+    if (F.matkids.empty()) F.matkids.push_back(0);
+  }
+
+  void emit_materials() {
+    for (const Mat& m : G.mats) {
+      uint32_t a = 0, b = 0;
+      F4 m1{0, 0, 0, 0}, m2{0, 0, 0, 0};
+      float w = 0;
+      switch (m.kind) {
+        case MAT_SURFACE: m1 = mk4(m.color[0], m.color[1], m.color[2], m.alpha); m2 = mk4(m.amb, m.kd, m.ks, m.shine); break;
+        case MAT_REFLECT: m1 = mk4(m.refl, 0, 0, 0); break;
+        case MAT_REFRACT: m1 = mk4(m.refl, m.refr, m.ior, 0); break;
+        case MAT_LAYERS: a = (uint32_t)F.matkids.size(); b = (uint32_t)m.kids.size(); for (int k : m.kids) F.matkids.push_back((uint32_t)k); break;
+        case MAT_BLEND: a = (uint32_t)m.a; b = (uint32_t)m.b; w = f32(m.weight); break;
+      }
+      F.mats.push_back(F4{as_float_bits((uint32_t)m.kind), as_float_bits(a), as_float_bits(b), w});
+      F.mats.push_back(m1);
+      F.mats.push_back(m2);
+    }
+    if (mat_nest_max() > kMaxMatNest) throw limit_error("material Blend/AdditiveLayers nesting deeper than the device shader supports");
+    if (G.mats.size() > 65534) throw limit_error("more than 65534 materials");
+  }
+  int mat_nest(int m, int guard) const {
+    if (guard > 64) throw scene_error("material graph is cyclic");
+    const Mat& M = G.mats[m];
+    if (M.kind == MAT_LAYERS) { int d = 0; for (int k : M.kids) d = std::max(d, mat_nest(k, guard + 1)); return d + 1; }
+    if (M.kind == MAT_BLEND) return 1 + std::max(mat_nest(M.a, guard + 1), mat_nest(M.b, guard + 1));
+    return 0;
+  }
+  int mat_nest_max() const { int d = 0; for (size_t m = 0; m < G.mats.size(); m++) d = std::max(d, mat_nest((int)m, 0)); return d; }
+
+  // composite nesting depth (Tex / Tag / NoShadow / OnlyShadow wrappers are free: the interpreter loops over them)
+  int depth_of(int id) const {
+    const Node& n = G.at(id);
+    switch (n.kind) {
+      case K_LIST: case K_ISECT: { int d = 0; for (int k : n.kids) d = std::max(d, depth_of(k)); return d + 1; }
+      case K_INSTANCE: return depth_of(n.a) + 1;
+      case K_DIFF: case K_BOUND: case K_INNERBOUND: return std::max(depth_of(n.a), depth_of(n.b)) + 1;
+      case K_BIH: { int d = 0; for (auto& bn : n.bih->nodes) for (int k : bn.items) d = std::max(d, depth_of(k)); return d + 1; }
+      case K_MESH: return 1;
+      case K_TEX: case K_TAG: case K_NOSHADOW: case K_ONLYSHADOW: return depth_of(n.a);
+      default: return 0;
+    }
+  }
+
+  // ---- primitive pools ----
+  uint32_t emit_tri(const double* p) {  // (p1, e1, e2, n) evaluated in double, rounded once
+    D3 p1{p[0], p[1], p[2]}, p2{p[3], p[4], p[5]}, p3{p[6], p[7], p[8]};
+    D3 e1 = p2 - p1, e2 = p3 - p1;
+    D3 n = normalize(cross(e1, e2));  // vnorm $ vcross e1 e2, Triangle.hs:73
+    uint32_t idx = (uint32_t)(F.tris.size() / 3);
+    F.tris.push_back(mk4(p1.x, p1.y, p1.z, n.x));
+    F.tris.push_back(mk4(e1.x, e1.y, e1.z, n.y));
+    F.tris.push_back(mk4(e2.x, e2.y, e2.z, n.z));
+    return idx;
+  }
+  U4 emit_prim(const Node& n) {
+    const double* p = n.p;
+    U4 r{0, 0, 0, (uint32_t)n.uid};
+    switch (n.kind) {
+      case K_SPHERE: r.x = R_SPHERE; r.y = (uint32_t)F.spheres.size(); F.spheres.push_back(mk4(p[0], p[1], p[2], p[3])); break;
+      case K_TRI: r.x = R_TRI; r.y = emit_tri(p); break;
+      case K_TRIN: {  // self-contained 6-word block in the trinorms heap
+        D3 p1{p[0], p[1], p[2]}, p2{p[3], p[4], p[5]}, p3{p[6], p[7], p[8]};
+        D3 e1 = p2 - p1, e2 = p3 - p1;
+        r.x = R_TRIN; r.y = (uint32_t)F.trinorms.size();
+        F.trinorms.push_back(mk4(p1.x, p1.y, p1.z, 0)); F.trinorms.push_back(mk4(e1.x, e1.y, e1.z, 0)); F.trinorms.push_back(mk4(e2.x, e2.y, e2.z, 0));
+        for (int k = 0; k < 3; k++) F.trinorms.push_back(mk4(p[9 + 3 * k], p[10 + 3 * k], p[11 + 3 * k], 0));
+        F.n_other_prims++;
+        break;
+      }
+      case K_BOX: r.x = R_BOX; r.y = (uint32_t)(F.boxes.size() / 2); F.boxes.push_back(mk4(p[0], p[1], p[2], 0)); F.boxes.push_back(mk4(p[3], p[4], p[5], 0)); F.n_other_prims++; break;
+      case K_PLANE: r.x = R_PLANE; r.y = (uint32_t)F.planes.size(); F.planes.push_back(mk4(p[0], p[1], p[2], p[3])); F.n_other_prims++; break;
+      case K_DISC: r.x = R_DISC; r.y = (uint32_t)(F.discs.size() / 2); F.discs.push_back(mk4(p[0], p[1], p[2], p[6])); F.discs.push_back(mk4(p[3], p[4], p[5], 0)); F.n_other_prims++; break;
+      case K_CYL: r.x = R_CYL; r.y = (uint32_t)F.quadrics.size(); F.quadrics.push_back(mk4(p[0], p[1], p[2], 0)); F.n_other_prims++; break;
+      case K_CONE: r.x = R_CONE; r.y = (uint32_t)F.quadrics.size(); F.quadrics.push_back(mk4(p[0], p[1], p[2], p[3])); F.n_other_prims++; break;
+      default: break;
+    }
+    return r;
+  }
+
+  // Peel Tex / Tag / NoShadow / OnlyShadow wrappers off a node.  Up to two Tex levels fold into a primitive's
+  // own stack (innermost first, id+1, 16 bits each); flags fold into the record.
+  struct Peeled { int id; uint32_t flags; uint32_t own; int ntex; };
+  Peeled peel(int id) const {
+    Peeled p{id, 0, 0, 0};
+    std::vector<int> texs;  // outermost first
+    for (;;) {
+      const Node& n = G.at(p.id);
+      if (n.kind == K_TEX) { texs.push_back(n.mat); p.id = n.a; }
+      else if (n.kind == K_TAG) p.id = n.a;
+      else if (n.kind == K_NOSHADOW) { p.flags |= RF_NOSHADOW; p.id = n.a; }
+      else if (n.kind == K_ONLYSHADOW) { p.flags |= RF_NOVIS; p.id = n.a; }
+      else break;
+    }
+    p.ntex = (int)texs.size();
+    // head of the stack = innermost Tex = last in `texs`
+    if (p.ntex <= 2) for (int k = 0; k < p.ntex; k++) p.own |= (uint32_t)(texs[p.ntex - 1 - k] + 1) << (16 * k);
+    return p;
+  }
+
+  // emit(id) -> the record VALUE for a reference to node id (children are written into F.recs / pools)
+  U4 emit(int id) {
+    auto it = memo.find(id);
+    if (it != memo.end()) return it->second;
+    const Node& n = G.at(id);
+    U4 r{R_VOID, 0, 0, (uint32_t)n.uid};
+    switch (n.kind) {
+      case K_VOID: break;
+      case K_SPHERE: case K_TRI: case K_TRIN: case K_BOX: case K_PLANE: case K_DISC: case K_CYL: case K_CONE: r = emit_prim(n); break;
+      case K_TEX: case K_TAG: case K_NOSHADOW: case K_ONLYSHADOW: {
+        Peeled p = peel(id);
+        const Node& c = G.at(p.id);
+        if (is_prim(c.kind) && p.ntex <= 2) {  // fold into the primitive's record
+          r = emit(p.id);
+          r.x |= p.flags; r.z = p.own;
+        } else if (n.kind == K_TEX) {  // explicit Tex record over the child
+          U4 child = emit(n.a);
+          r.x = R_TEX; r.y = slot(child); r.z = (uint32_t)n.mat;
+        } else {  // Tag / NoShadow / OnlyShadow over a composite: flags on a copy of the child's record
+          r = emit(n.a);
+          if (n.kind == K_NOSHADOW) r.x |= RF_NOSHADOW;
+          if (n.kind == K_ONLYSHADOW) r.x |= RF_NOVIS;
+        }
+        break;
+      }
+      case K_LIST: case K_ISECT: {
+        std::vector<U4> kids;
+        for (int k : n.kids) kids.push_back(emit(k));
+        r.x = (n.kind == K_LIST) ? R_LIST : R_ISECT;
+        r.y = (uint32_t)F.recs.size(); r.z = (uint32_t)kids.size();
+        F.recs.insert(F.recs.end(), kids.begin(), kids.end());
+        break;
+      }
+      case K_INSTANCE: {
+        U4 child = emit(n.a);
+        r.x = R_INSTANCE; r.y = slot(child); r.z = (uint32_t)(F.xfms.size() / 6);
+        for (int k = 0; k < 3; k++) F.xfms.push_back(mk4(n.xf.f.m[4 * k], n.xf.f.m[4 * k + 1], n.xf.f.m[4 * k + 2], n.xf.f.m[4 * k + 3]));
+        for (int k = 0; k < 3; k++) F.xfms.push_back(mk4(n.xf.i.m[4 * k], n.xf.i.m[4 * k + 1], n.xf.i.m[4 * k + 2], n.xf.i.m[4 * k + 3]));
+        break;
+      }
+      case K_DIFF: case K_BOUND: case K_INNERBOUND: {
+        U4 a = emit(n.a), b = emit(n.b);
+        r.x = n.kind == K_DIFF ? R_DIFF : (n.kind == K_BOUND ? R_BOUND : R_INNERBOUND);
+        r.y = slot(a); r.z = slot(b);
+        break;
+      }
+      case K_BIH: r = emit_bih(n); break;
+      case K_MESH: r = emit_mesh(n); break;
+    }
+    memo[id] = r;
+    return r;
+  }
+  uint32_t slot(const U4& v) { F.recs.push_back(v); return (uint32_t)F.recs.size() - 1; }
+
+  // BIH: nodes in preorder; leaf items become consecutive records, and (for homogeneous leaves) consecutive pool
+  // entries, so a leaf is one contiguous run of 48-byte triangles / 16-byte spheres.
+  U4 emit_bih(const Node& n) {
+    const BihTree& T = *n.bih;
+    F.max_bih_depth = std::max(F.max_bih_depth, T.depth);
+    // classify
+    bool all_tri = true, all_sph = true, all_simple = true;
+    for (auto& bn : T.nodes) for (int it : bn.items) {
+      Peeled p = peel(it);
+      const Node& c = G.at(p.id);
+      bool simple = is_prim(c.kind) && p.ntex <= 2;
+      all_simple &= simple;
+      all_tri &= simple && c.kind == K_TRI && p.flags == 0;
+      all_sph &= simple && c.kind == K_SPHERE && p.flags == 0;
+    }
+    uint32_t cls = all_tri ? BC_TRI : (all_sph ? BC_SPHERE : (all_simple ? BC_SIMPLE : BC_GENERIC));
+    uint32_t hdr = (uint32_t)(F.bihhdr.size() / 2);
+    uint32_t base = (uint32_t)F.bihnodes.size();
+    F.bihhdr.push_back(mk4u(round_down(T.bb.lo.x), round_down(T.bb.lo.y), round_down(T.bb.lo.z), base));
+    F.bihhdr.push_back(mk4u(round_up(T.bb.hi.x), round_up(T.bb.hi.y), round_up(T.bb.hi.z), cls));
+    F.bihnodes.resize(base + T.nodes.size());
+    if (base + T.nodes.size() >= (1u << 30)) throw limit_error("too many BIH nodes");
+    for (size_t k = 0; k < T.nodes.size(); k++) {
+      const BihTree::Node& bn = T.nodes[k];
+      if (!bn.leaf) {
+        F.bihnodes[base + k] = F4{round_up(bn.lsplit), round_down(bn.rsplit), as_float_bits((uint32_t)bn.axis | ((base + (uint32_t)bn.left) << 2)),
+                                  as_float_bits(base + (uint32_t)bn.right)};
+        continue;
+      }
+      // leaf: emit the items fresh (no memo) so records and pool entries are consecutive
+      std::vector<U4> items;
+      uint32_t first_prim = 0;
+      for (size_t q = 0; q < bn.items.size(); q++) {
+        int it = bn.items[q];
+        U4 rec;
+        if (cls == BC_GENERIC) rec = emit(it);
+        else {
+          Peeled p = peel(it);
+          rec = emit_prim(G.at(p.id));
+          rec.x |= p.flags; rec.z = p.own;
+        }
+        if (q == 0) first_prim = rec.y;
+        items.push_back(rec);
+      }
+      uint32_t first_rec = (uint32_t)F.recs.size();
+      F.recs.insert(F.recs.end(), items.begin(), items.end());
+      if (bn.items.size() >= (1u << 30)) throw limit_error("BIH leaf too large");
+      F.bihnodes[base + k] = F4{as_float_bits(first_prim), 0.0f, as_float_bits(3u | ((uint32_t)bn.items.size() << 2)), as_float_bits(first_rec)};
+    }
+    return U4{R_BIH, hdr, 0, (uint32_t)n.uid};
+  }
+
+  U4 emit_mesh(const Node& n) {
+    const MeshData& M = *n.mesh;
+    F.max_mesh_depth = std::max(F.max_mesh_depth, M.depth);
+    uint32_t hdr = (uint32_t)(F.meshhdr.size() / 2);
+    uint32_t nbase = (uint32_t)(F.meshnodes.size() / 4);
+    // node index remap: branches only (leaves are encoded in the parent's ref)
+    std::vector<uint32_t> bidx(M.nodes.size(), 0);
+    uint32_t nb = 0;
+    for (size_t k = 0; k < M.nodes.size(); k++) if (!M.nodes[k].leaf) bidx[k] = nbase + nb++;
+    F.meshnodes.resize((size_t)4 * (nbase + nb));
+    std::vector<uint32_t> ref(M.nodes.size(), 0);
+    // leaves first (preorder), so triangle runs follow traversal order
+    for (size_t k = 0; k < M.nodes.size(); k++) {
+      const MeshData::Node& mn = M.nodes[k];
+      if (!mn.leaf) { ref[k] = bidx[k]; continue; }
+      uint32_t first = (uint32_t)(F.mtris.size() / 3), count = (uint32_t)mn.tris.size();
+      if (first + count >= (1u << 27)) throw limit_error("mesh has too many triangles");
+      for (size_t q = 0; q < mn.tris.size(); q++) {
+        const MeshTri& t = M.tris[mn.tris[q]];
+        const D3 &a = M.verts[t.a], &b = M.verts[t.b], &c = M.verts[t.c];
+        D3 e1 = b - a, e2 = c - a, nn = normalize(cross(e1, e2));
+        F.mtris.push_back(mk4(a.x, a.y, a.z, nn.x));
+        F.mtris.push_back(mk4(e1.x, e1.y, e1.z, nn.y));
+        F.mtris.push_back(mk4(e2.x, e2.y, e2.z, nn.z));
+        U4 meta{0, 0, q == 0 ? count : 0u, 0};
+        if (t.na != -1) {
+          meta.x = (uint32_t)F.trinorms.size() + 1;
+          for (int ni : {t.na, t.nb, t.nc}) F.trinorms.push_back(mk4(M.norms[ni].x, M.norms[ni].y, M.norms[ni].z, 0));
+        }
+        if (t.tex != -1) meta.y = (uint32_t)M.mats[t.tex] + 1;
+        F.mtrimeta.push_back(meta);
+      }
+      if (count == 0) { F.mtrimeta.push_back(U4{0, 0, 0, 0}); for (int q = 0; q < 3; q++) F.mtris.push_back(F4{0, 0, 0, 0}); }  // keep `first` addressable
+      ref[k] = 0x80000000u | ((count >= 15 ? 15u : count) << 27) | first;
+    }
+    for (size_t k = 0; k < M.nodes.size(); k++) {
+      const MeshData::Node& mn = M.nodes[k];
+      if (mn.leaf) continue;
+      F4* o = &F.meshnodes[(size_t)4 * bidx[k]];
+      // boxes rounded outward
+      o[0] = mk4u(round_down(mn.lbb.lo.x), round_down(mn.lbb.lo.y), round_down(mn.lbb.lo.z), ref[mn.left]);
+      o[1] = mk4(round_up(mn.lbb.hi.x), round_up(mn.lbb.hi.y), round_up(mn.lbb.hi.z), 0);
+      o[2] = mk4u(round_down(mn.rbb.lo.x), round_down(mn.rbb.lo.y), round_down(mn.rbb.lo.z), ref[mn.right]);
+      o[3] = mk4(round_up(mn.rbb.hi.x), round_up(mn.rbb.hi.y), round_up(mn.rbb.hi.z), 0);
+    }
+    F.meshhdr.push_back(mk4u(round_down(M.bb.lo.x), round_down(M.bb.lo.y), round_down(M.bb.lo.z), ref[0]));
+    F.meshhdr.push_back(mk4(round_up(M.bb.hi.x), round_up(M.bb.hi.y), round_up(M.bb.hi.z), 0));
+    return U4{R_MESH, hdr, 0, (uint32_t)n.uid};
+  }
+
+  // ---- flat tier root program ----
+  // Walk Tex / Tag / flag wrappers and lists from the root; every leaf of that walk must be a simple primitive,
+  // a homogeneous BIH or a mesh.  `incoming` = texture stack pushed by the wrappers above the entry.
+  void collect_entries(int id, uint32_t incoming, int nin, uint32_t flags) {
+    if (F.tier != 0) return;
+    const Node& n = G.at(id);
+    switch (n.kind) {
+      case K_VOID: return;
+      case K_TAG: collect_entries(n.a, incoming, nin, flags); return;
+      case K_NOSHADOW: collect_entries(n.a, incoming, nin, flags | RF_NOSHADOW); return;
+      case K_ONLYSHADOW: collect_entries(n.a, incoming, nin, flags | RF_NOVIS); return;
+      case K_TEX:
+        if (nin >= 2) { F.tier = 1; F.why_generic = "more than two Tex levels above a root entry"; return; }
+        // `tex:texs`: the inner Tex is pushed later, so it sits in front
+        collect_entries(n.a, (incoming << 16) | (uint32_t)(n.mat + 1), nin + 1, flags);
+        return;
+      case K_LIST: for (int k : n.kids) collect_entries(k, incoming, nin, flags); return;
+      case K_BIH: {
+        U4 r = emit(id);
+        uint32_t cls;
+        std::memcpy(&cls, &F.bihhdr[2 * r.y + 1].w, 4);
+        if (cls == BC_GENERIC) { F.tier = 1; F.why_generic = "BIH with composite items"; return; }
+        F.entries.push_back(U4{slot(r), incoming, flags, 0});
+        return;
+      }
+      case K_MESH: F.entries.push_back(U4{slot(emit(id)), incoming, flags, 0}); return;
+      default:
+        if (is_prim(n.kind) && n.kind != K_CYL && n.kind != K_CONE) { F.entries.push_back(U4{slot(emit(id)), incoming, flags, 0}); return; }
+        F.tier = 1; F.why_generic = std::string("root reaches a ") + kind_name(n.kind);
+        return;
+    }
+  }
+};
+
+}  // namespace glome

@@ -1,0 +1,703 @@
+// glome_device.hip -- HIP kernels for gfx950 and the device half of the C ABI (include/glome_hip.h):
+// context, scene commit/upload, the per-ray batch seams and the whole-frame render.
+//
+// Kernel catalogue
+//   k_render_flat<MAXD,FAITHFUL,COUNT>  persistent: one wave pulls 64-pixel work items (8x8 blocks of a 65x65
+//                                       reference tile, Glome.hs:371-386) from an atomic queue; per lane:
+//                                       primary ray -> BIH/Mesh closest hit (LDS stack) -> shadow rays ->
+//                                       shade -> secondary rays.  No ray streams in HBM at all.
+//   k_render_generic<MAXD,COUNT>        same loop over the generic interpreter (rt_generic.hpp)
+//   k_rayint_batch / k_shadow_batch / k_inside_batch   the `Solid` method seams on SoA ray streams
+//   k_tiles_pack / k_tiles_blit         Tile payload <-> frame (blitTile, Glome.hs:353-358)
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/glome_hip.h"
+#include "capi_shared.hpp"
+#include "flatten.hpp"
+#include "rt_device.hpp"
+#include "rt_generic.hpp"
+
+using namespace glome;
+
+// ------------------------------------------------------------------------------------------------ tiers
+// ANALYSIS = the reference's exact node-visit order (no ordered early-out, Bih.hs:332-368) + work counters; it
+// backs the `faithful` / `count_work` render params (byte-model measurement, parity tests).  The production
+// variant traverses with early-out and counts rays only.
+template <bool ANALYSIS, bool FULL_>
+struct FlatTier {
+  static constexpr bool FULL = FULL_;  // false: lean kernel -- no out-of-line calls at all (no secondary rays, no Blend/Layers)
+  const DScene& S;
+  const DLight* lights;
+  int nlights;
+  LaneStack stk;
+  Cnt cnt;
+  __device__ __forceinline__ HitG closest(const Ray& r, float tmax) {
+    Cand c = closest_flat<ANALYSIS, ANALYSIS>(S, r, tmax, stk, cnt);
+    return finalize_flat(S, r, c);
+  }
+  __device__ __forceinline__ bool occluded(const Ray& r, float d) { return occluded_flat<ANALYSIS>(S, r, d, stk, cnt); }
+  __device__ __noinline__ HitG closest_ni(const Ray& r, float tmax) { return closest(r, tmax); }
+  __device__ __noinline__ bool occluded_ni(const Ray& r, float d) { return occluded(r, d); }
+};
+struct GenericTier {
+  static constexpr bool FULL = true;
+  const DScene& S;
+  const DLight* lights;
+  int nlights;
+  Cnt cnt;
+  unsigned int err = 0;
+  __device__ __forceinline__ HitG closest(const Ray& r, float tmax) {
+    GCtx<true> g{S, cnt, err};
+    HitG h = rayint_g<kGenericDepth>(g, ldu4(S.recs, S.root_rec), r, tmax, (TexStack)0);
+    err = g.err;
+    return h;
+  }
+  __device__ __forceinline__ bool occluded(const Ray& r, float d) {
+    GCtx<true> g{S, cnt, err};
+    bool o = shadow_g<kGenericDepth>(g, ldu4(S.recs, S.root_rec), r, d);
+    err = g.err;
+    return o;
+  }
+  __device__ __forceinline__ HitG closest_ni(const Ray& r, float tmax) { return closest(r, tmax); }  // rayint_g is out of line already
+  __device__ __forceinline__ bool occluded_ni(const Ray& r, float d) { return occluded(r, d); }
+};
+
+__device__ __forceinline__ LaneStack lane_stack(uint32_t* lds, int cap) {
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t* base = lds + (size_t)wave * cap * 64 * 3;
+  LaneStack s;
+  s.node = base + lane;
+  s.nearv = (float*)(base + cap * 64) + lane;
+  s.farv = (float*)(base + 2 * cap * 64) + lane;
+  s.cap = cap;
+  return s;
+}
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned int v) {
+  unsigned long long s = v;
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  return s;
+}
+__device__ __forceinline__ void flush_counters(DCounters* c, const Cnt& cnt, unsigned int err) {
+  unsigned long long a = wave_sum(cnt.primary), b = wave_sum(cnt.shadow), s = wave_sum(cnt.secondary);
+  unsigned long long n = wave_sum(cnt.bih), m = wave_sum(cnt.mesh), p = wave_sum(cnt.prim);
+  unsigned long long e = wave_sum(err);
+  if ((threadIdx.x & 63) == 0) {
+    if (a) atomicAdd(&c->rays_primary, a);
+    if (b) atomicAdd(&c->rays_shadow, b);
+    if (s) atomicAdd(&c->rays_secondary, s);
+    if (n) atomicAdd(&c->bih_nodes, n);
+    if (m) atomicAdd(&c->mesh_nodes, m);
+    if (p) atomicAdd(&c->prim_tests, p);
+    if (e) atomicOr(&c->error, 1u);
+  }
+}
+
+// work item w -> tile + 64 pixels.  A tile is cut into 8x8 blocks (coherent rays per wave); the pixels left over on
+// the right and bottom edges (65 = 8*8 + 1) are packed 64 at a time, so lanes are not wasted on partial blocks.
+__device__ __forceinline__ bool work_to_pixel(const DRenderArgs& A, uint32_t w, int lane, int& px, int& py) {
+  int lo = 0, hi = A.ntiles - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (A.tiles[mid].wave_base <= w) lo = mid; else hi = mid - 1;
+  }
+  DTile t = A.tiles[lo];
+  uint32_t j = w - t.wave_base;
+  uint32_t nbx = t.w >> 3, nby = t.h >> 3, nblk = nbx * nby;
+  int lx, ly;
+  if (j < nblk) {
+    lx = (j % nbx) * 8 + (lane & 7);
+    ly = (j / nbx) * 8 + (lane >> 3);
+  } else {
+    uint32_t i = (j - nblk) * 64 + lane;
+    uint32_t rw = t.w - 8 * nbx, rcount = rw * t.h;
+    if (i < rcount) { lx = 8 * nbx + i % rw; ly = i / rw; }
+    else {
+      uint32_t i2 = i - rcount, bw = 8 * nbx, bh = t.h - 8 * nby;
+      if (i2 >= bw * bh) return false;
+      lx = i2 % bw; ly = 8 * nby + i2 / bw;
+    }
+  }
+  px = t.x + lx; py = t.y + ly;
+  return true;
+}
+
+template <class TIER>
+__device__ __forceinline__ void render_loop(const DRenderArgs& A, TIER& T) {
+  int lane = threadIdx.x & 63;
+  for (;;) {
+    uint32_t w = 0;
+    if (lane == 0) w = atomicAdd(&A.counters->next_work, 1u);
+    w = __shfl(w, 0, 64);
+    if (w >= A.total_waves) break;
+    int px, py;
+    if (!work_to_pixel(A, w, lane, px, py)) continue;
+    float xc, yc;
+    get_coordsf(A.width, A.height, (float)px, (float)py, xc, yc);
+    Ray ray = primary_ray(A.cam, xc, yc);
+    T.cnt.primary++;
+    HitG h;
+    CA c = trace_primary(T, ray, kInf, A.maxdepth, &h);  // Trace.trace lights shader sld ray infinity maxdepth (Glome.hs:33)
+    float depth = h.hit ? h.t : kInf;      // ridepth
+    float r = c.r;
+    if (A.fog) r = r + (depth / 400);      // renderTile's debug fog (Glome.hs:174, Q20)
+    size_t o = (size_t)py * A.width + px;
+    float* out = A.out5 + o * 5;
+    out[0] = r; out[1] = c.g; out[2] = c.b; out[3] = c.a; out[4] = depth;
+    if (A.packed) A.packed[o] = rgbf(r * c.a, c.g * c.a, c.b * c.a);  // blitTile (Glome.hs:353-358)
+  }
+}
+
+template <bool ANALYSIS, bool FULL>
+__global__ void __launch_bounds__(64) k_render_flat(DRenderArgs A, int stack_cap) {
+  extern __shared__ uint32_t lds[];
+  FlatTier<ANALYSIS, FULL> T{A.S, A.lights, A.nlights, lane_stack(lds, stack_cap), Cnt()};
+  render_loop(A, T);
+  flush_counters(A.counters, T.cnt, 0);
+}
+__global__ void __launch_bounds__(64) k_render_generic(DRenderArgs A) {
+  GenericTier T{A.S, A.lights, A.nlights, Cnt()};
+  render_loop(A, T);
+  flush_counters(A.counters, T.cnt, T.err);
+}
+
+// ------------------------------------------------------------------------------------------------ batch seams
+struct RayStream { const float *ox, *oy, *oz, *dx, *dy, *dz, *tmax; };
+struct HitStream { float* t; int32_t* prim; float *nx, *ny, *nz; int32_t* tex4; };
+
+__device__ __forceinline__ void store_hit(const HitStream& H, size_t i, const HitG& h) {
+  if (H.t) H.t[i] = h.hit ? h.t : -1.0f;
+  if (H.prim) H.prim[i] = h.hit ? (int32_t)h.uid : -1;
+  if (H.nx) H.nx[i] = h.n.x;
+  if (H.ny) H.ny[i] = h.n.y;
+  if (H.nz) H.nz[i] = h.n.z;
+  if (H.tex4) {
+    TexStack ts = h.hit ? h.tex : 0;
+    for (int k = 0; k < 4; k++) { H.tex4[4 * i + k] = (int32_t)((ts >> (16 * k)) & 0xffffu) - 1; }
+  }
+}
+__device__ __forceinline__ Ray load_ray(const RayStream& R, size_t i) {
+  Ray r;
+  r.o = v3(R.ox[i], R.oy[i], R.oz[i]);
+  r.d = v3(R.dx[i], R.dy[i], R.dz[i]);
+  return r;
+}
+template <bool ANALYSIS>
+__global__ void __launch_bounds__(64) k_rayint_batch_flat(DScene S, size_t n, RayStream R, HitStream H, int stack_cap) {
+  extern __shared__ uint32_t lds[];
+  FlatTier<ANALYSIS, false> T{S, nullptr, 0, lane_stack(lds, stack_cap), Cnt()};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    store_hit(H, i, T.closest(load_ray(R, i), R.tmax[i]));
+}
+__global__ void __launch_bounds__(64) k_shadow_batch_flat(DScene S, size_t n, RayStream R, uint8_t* occ, int stack_cap) {
+  extern __shared__ uint32_t lds[];
+  FlatTier<false, false> T{S, nullptr, 0, lane_stack(lds, stack_cap), Cnt()};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    occ[i] = T.occluded(load_ray(R, i), R.tmax[i]) ? 1 : 0;
+}
+__global__ void __launch_bounds__(64) k_rayint_batch_generic(DScene S, size_t n, RayStream R, HitStream H, DCounters* c) {
+  GenericTier T{S, nullptr, 0, Cnt()};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    store_hit(H, i, T.closest(load_ray(R, i), R.tmax[i]));
+  if (T.err) atomicOr(&c->error, 1u);
+}
+__global__ void __launch_bounds__(64) k_shadow_batch_generic(DScene S, size_t n, RayStream R, uint8_t* occ, DCounters* c) {
+  GenericTier T{S, nullptr, 0, Cnt()};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    occ[i] = T.occluded(load_ray(R, i), R.tmax[i]) ? 1 : 0;
+  if (T.err) atomicOr(&c->error, 1u);
+}
+__global__ void __launch_bounds__(64) k_inside_batch(DScene S, size_t n, const float* px, const float* py, const float* pz, uint8_t* in, DCounters* c) {
+  Cnt cnt; unsigned int err = 0;
+  GCtx<true> g{S, cnt, err};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    in[i] = inside_g<kGenericDepth>(g, ldu4(S.recs, S.root_rec), v3(px[i], py[i], pz[i])) ? 1 : 0;
+  if (g.err) atomicOr(&c->error, 1u);
+}
+
+// ------------------------------------------------------------------------------------------------ tile transport
+__global__ void k_tiles_pack(const DTile* tiles, int ntiles, int width, const float* frame, float* payload) {
+  for (int t = blockIdx.y; t < ntiles; t += gridDim.y) {
+    DTile T = tiles[t];
+    int np = T.w * T.h;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < np * 5; i += gridDim.x * blockDim.x) {
+      int p = i / 5, k = i - p * 5;
+      size_t src = ((size_t)(T.y + p / T.w) * width + (T.x + p % T.w)) * 5 + k;
+      payload[(size_t)T.pix_base * 5 + i] = frame[src];
+    }
+  }
+}
+__global__ void k_tiles_blit(const DTile* tiles, int ntiles, int width, const float* payload, float* frame, uint32_t* packed) {
+  for (int t = blockIdx.y; t < ntiles; t += gridDim.y) {
+    DTile T = tiles[t];
+    int np = T.w * T.h;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < np; p += gridDim.x * blockDim.x) {
+      const float* s = payload + ((size_t)T.pix_base + p) * 5;
+      size_t o = (size_t)(T.y + p / T.w) * width + (T.x + p % T.w);
+      float r = s[0], g = s[1], b = s[2], a = s[3], d = s[4];
+      float* dst = frame + o * 5;
+      dst[0] = r; dst[1] = g; dst[2] = b; dst[3] = a; dst[4] = d;
+      if (packed) packed[o] = rgbf(r * a, g * a, b * a);
+    }
+  }
+}
+
+// ================================================================================================ host runtime
+struct glome_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipDeviceProp_t prop;
+  DCounters* d_counters = nullptr;
+  std::string err;
+  // tile tables cached per (w, h, blocksize, first, stride)
+  struct TileTable { std::vector<DTile> host; DTile* dev = nullptr; uint32_t total_waves = 0; int64_t pixels = 0; };
+  std::map<std::vector<int>, TileTable> tile_cache;
+};
+struct glome_scene {
+  glome_ctx* ctx = nullptr;
+  DScene dev{};
+  std::vector<void*> allocs;
+  glome_scene_info info{};
+  int stack_cap = 8;
+  bool has_secondary_mats = false, has_nested_mats = false;
+};
+
+static std::string g_global_error;
+#define HIPCHK(ctx, call)                                                                          \
+  do {                                                                                             \
+    hipError_t e_ = (call);                                                                        \
+    if (e_ != hipSuccess) {                                                                        \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                              \
+      return GLOME_E_HIP;                                                                          \
+    }                                                                                              \
+  } while (0)
+
+static std::vector<std::pair<int, int>> chunk(int size, int blocksize) {  // Glome.hs:371-377
+  std::vector<std::pair<int, int>> o;
+  int pos = 0;
+  for (;;) {
+    if (pos + blocksize >= size) { o.push_back({pos, size - pos}); break; }
+    o.push_back({pos, blocksize});
+    pos += blocksize;
+  }
+  return o;
+}
+static uint32_t tile_waves(int w, int h) {
+  uint32_t nbx = w >> 3, nby = h >> 3;
+  uint32_t rest = (uint32_t)(w * h) - nbx * nby * 64;
+  return nbx * nby + (rest + 63) / 64;
+}
+// tiles owned by (first, stride) in renderTiles' order: x chunks outer, y chunks inner (Glome.hs:382-384)
+static void owned_tiles(int width, int height, int blocksize, int first, int stride, std::vector<DTile>& out, uint32_t& total_waves, int64_t& pixels) {
+  out.clear(); total_waves = 0; pixels = 0;
+  int k = 0;
+  for (auto& xc : chunk(width, blocksize))
+    for (auto& yc : chunk(height, blocksize)) {
+      if (k >= first && (k - first) % stride == 0) {
+        DTile t{xc.first, yc.first, xc.second, yc.second, total_waves, (uint32_t)pixels};
+        out.push_back(t);
+        total_waves += tile_waves(t.w, t.h);
+        pixels += (int64_t)t.w * t.h;
+      }
+      k++;
+    }
+}
+static int check_params(glome_ctx* ctx, const glome_render_params* P) {
+  if (!P || P->width <= 0 || P->height <= 0 || P->blocksize <= 0 || P->tile_stride <= 0 || P->tile_first < 0) { ctx->err = "bad render params"; return GLOME_E_INVALID; }
+  if ((int64_t)P->width * P->height > (1ll << 30)) { ctx->err = "frame too large"; return GLOME_E_INVALID; }
+  if (P->maxdepth < 1 || P->maxdepth > kMaxTraceDepth) { ctx->err = "maxdepth must be in 1.." + std::to_string(kMaxTraceDepth); return GLOME_E_LIMIT; }
+  return 0;
+}
+static int get_tiles(glome_ctx* ctx, const glome_render_params* P, int first, int stride, glome_ctx::TileTable** out) {
+  std::vector<int> key{P->width, P->height, P->blocksize, first, stride};
+  auto it = ctx->tile_cache.find(key);
+  if (it == ctx->tile_cache.end()) {
+    glome_ctx::TileTable tt;
+    owned_tiles(P->width, P->height, P->blocksize, first, stride, tt.host, tt.total_waves, tt.pixels);
+    size_t bytes = std::max<size_t>(1, tt.host.size()) * sizeof(DTile);
+    HIPCHK(ctx, hipMalloc((void**)&tt.dev, bytes));
+    if (!tt.host.empty()) HIPCHK(ctx, hipMemcpy(tt.dev, tt.host.data(), tt.host.size() * sizeof(DTile), hipMemcpyHostToDevice));
+    it = ctx->tile_cache.emplace(key, std::move(tt)).first;
+  }
+  *out = &it->second;
+  return 0;
+}
+
+template <class T> static int upload(glome_scene* s, const std::vector<T>& v, const T** out) {
+  glome_ctx* ctx = s->ctx;
+  void* d = nullptr;
+  size_t bytes = v.size() * sizeof(T);
+  HIPCHK(ctx, hipMalloc(&d, bytes));
+  s->allocs.push_back(d);
+  HIPCHK(ctx, hipMemcpy(d, v.data(), bytes, hipMemcpyHostToDevice));
+  s->info.device_bytes += (int64_t)bytes;
+  *out = (const T*)d;
+  return 0;
+}
+
+const char* glome_global_error(void) { return g_global_error.c_str(); }
+
+glome_ctx* glome_ctx_create(int device_ordinal) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) { g_global_error = std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"); return nullptr; }
+  if (device_ordinal < 0 || device_ordinal >= n) { g_global_error = "device ordinal out of range"; return nullptr; }
+  glome_ctx* c = new glome_ctx();
+  c->device = device_ordinal;
+  auto fail = [&](const char* what, hipError_t err) { g_global_error = std::string(what) + ": " + hipGetErrorString(err); delete c; return (glome_ctx*)nullptr; };
+  if ((e = hipSetDevice(device_ordinal)) != hipSuccess) return fail("hipSetDevice", e);
+  if ((e = hipGetDeviceProperties(&c->prop, device_ordinal)) != hipSuccess) return fail("hipGetDeviceProperties", e);
+  if (std::string(c->prop.gcnArchName).rfind("gfx950", 0) != 0) {
+    g_global_error = std::string("device is ") + c->prop.gcnArchName + ", this library is built for gfx950 only";
+    delete c;
+    return nullptr;
+  }
+  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+  if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return fail("hipEventCreate", e);
+  if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return fail("hipEventCreate", e);
+  if ((e = hipMalloc((void**)&c->d_counters, sizeof(DCounters))) != hipSuccess) return fail("hipMalloc", e);
+  return c;
+}
+void glome_ctx_destroy(glome_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  for (auto& kv : c->tile_cache) if (kv.second.dev) (void)hipFree(kv.second.dev);
+  if (c->d_counters) (void)hipFree(c->d_counters);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+const char* glome_last_error(const glome_ctx* c) { return c ? c->err.c_str() : g_global_error.c_str(); }
+void* glome_ctx_stream(glome_ctx* c) { return c ? (void*)c->stream : nullptr; }
+int glome_ctx_synchronize(glome_ctx* c) {
+  if (!c) return GLOME_E_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+int glome_ctx_device_info(glome_ctx* c, char* name, int cap, int* cu_count, int* warp_size) {
+  if (!c) return GLOME_E_INVALID;
+  if (name && cap > 0) snprintf(name, cap, "%s (%s)", c->prop.name, c->prop.gcnArchName);
+  if (cu_count) *cu_count = c->prop.multiProcessorCount;
+  if (warp_size) *warp_size = c->prop.warpSize;
+  return 0;
+}
+
+// ---- commit ----
+glome_scene* glome_scene_commit(glome_ctx* ctx, glome_sb* sb, int32_t root) {
+  if (!ctx || !sb) { g_global_error = "null ctx or builder"; return nullptr; }
+  FlatScene F;
+  try {
+    Flattener fl(sb_graph(sb), F);
+    fl.run(root);
+  } catch (std::exception& e) { ctx->err = e.what(); return nullptr; }
+  (void)hipSetDevice(ctx->device);
+  glome_scene* s = new glome_scene();
+  s->ctx = ctx;
+  int rc = 0;
+  DScene& D = s->dev;
+  rc |= upload(s, F.recs, &D.recs);
+  rc |= upload(s, F.spheres, &D.spheres); rc |= upload(s, F.tris, &D.tris); rc |= upload(s, F.trinorms, &D.trinorms);
+  rc |= upload(s, F.boxes, &D.boxes); rc |= upload(s, F.planes, &D.planes); rc |= upload(s, F.discs, &D.discs);
+  rc |= upload(s, F.quadrics, &D.quadrics); rc |= upload(s, F.xfms, &D.xfms);
+  rc |= upload(s, F.bihhdr, &D.bihhdr); rc |= upload(s, F.bihnodes, &D.bihnodes);
+  rc |= upload(s, F.meshhdr, &D.meshhdr); rc |= upload(s, F.meshnodes, &D.meshnodes); rc |= upload(s, F.mtris, &D.mtris);
+  rc |= upload(s, F.mtrimeta, &D.mtrimeta); rc |= upload(s, F.mats, &D.mats); rc |= upload(s, F.matkids, &D.matkids);
+  rc |= upload(s, F.entries, &D.entries);
+  if (rc) { glome_scene_release(s); return nullptr; }
+  D.n_entries = F.tier == 0 ? (uint32_t)F.entries.size() : 0;
+  D.root_rec = F.root_rec; D.tier = F.tier; D.n_mats = (uint32_t)sb_graph(sb).mats.size();
+  glome_scene_info& I = s->info;
+  I.tier = (int32_t)F.tier; I.nesting_depth = F.nesting_depth;
+  I.n_records = (int64_t)F.recs.size(); I.n_bih_nodes = (int64_t)F.bihnodes.size(); I.n_mesh_nodes = (int64_t)F.meshnodes.size() / 4;
+  I.n_triangles = (int64_t)(F.tris.size() + F.mtris.size()) / 3; I.n_spheres = (int64_t)F.spheres.size();
+  I.n_other_prims = F.n_other_prims; I.n_xfms = (int64_t)F.xfms.size() / 6; I.n_materials = D.n_mats;
+  I.max_bih_depth = F.max_bih_depth; I.max_mesh_depth = F.max_mesh_depth;
+  for (const Mat& m : sb_graph(sb).mats) {
+    if (m.kind == MAT_REFLECT || m.kind == MAT_REFRACT) s->has_secondary_mats = true;
+    if (m.kind == MAT_LAYERS || m.kind == MAT_BLEND) s->has_nested_mats = true;
+  }
+  int need = std::max(F.max_bih_depth, F.max_mesh_depth);
+  s->stack_cap = std::min(kFlatStack, std::max(4, (need + 3) & ~3));
+  return s;
+}
+void glome_scene_release(glome_scene* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->ctx->device);
+  for (void* p : s->allocs) (void)hipFree(p);
+  delete s;
+}
+int glome_scene_get_info(const glome_scene* s, glome_scene_info* out) {
+  if (!s || !out) return GLOME_E_INVALID;
+  *out = s->info;
+  return 0;
+}
+
+// ---- launch helpers ----
+static int persistent_grid(glome_ctx* ctx, size_t lds_per_block, uint32_t total_work) {
+  int cus = ctx->prop.multiProcessorCount;
+  int per_cu = 32;  // wave slots per CU
+  if (lds_per_block) per_cu = std::min<int>(per_cu, (int)(160 * 1024 / lds_per_block));
+  per_cu = std::max(per_cu, 1);
+  long g = (long)cus * per_cu;
+  return (int)std::max<long>(1, std::min<long>(g, total_work));
+}
+static int check_device_error(glome_ctx* ctx) {
+  DCounters c;
+  HIPCHK(ctx, hipMemcpy(&c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+  if (c.error) { ctx->err = "device-side limit hit (traversal stack or CSG advance cap)"; return GLOME_E_LIMIT; }
+  return 0;
+}
+
+static void launch_render(glome_scene* s, const DRenderArgs& A, const glome_render_params* P, int grid, size_t lds) {
+  hipStream_t st = s->ctx->stream;
+  bool analysis = P->faithful != 0 || P->count_work != 0;
+  if (s->dev.tier == 0) {
+    // lean kernel: legal when no secondary trace can do work and no material nests (Blend / AdditiveLayers)
+    bool full = s->has_nested_mats || (s->has_secondary_mats && P->maxdepth > 1);
+    if (analysis) { if (full) hipLaunchKernelGGL((k_render_flat<true, true>), dim3(grid), dim3(64), lds, st, A, s->stack_cap); else hipLaunchKernelGGL((k_render_flat<true, false>), dim3(grid), dim3(64), lds, st, A, s->stack_cap); }
+    else { if (full) hipLaunchKernelGGL((k_render_flat<false, true>), dim3(grid), dim3(64), lds, st, A, s->stack_cap); else hipLaunchKernelGGL((k_render_flat<false, false>), dim3(grid), dim3(64), lds, st, A, s->stack_cap); }
+  } else {
+    hipLaunchKernelGGL(k_render_generic, dim3(grid), dim3(64), 0, st, A);
+  }
+}
+
+int glome_render_dev(glome_scene* s, const glome_camera* cam, const glome_light* lights, int nlights, const glome_render_params* P,
+                     float* rgbad_dev, uint32_t* packed_dev, glome_stats* stats) {
+  if (!s) return GLOME_E_INVALID;
+  glome_ctx* ctx = s->ctx;
+  if (!cam || !rgbad_dev || nlights < 0 || (nlights > 0 && !lights)) { ctx->err = "bad argument"; return GLOME_E_INVALID; }
+  if (nlights > kMaxLights) { ctx->err = "too many lights"; return GLOME_E_LIMIT; }
+  int rc = check_params(ctx, P);
+  if (rc) return rc;
+  if (P->mode != GLOME_MODE_TILE) { ctx->err = "GLOME_MODE_SUBSAMPLE is not available in this build"; return GLOME_E_LIMIT; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  glome_ctx::TileTable* tt;
+  if ((rc = get_tiles(ctx, P, P->tile_first, P->tile_stride, &tt))) return rc;
+  DRenderArgs A;
+  memset(&A, 0, sizeof(A));
+  A.S = s->dev;
+  memcpy(&A.cam, cam, sizeof(DCamera));
+  for (int i = 0; i < nlights; i++) {
+    memcpy(A.lights[i].pos, lights[i].pos, 12); memcpy(A.lights[i].color, lights[i].color, 12);
+    A.lights[i].rad = lights[i].rad; A.lights[i].shadow = lights[i].shadow;
+  }
+  A.nlights = nlights; A.width = P->width; A.height = P->height; A.fog = P->fog; A.maxdepth = P->maxdepth;
+  memcpy(A.thresholds, P->thresholds, 16);
+  A.tiles = tt->dev; A.ntiles = (int)tt->host.size(); A.total_waves = tt->total_waves;
+  A.out5 = rgbad_dev; A.packed = packed_dev; A.counters = ctx->d_counters;
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(DCounters), ctx->stream));
+  if (A.ntiles > 0) {
+    size_t lds = s->dev.tier == 0 ? (size_t)s->stack_cap * 64 * 12 : 0;
+    int grid = persistent_grid(ctx, lds, A.total_waves);
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    launch_render(s, A, P, grid, lds);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  }
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    DCounters c;
+    HIPCHK(ctx, hipMemcpy(&c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+    stats->rays_primary = c.rays_primary; stats->rays_shadow = c.rays_shadow; stats->rays_secondary = c.rays_secondary;
+    stats->bih_nodes = c.bih_nodes; stats->mesh_nodes = c.mesh_nodes; stats->prim_tests = c.prim_tests;
+    if (A.ntiles > 0) HIPCHK(ctx, hipEventElapsedTime(&stats->kernel_ms, ctx->ev0, ctx->ev1));
+    stats->n_tiles = A.ntiles; stats->n_pixels = (int32_t)tt->pixels;
+    if (c.error) { ctx->err = "device-side limit hit (traversal stack or CSG advance cap)"; return GLOME_E_LIMIT; }
+  }
+  return 0;
+}
+
+int glome_render(glome_scene* s, const glome_camera* cam, const glome_light* lights, int nlights, const glome_render_params* P, float* rgbad,
+                 uint32_t* packed, glome_stats* stats) {
+  if (!s) return GLOME_E_INVALID;
+  glome_ctx* ctx = s->ctx;
+  int rc = check_params(ctx, P);
+  if (rc) return rc;
+  if (!rgbad) { ctx->err = "null framebuffer"; return GLOME_E_INVALID; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  size_t np = (size_t)P->width * P->height;
+  float* d5 = nullptr; uint32_t* dp = nullptr;
+  HIPCHK(ctx, hipMalloc((void**)&d5, np * 5 * sizeof(float)));
+  // tiles this call does not own keep the caller's values
+  hipError_t e = hipMemcpy(d5, rgbad, np * 5 * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess && packed) { e = hipMalloc((void**)&dp, np * 4); if (e == hipSuccess) e = hipMemcpy(dp, packed, np * 4, hipMemcpyHostToDevice); }
+  if (e != hipSuccess) { ctx->err = hipGetErrorString(e); (void)hipFree(d5); if (dp) (void)hipFree(dp); return GLOME_E_HIP; }
+  glome_stats local;
+  rc = glome_render_dev(s, cam, lights, nlights, P, d5, dp, stats ? stats : &local);
+  if (rc == 0) {
+    e = hipMemcpy(rgbad, d5, np * 5 * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && packed) e = hipMemcpy(packed, dp, np * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { ctx->err = hipGetErrorString(e); rc = GLOME_E_HIP; }
+  }
+  (void)hipFree(d5);
+  if (dp) (void)hipFree(dp);
+  return rc;
+}
+
+// ---- per-ray seams ----
+static int batch_grid(glome_ctx* ctx, size_t n, size_t lds) {
+  size_t blocks = (n + 63) / 64;
+  return (int)std::max<size_t>(1, std::min<size_t>(blocks, (size_t)persistent_grid(ctx, lds, 0x7fffffff) * 4));
+}
+int glome_rayint_batch_dev(glome_scene* s, size_t n, const float* ox, const float* oy, const float* oz, const float* dx, const float* dy,
+                           const float* dz, const float* tmax, float* t, int32_t* prim, float* nx, float* ny, float* nz, int32_t* tex4) {
+  if (!s) return GLOME_E_INVALID;
+  glome_ctx* ctx = s->ctx;
+  if (n == 0) return 0;
+  if (!ox || !oy || !oz || !dx || !dy || !dz || !tmax) { ctx->err = "null ray stream"; return GLOME_E_INVALID; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  RayStream R{ox, oy, oz, dx, dy, dz, tmax};
+  HitStream H{t, prim, nx, ny, nz, tex4};
+  if (s->dev.tier == 0) {
+    size_t lds = (size_t)s->stack_cap * 64 * 12;
+    hipLaunchKernelGGL((k_rayint_batch_flat<false>), dim3(batch_grid(ctx, n, lds)), dim3(64), lds, ctx->stream, s->dev, n, R, H, s->stack_cap);
+  } else {
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(DCounters), ctx->stream));
+    hipLaunchKernelGGL(k_rayint_batch_generic, dim3(batch_grid(ctx, n, 0)), dim3(64), 0, ctx->stream, s->dev, n, R, H, ctx->d_counters);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  return 0;
+}
+int glome_shadow_batch_dev(glome_scene* s, size_t n, const float* ox, const float* oy, const float* oz, const float* dx, const float* dy,
+                           const float* dz, const float* tmax, uint8_t* occluded) {
+  if (!s) return GLOME_E_INVALID;
+  glome_ctx* ctx = s->ctx;
+  if (n == 0) return 0;
+  if (!ox || !oy || !oz || !dx || !dy || !dz || !tmax || !occluded) { ctx->err = "null stream"; return GLOME_E_INVALID; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  RayStream R{ox, oy, oz, dx, dy, dz, tmax};
+  if (s->dev.tier == 0) {
+    size_t lds = (size_t)s->stack_cap * 64 * 12;
+    hipLaunchKernelGGL(k_shadow_batch_flat, dim3(batch_grid(ctx, n, lds)), dim3(64), lds, ctx->stream, s->dev, n, R, occluded, s->stack_cap);
+  } else {
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(DCounters), ctx->stream));
+    hipLaunchKernelGGL(k_shadow_batch_generic, dim3(batch_grid(ctx, n, 0)), dim3(64), 0, ctx->stream, s->dev, n, R, occluded, ctx->d_counters);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  return 0;
+}
+
+// host-buffer wrappers: stage the SoA streams through HBM
+struct Staging {
+  glome_ctx* ctx;
+  std::vector<void*> bufs;
+  ~Staging() { for (void* p : bufs) (void)hipFree(p); }
+  template <class T> T* in(const T* h, size_t n) {
+    T* d = nullptr;
+    if (hipMalloc((void**)&d, std::max<size_t>(1, n) * sizeof(T)) != hipSuccess) return nullptr;
+    bufs.push_back(d);
+    if (h && hipMemcpy(d, h, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    return d;
+  }
+};
+int glome_rayint_batch(glome_scene* s, size_t n, const float* ox, const float* oy, const float* oz, const float* dx, const float* dy,
+                       const float* dz, const float* tmax, float* t, int32_t* prim, float* nx, float* ny, float* nz, int32_t* tex4) {
+  if (!s) return GLOME_E_INVALID;
+  glome_ctx* ctx = s->ctx;
+  if (n == 0) return 0;
+  if (!ox || !oy || !oz || !dx || !dy || !dz || !tmax) { ctx->err = "null ray stream"; return GLOME_E_INVALID; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  Staging st{ctx, {}};
+  const float* in[7] = {ox, oy, oz, dx, dy, dz, tmax};
+  float* din[7];
+  for (int k = 0; k < 7; k++) if (!(din[k] = st.in(in[k], n))) { ctx->err = "staging allocation failed"; return GLOME_E_HIP; }
+  float* dt = t ? st.in<float>(nullptr, n) : nullptr;
+  int32_t* dprim = prim ? st.in<int32_t>(nullptr, n) : nullptr;
+  float* dnx = nx ? st.in<float>(nullptr, n) : nullptr;
+  float* dny = ny ? st.in<float>(nullptr, n) : nullptr;
+  float* dnz = nz ? st.in<float>(nullptr, n) : nullptr;
+  int32_t* dtex = tex4 ? st.in<int32_t>(nullptr, 4 * n) : nullptr;
+  int rc = glome_rayint_batch_dev(s, n, din[0], din[1], din[2], din[3], din[4], din[5], din[6], dt, dprim, dnx, dny, dnz, dtex);
+  if (rc) return rc;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (s->dev.tier != 0 && (rc = check_device_error(ctx))) return rc;
+  if (t) HIPCHK(ctx, hipMemcpy(t, dt, n * 4, hipMemcpyDeviceToHost));
+  if (prim) HIPCHK(ctx, hipMemcpy(prim, dprim, n * 4, hipMemcpyDeviceToHost));
+  if (nx) HIPCHK(ctx, hipMemcpy(nx, dnx, n * 4, hipMemcpyDeviceToHost));
+  if (ny) HIPCHK(ctx, hipMemcpy(ny, dny, n * 4, hipMemcpyDeviceToHost));
+  if (nz) HIPCHK(ctx, hipMemcpy(nz, dnz, n * 4, hipMemcpyDeviceToHost));
+  if (tex4) HIPCHK(ctx, hipMemcpy(tex4, dtex, n * 16, hipMemcpyDeviceToHost));
+  return 0;
+}
+int glome_shadow_batch(glome_scene* s, size_t n, const float* ox, const float* oy, const float* oz, const float* dx, const float* dy,
+                       const float* dz, const float* tmax, uint8_t* occluded) {
+  if (!s) return GLOME_E_INVALID;
+  glome_ctx* ctx = s->ctx;
+  if (n == 0) return 0;
+  if (!ox || !oy || !oz || !dx || !dy || !dz || !tmax || !occluded) { ctx->err = "null stream"; return GLOME_E_INVALID; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  Staging st{ctx, {}};
+  const float* in[7] = {ox, oy, oz, dx, dy, dz, tmax};
+  float* din[7];
+  for (int k = 0; k < 7; k++) if (!(din[k] = st.in(in[k], n))) { ctx->err = "staging allocation failed"; return GLOME_E_HIP; }
+  uint8_t* docc = st.in<uint8_t>(nullptr, n);
+  int rc = glome_shadow_batch_dev(s, n, din[0], din[1], din[2], din[3], din[4], din[5], din[6], docc);
+  if (rc) return rc;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (s->dev.tier != 0 && (rc = check_device_error(ctx))) return rc;
+  HIPCHK(ctx, hipMemcpy(occluded, docc, n, hipMemcpyDeviceToHost));
+  return 0;
+}
+int glome_inside_batch(glome_scene* s, size_t n, const float* px, const float* py, const float* pz, uint8_t* inside) {
+  if (!s) return GLOME_E_INVALID;
+  glome_ctx* ctx = s->ctx;
+  if (n == 0) return 0;
+  if (!px || !py || !pz || !inside) { ctx->err = "null stream"; return GLOME_E_INVALID; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  Staging st{ctx, {}};
+  float *dx = st.in(px, n), *dy = st.in(py, n), *dz = st.in(pz, n);
+  uint8_t* din = st.in<uint8_t>(nullptr, n);
+  if (!dx || !dy || !dz || !din) { ctx->err = "staging allocation failed"; return GLOME_E_HIP; }
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(DCounters), ctx->stream));
+  hipLaunchKernelGGL(k_inside_batch, dim3(batch_grid(ctx, n, 0)), dim3(64), 0, ctx->stream, s->dev, n, dx, dy, dz, din, ctx->d_counters);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  int rc = check_device_error(ctx);
+  if (rc) return rc;
+  HIPCHK(ctx, hipMemcpy(inside, din, n, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ---- tile payload transport ----
+int64_t glome_tiles_payload_floats(const glome_render_params* P, int tile_first, int tile_stride) {
+  if (!P || P->width <= 0 || P->height <= 0 || P->blocksize <= 0 || tile_stride <= 0 || tile_first < 0) return -1;
+  std::vector<DTile> t; uint32_t w; int64_t px;
+  owned_tiles(P->width, P->height, P->blocksize, tile_first, tile_stride, t, w, px);
+  return px * 5;
+}
+int glome_tiles_pack_dev(glome_ctx* ctx, const glome_render_params* P, const float* rgbad_dev, float* payload_dev) {
+  if (!ctx) return GLOME_E_INVALID;
+  int rc = check_params(ctx, P);
+  if (rc) return rc;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  glome_ctx::TileTable* tt;
+  if ((rc = get_tiles(ctx, P, P->tile_first, P->tile_stride, &tt))) return rc;
+  if (tt->host.empty()) return 0;
+  hipLaunchKernelGGL(k_tiles_pack, dim3(21, std::min<int>((int)tt->host.size(), 1024)), dim3(256), 0, ctx->stream, tt->dev, (int)tt->host.size(), P->width, rgbad_dev, payload_dev);
+  HIPCHK(ctx, hipGetLastError());
+  return 0;
+}
+int glome_tiles_blit_dev(glome_ctx* ctx, const glome_render_params* P, int tile_first, int tile_stride, const float* payload_dev, float* rgbad_dev, uint32_t* packed_dev) {
+  if (!ctx) return GLOME_E_INVALID;
+  int rc = check_params(ctx, P);
+  if (rc) return rc;
+  if (tile_stride <= 0 || tile_first < 0) { ctx->err = "bad tile shard"; return GLOME_E_INVALID; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  glome_ctx::TileTable* tt;
+  if ((rc = get_tiles(ctx, P, tile_first, tile_stride, &tt))) return rc;
+  if (tt->host.empty()) return 0;
+  hipLaunchKernelGGL(k_tiles_blit, dim3(17, std::min<int>((int)tt->host.size(), 1024)), dim3(256), 0, ctx->stream, tt->dev, (int)tt->host.size(), P->width, payload_dev, rgbad_dev, packed_dev);
+  HIPCHK(ctx, hipGetLastError());
+  return 0;
+}
+

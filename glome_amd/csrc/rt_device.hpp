@@ -1,0 +1,824 @@
+// rt_device.hpp -- per-ray device code for gfx950: primitive tests, BIH / Mesh traversal, the
+// trace / shade recursion.  fp32 restatement of glome's formulas (reference file:line cited per
+// function; Qn = SURVEY.md Appendix A).  Compare-select min/max and the exact comparison forms
+// of the reference are kept, because they decide NaN / +-0 behaviour (Q1, Q2).
+//
+// Two tiers share the primitive and shading code:
+//   flat tier    -- root = list of simple primitives / homogeneous BIHs / meshes.  Fully inlined,
+//                   traversal stack in LDS (one column per lane, conflict-free), deferred normals.
+//   generic tier -- arbitrary nesting (Instance, CSG, Bound, nested BIH): an interpreter whose
+//                   recursion is unrolled at compile time (rayint_g<D> calls rayint_g<D-1>), so
+//                   the call graph is static and the stacks are fixed-size scratch.
+#pragma once
+#include "rt_types.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define GD __device__ __forceinline__
+#define GDN __device__ __noinline__
+#else
+#include <cmath>
+#include <cstring>
+#define GD inline
+#define GDN
+#endif
+
+namespace glome {
+
+// ------------------------------------------------------------------ small helpers
+GD float as_f(uint32_t u) {
+#if defined(__HIPCC__)
+  return __uint_as_float(u);
+#else
+  float f; std::memcpy(&f, &u, 4); return f;
+#endif
+}
+GD uint32_t as_u(float f) {
+#if defined(__HIPCC__)
+  return __float_as_uint(f);
+#else
+  uint32_t u; std::memcpy(&u, &f, 4); return u;
+#endif
+}
+constexpr float kInf = 1000000.0f;  // Vec.hs:14 (Q0)
+constexpr float kDel = 0.0001f;     // Vec.hs:40
+
+GD float gminf(float a, float b) { return a > b ? b : a; }  // fmin, Vec.hs:44-45 (compare-select)
+GD float gmaxf(float a, float b) { return a > b ? a : b; }  // fmax, Vec.hs:48-49
+GD float gmin3f(float a, float b, float c) { return a > b ? (b > c ? c : b) : (a > c ? c : a); }  // Vec.hs:52-59
+GD float gmax3f(float a, float b, float c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }  // Vec.hs:62-69
+GD float pmaxf(float x, float y) { return x <= y ? y : x; }  // Prelude max (Mesh.hs:167-170)
+GD float pminf(float x, float y) { return x <= y ? x : y; }  // Prelude min
+
+struct V3 { float x, y, z; };
+GD V3 v3(float x, float y, float z) { V3 v; v.x = x; v.y = y; v.z = z; return v; }
+GD V3 v3(const F4& f) { return v3(f.x, f.y, f.z); }
+GD V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+GD V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+GD V3 operator*(V3 a, float f) { return v3(a.x * f, a.y * f, a.z * f); }
+GD V3 vneg(V3 a) { return v3(-a.x, -a.y, -a.z); }
+GD float vdot(V3 a, V3 b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }  // Vec.hs:185-187
+GD V3 vcross(V3 a, V3 b) { return v3((a.y * b.z) - (a.z * b.y), (a.z * b.x) - (a.x * b.z), (a.x * b.y) - (a.y * b.x)); }  // Vec.hs:193-198
+GD V3 vscaleadd(V3 a, V3 b, float f) { return v3(a.x + (b.x * f), a.y + (b.y * f), a.z + (b.z * f)); }  // Vec.hs:302-306
+GD V3 vnorm(V3 a) {  // Vec.hs:314-317
+  float inv = 1.0f / sqrtf((a.x * a.x) + (a.y * a.y) + (a.z * a.z));
+  return v3(a.x * inv, a.y * inv, a.z * inv);
+}
+GD float vcomp(V3 a, uint32_t ax) { return ax == 0 ? a.x : (ax == 1 ? a.y : a.z); }  // va, Vec.hs:167-172
+
+struct Ray { V3 o, d; };
+
+GD F4 ld4(const F4* p, uint32_t i) { return p[i]; }
+GD U4 ldu4(const U4* p, uint32_t i) { return p[i]; }
+
+// texture stacks: 4 x 16 bit, innermost first, id+1 (rt_types.h)
+GD TexStack tex_push(TexStack s, uint32_t mat) { return (s << 16) | (TexStack)(mat + 1); }  // tex:texs, Tex.hs:66
+GD int tex_len(TexStack s) { return (s >> 48) ? 4 : ((s >> 32) ? 3 : ((s >> 16) ? 2 : (s ? 1 : 0))); }
+GD TexStack tex_cat(TexStack a, TexStack b) { return a | (b << (16 * tex_len(a))); }        // a ++ b (overflow truncates; commit validates depth)
+
+struct Cnt {  // per-lane work counters (only live when COUNT)
+  uint32_t bih = 0, mesh = 0, prim = 0, shadow = 0, secondary = 0, primary = 0;
+};
+
+// ------------------------------------------------------------------ slab tests (Vec.hs:725-762)
+// bbclip_ub: divides by the direction itself and branches on d > 0 (not on 1/d) -- Q1: d = +0 gives
+// (in, out) = (+inf, -inf) or NaN where the origin coordinate lies inside the slab.
+GD void bbclip_ub(const Ray& r, V3 lo, V3 hi, float& nearv, float& farv) {
+  float dxr = 1.0f / r.d.x, dyr = 1.0f / r.d.y, dzr = 1.0f / r.d.z;
+  float inx, outx, iny, outy, inz, outz;
+  if (r.d.x > 0) { inx = (lo.x - r.o.x) * dxr; outx = (hi.x - r.o.x) * dxr; } else { inx = (hi.x - r.o.x) * dxr; outx = (lo.x - r.o.x) * dxr; }
+  if (r.d.y > 0) { iny = (lo.y - r.o.y) * dyr; outy = (hi.y - r.o.y) * dyr; } else { iny = (hi.y - r.o.y) * dyr; outy = (lo.y - r.o.y) * dyr; }
+  if (r.d.z > 0) { inz = (lo.z - r.o.z) * dzr; outz = (hi.z - r.o.z) * dzr; } else { inz = (hi.z - r.o.z) * dzr; outz = (lo.z - r.o.z) * dzr; }
+  nearv = gmax3f(inx, iny, inz);
+  farv = gmin3f(outx, outy, outz);
+}
+// bbclip_ub_rcp: takes reciprocals and branches on the reciprocal's sign (Vec.hs:725-741)
+GD void bbclip_ub_rcp(V3 o, V3 rcp, V3 lo, V3 hi, float& nearv, float& farv) {
+  float inx, outx, iny, outy, inz, outz;
+  if (rcp.x > 0) { inx = (lo.x - o.x) * rcp.x; outx = (hi.x - o.x) * rcp.x; } else { inx = (hi.x - o.x) * rcp.x; outx = (lo.x - o.x) * rcp.x; }
+  if (rcp.y > 0) { iny = (lo.y - o.y) * rcp.y; outy = (hi.y - o.y) * rcp.y; } else { iny = (hi.y - o.y) * rcp.y; outy = (lo.y - o.y) * rcp.y; }
+  if (rcp.z > 0) { inz = (lo.z - o.z) * rcp.z; outz = (hi.z - o.z) * rcp.z; } else { inz = (hi.z - o.z) * rcp.z; outz = (lo.z - o.z) * rcp.z; }
+  nearv = gmax3f(inx, iny, inz);
+  farv = gmin3f(outx, outy, outz);
+}
+
+// ------------------------------------------------------------------ primitives
+// Sphere.hs:20-41 (Q4).  Returns the hit distance; the normal is vnorm(p - c), computed by the caller.
+GD bool sphere_test(const F4& s, const Ray& ray, float dist, float& t) {
+  V3 eo = v3(s) - ray.o;
+  float v = vdot(eo, ray.d), vsqr = v * v, csqr = vdot(eo, eo), rsqr = s.w * s.w;
+  float disc = rsqr - (csqr - vsqr);
+  if (disc < 0.0f) return false;
+  float d = sqrtf(disc);
+  float hitdist = ((v - d) > 0) ? (v - d) : (v + d);
+  if ((hitdist < 0) || (hitdist > dist)) return false;
+  t = hitdist;
+  return true;
+}
+// Sphere.hs:51-71: the shadow form rejects early on (dist >= v - r) && (v > 0)
+GD bool sphere_shadow(const F4& s, const Ray& ray, float dist) {
+  V3 eo = v3(s) - ray.o;
+  float v = vdot(eo, ray.d);
+  if (!((dist >= (v - s.w)) && (v > 0.0f))) return false;
+  float vsqr = v * v, csqr = vdot(eo, eo), rsqr = s.w * s.w;
+  float disc = rsqr - (csqr - vsqr);
+  if (disc < 0.0f) return false;
+  float d = sqrtf(disc);
+  float hitdist = ((v - d) > 0) ? (v - d) : (v + d);
+  return !((hitdist < 0) || (hitdist > dist));
+}
+// Moeller-Trumbore, Triangle.hs:45-73 / 82-107 (Q5): two sided, divisor == 0 exact, the reference's
+// comparison forms.  q0 = (p1, .), q1 = (e1, .), q2 = (e2, .) from the 48-byte triangle record.
+GD bool tri_test(const F4& q0, const F4& q1, const F4& q2, const Ray& ray, float dist, float& t, float& b1, float& b2) {
+  V3 p1 = v3(q0), e1 = v3(q1), e2 = v3(q2);
+  V3 s1 = vcross(ray.d, e2);
+  float divisor = vdot(s1, e1);
+  float invdivisor = 1.0f / divisor;
+  V3 d = ray.o - p1;
+  b1 = vdot(d, s1) * invdivisor;
+  V3 s2 = vcross(d, e1);
+  b2 = vdot(ray.d, s2) * invdivisor;
+  t = vdot(e2, s2) * invdivisor;
+  bool miss = (divisor == 0) | (b1 < 0) | (b1 > 1) | (b2 < 0) | (b1 + b2 > 1) | (t < 0) | (t > dist);
+  return !miss;
+}
+// Box.hs:18-54 (Q1, Q6)
+GD bool box_test(const F4& lo, const F4& hi, const Ray& r, float d, float& t, V3& n) {
+  float dx = r.d.x, dy = r.d.y, dz = r.d.z;
+  float dxr = 1.0f / dx, dyr = 1.0f / dy, dzr = 1.0f / dz;
+  float inx, outx, iny, outy, inz, outz;
+  if (dx > 0) { inx = (lo.x - r.o.x) * dxr; outx = (hi.x - r.o.x) * dxr; } else { inx = (hi.x - r.o.x) * dxr; outx = (lo.x - r.o.x) * dxr; }
+  if (dy > 0) { iny = (lo.y - r.o.y) * dyr; outy = (hi.y - r.o.y) * dyr; } else { iny = (hi.y - r.o.y) * dyr; outy = (lo.y - r.o.y) * dyr; }
+  if (dz > 0) { inz = (lo.z - r.o.z) * dzr; outz = (hi.z - r.o.z) * dzr; } else { inz = (hi.z - r.o.z) * dzr; outz = (lo.z - r.o.z) * dzr; }
+  float lastin = gmax3f(inx, iny, inz), firstout = gmin3f(outx, outy, outz);
+  if (lastin > firstout || firstout < 0 || lastin > d) return false;
+  if (lastin < 0) {  // origin is inside: exit hit
+    if (outx == firstout) n = (dx > 0) ? v3(1, 0, 0) : v3(-1, 0, 0);
+    else if (outy == firstout) n = (dy > 0) ? v3(0, 1, 0) : v3(0, -1, 0);
+    else n = (dz > 0) ? v3(0, 0, 1) : v3(0, 0, -1);
+    t = firstout;
+  } else {
+    if (inx == lastin) n = (dx > 0) ? v3(-1, 0, 0) : v3(1, 0, 0);
+    else if (iny == lastin) n = (dy > 0) ? v3(0, -1, 0) : v3(0, 1, 0);
+    else n = (dz > 0) ? v3(0, 0, -1) : v3(0, 0, 1);
+    t = lastin;
+  }
+  return true;
+}
+GD bool box_shadow(const F4& lo, const F4& hi, const Ray& r, float d) {  // Box.hs:56-62
+  float nearv, farv;
+  bbclip_ub(r, v3(lo), v3(hi), nearv, farv);
+  return !((nearv > farv) || farv <= 0 || farv > d);
+}
+// Plane.hs:27-32 (Q2: a NaN passes both comparisons and is a hit)
+GD bool plane_test(const F4& pl, const Ray& r, float d, float& t) {
+  V3 n = v3(pl);
+  float hit = -((vdot(n, r.o) - pl.w) / vdot(n, r.d));
+  if (hit < 0 || hit > d) return false;
+  t = hit;
+  return true;
+}
+// Cone.hs:69-79 with plane_int_dist (Vec.hs:391-394)
+GD bool disc_test(V3 point, V3 norm, float r2, const Ray& r, float d, float& t) {
+  V3 newo = r.o - point;
+  float dist = -(vdot(norm, newo)) / (vdot(norm, r.d));
+  if (dist < 0 || dist > d) return false;
+  V3 pos = vscaleadd(r.o, r.d, dist);
+  V3 off = pos - point;
+  if (vdot(off, off) > r2) return false;
+  t = dist;
+  return true;
+}
+// Cone.hs:104-139 (Q7): z-axis cylinder (r, h1, h2)
+GD bool cyl_test(const F4& q, const Ray& ray, float d, float& t, V3& n) {
+  float r = q.x, h1 = q.y, h2 = q.z;
+  float ox = ray.o.x, oy = ray.o.y, oz = ray.o.z, dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
+  float a = dx * dx + dy * dy, b = 2 * (dx * ox + dy * oy), c = ox * ox + oy * oy - r * r;
+  float disc = b * b - 4 * a * c;
+  if (disc < 0) return false;
+  float ds = sqrtf(disc);
+  float qq = (b < 0) ? (b - ds) * (-0.5f) : (b + ds) * (-0.5f);
+  float t0p = qq / a, t1p = c / qq;
+  float t0 = gminf(t0p, t1p), t1 = gmaxf(t0p, t1p);
+  if (t1 < 0 || t0 > d) return false;
+  float dist = (t0 < 0) ? t1 : t0;
+  if (dist < 0 || dist > d) return false;
+  V3 pos = vscaleadd(ray.o, ray.d, dist);
+  if (pos.z > h1 && pos.z < h2) { t = dist; n = v3(pos.x / r, pos.y / r, 0); return true; }
+  if (dz > 0) {
+    if (oz < h1) { n = v3(0, 0, -1); return disc_test(v3(0, 0, h1), n, r * r, ray, d, t); }
+    return false;
+  }
+  if (oz > h2) { n = v3(0, 0, 1); return disc_test(v3(0, 0, h2), n, r * r, ray, d, t); }
+  return false;
+}
+// Cone.hs:155-200 / 206-245: z-axis cone (r, clip1, clip2, height)
+GD bool cone_test(const F4& q, const Ray& ray, float d, float& t, V3& n) {
+  float r = q.x, clip1 = q.y, clip2 = q.z, height = q.w;
+  float ox = ray.o.x, oy = ray.o.y, oz = ray.o.z, dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
+  float kp = r / height, k = kp * kp;
+  float a = dx * dx + dy * dy - k * dz * dz;
+  float b = 2 * (dx * ox + dy * oy - k * dz * (oz - height));
+  float c = ox * ox + oy * oy - k * (oz - height) * (oz - height);
+  float disc = b * b - 4 * a * c;
+  if (disc < 0) return false;
+  float ds = sqrtf(disc);
+  float qq = (b < 0) ? (b - ds) * (-0.5f) : (b + ds) * (-0.5f);
+  float t0p = qq / a, t1p = c / qq;
+  float t0 = gminf(t0p, t1p), t1 = gmaxf(t0p, t1p);
+  if (t1 < 0 || t0 > d) return false;
+  float dist = (t0 < 0) ? t1 : t0;
+  if (dist < 0 || dist > d) return false;
+  V3 pos = vscaleadd(ray.o, ray.d, dist);
+  if (pos.z > clip1 && pos.z < clip2) {
+    float invhyp = 1.0f / sqrtf(height * height + r * r);
+    float up = r * invhyp, out = height * invhyp;
+    float r_ = sqrtf(pos.x * pos.x + pos.y * pos.y);
+    float corr = out / r_;
+    t = dist; n = v3(pos.x * corr, pos.y * corr, up);
+    return true;
+  }
+  if (dz > 0) {
+    if (oz < clip1) { n = v3(0, 0, -1); return disc_test(v3(0, 0, clip1), n, r * r, ray, d, t); }
+    return false;
+  }
+  if (oz > clip2) {
+    float r2 = r * (1 - ((clip2 - clip1) / height));
+    n = v3(0, 0, 1);
+    return disc_test(v3(0, 0, clip2), n, r2 * r2, ray, d, t);
+  }
+  return false;
+}
+
+// One simple primitive (record kinds R_SPHERE..R_CONE): closest-hit test; the normal is produced only
+// when WANT_N (the flat tier defers normals to finalize and lets the compiler drop this code).
+template <bool WANT_N>
+GD bool prim_test(const DScene& S, uint32_t kind, uint32_t a, const Ray& r, float d, float& t, V3& n) {
+  switch (kind) {
+    case R_SPHERE: {
+      F4 s = ld4(S.spheres, a);
+      if (!sphere_test(s, r, d, t)) return false;
+      if (WANT_N) n = vnorm(vscaleadd(r.o, r.d, t) - v3(s));
+      return true;
+    }
+    case R_TRI: {
+      F4 q0 = ld4(S.tris, 3 * a), q1 = ld4(S.tris, 3 * a + 1), q2 = ld4(S.tris, 3 * a + 2);
+      float b1, b2;
+      if (!tri_test(q0, q1, q2, r, d, t, b1, b2)) return false;
+      if (WANT_N) n = v3(q0.w, q1.w, q2.w);  // vnorm(e1 x e2), Triangle.hs:73, precomputed on the host
+      return true;
+    }
+    case R_TRIN: {  // a = base of a 6-word block in trinorms: (p1,.) (e1,.) (e2,.) n1 n2 n3
+      F4 q0 = ld4(S.trinorms, a), q1 = ld4(S.trinorms, a + 1), q2 = ld4(S.trinorms, a + 2);
+      float b1, b2;
+      if (!tri_test(q0, q1, q2, r, d, t, b1, b2)) return false;
+      if (WANT_N) {  // Triangle.hs:137-141
+        V3 n1 = v3(ld4(S.trinorms, a + 3)), n2 = v3(ld4(S.trinorms, a + 4)), n3 = v3(ld4(S.trinorms, a + 5));
+        V3 a1 = n1 * (1 - (b1 + b2)), a2 = n2 * b1, a3 = n3 * b2;
+        n = vnorm(v3(a1.x + a2.x + a3.x, a1.y + a2.y + a3.y, a1.z + a2.z + a3.z));
+      }
+      return true;
+    }
+    case R_BOX: return box_test(ld4(S.boxes, 2 * a), ld4(S.boxes, 2 * a + 1), r, d, t, n);
+    case R_PLANE: {
+      F4 pl = ld4(S.planes, a);
+      if (!plane_test(pl, r, d, t)) return false;
+      if (WANT_N) n = v3(pl);
+      return true;
+    }
+    case R_DISC: {
+      F4 d0 = ld4(S.discs, 2 * a), d1 = ld4(S.discs, 2 * a + 1);
+      if (!disc_test(v3(d0), v3(d1), d0.w, r, d, t)) return false;
+      if (WANT_N) n = v3(d1);
+      return true;
+    }
+    case R_CYL: return cyl_test(ld4(S.quadrics, a), r, d, t, n);
+    case R_CONE: return cone_test(ld4(S.quadrics, a), r, d, t, n);
+    default: return false;
+  }
+}
+// shadow of one simple primitive.  Sphere / Triangle / Box / Disc / Cone override `shadow`; Plane and
+// Cylinder fall back on rayint (Solid.hs:218-221, Q15).
+GD bool prim_shadow(const DScene& S, uint32_t kind, uint32_t a, const Ray& r, float d) {
+  float t; V3 n;
+  switch (kind) {
+    case R_SPHERE: return sphere_shadow(ld4(S.spheres, a), r, d);
+    case R_BOX: return box_shadow(ld4(S.boxes, 2 * a), ld4(S.boxes, 2 * a + 1), r, d);
+    default: return prim_test<false>(S, kind, a, r, d, t, n);
+  }
+}
+// inside, Solid.hs:166: Sphere.hs:73-76, Box.hs:64-68, Plane.hs:34-38, Cone.hs:141-143, 248-251; others False
+GD bool prim_inside(const DScene& S, uint32_t kind, uint32_t a, V3 p) {
+  switch (kind) {
+    case R_SPHERE: { F4 s = ld4(S.spheres, a); V3 off = v3(s) - p; return vdot(off, off) < s.w * s.w; }
+    case R_BOX: { F4 lo = ld4(S.boxes, 2 * a), hi = ld4(S.boxes, 2 * a + 1); return p.x > lo.x && p.x < hi.x && p.y > lo.y && p.y < hi.y && p.z > lo.z && p.z < hi.z; }
+    case R_PLANE: { F4 pl = ld4(S.planes, a); V3 n = v3(pl); V3 onplane = n * pl.w; return vdot(onplane - p, n) > 0; }
+    case R_CYL: { F4 q = ld4(S.quadrics, a); return p.z > q.y && p.z < q.z && p.x * p.x + p.y * p.y < q.x * q.x; }
+    case R_CONE: { F4 q = ld4(S.quadrics, a); float rr = q.x * (1 - ((p.z - q.y) / q.w)); return p.z > q.y && p.z < q.z && p.x * p.x + p.y * p.y < rr * rr; }
+    default: return false;
+  }
+}
+
+// ------------------------------------------------------------------ traversal stacks
+// Flat tier: one LDS column per lane -- entry e of lane l lives at base[e * 64 + l], so a wave's push or
+// pop touches 64 consecutive dwords: conflict-free for ds_read/write_b32 whatever the lanes' depths.
+struct LaneStack {
+  uint32_t* node; float* nearv; float* farv;  // pointers to this lane's column (stride 64)
+  int cap;                                   // entries available (chosen from the scene's tree depth at commit)
+#if defined(__HIPCC__)
+  static constexpr int STRIDE = 64;
+#else
+  static constexpr int STRIDE = 1;
+#endif
+  GD void push(int sp, uint32_t n, float a, float b) { node[sp * STRIDE] = n; nearv[sp * STRIDE] = a; farv[sp * STRIDE] = b; }
+  GD void pop(int sp, uint32_t& n, float& a, float& b) const { n = node[sp * STRIDE]; a = nearv[sp * STRIDE]; b = farv[sp * STRIDE]; }
+};
+// Generic tier: a fixed private array (scratch).
+struct PrivStack {
+  uint32_t node[kGenericStack]; float nearv[kGenericStack]; float farv[kGenericStack];
+  GD void push(int sp, uint32_t n, float a, float b) { node[sp] = n; nearv[sp] = a; farv[sp] = b; }
+  GD void pop(int sp, uint32_t& n, float& a, float& b) const { n = node[sp]; a = nearv[sp]; b = farv[sp]; }
+};
+
+
+// ------------------------------------------------------------------ BIH traversal (Bih.hs:332-368, 510-544; Q10)
+// Interval traversal, near child first, far child pushed.
+//   MODE 0 (faithful closest): every node the reference visits is visited; `far` is never shrunk.
+//   MODE 1 (closest, ordered early-out): `far` is clamped to the best t so far.  The same nearest hit comes
+//          out (ties -> later item, like `nearest`, Solid.hs:37-44), in fewer steps.
+//   MODE 2 (any hit, shadow_bih): stops at the first occluder.
+// leaf(first_rec, first_prim, count, tmax) tests a leaf's items; it returns true to stop the traversal.
+// best_t() is the running best distance (MODE 1).
+template <int MODE, bool COUNT, class STK, class LEAF, class BEST>
+GD void bih_traverse(const DScene& S, uint32_t hdr, const Ray& r, float d, STK& stk, int stack_cap, Cnt& cnt, LEAF&& leaf, BEST&& best_t) {
+  F4 h0 = ld4(S.bihhdr, 2 * hdr), h1 = ld4(S.bihhdr, 2 * hdr + 1);
+  float nearv, farv;
+  bbclip_ub(r, v3(h0), v3(h1), nearv, farv);
+  farv = gminf(d, farv);  // `traverse root near (fmin d far)`, Bih.hs:368
+  V3 rcp = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+  uint32_t node = as_u(h0.w);
+  int sp = 0;
+  for (;;) {
+    bool popit = true;
+    if (MODE == 1) farv = gminf(farv, best_t());
+    F4 n = ld4(S.bihnodes, node);
+    uint32_t w0 = as_u(n.z), w1 = as_u(n.w);
+    uint32_t axis = w0 & 3u;
+    if (axis == 3u) {
+      // BihLeaf: `rayint s r far` -- the reference tests a leaf it has reached without looking at near > far
+      // (Bih.hs:339); with early-out an empty interval cannot hold the nearest hit, so it is skipped.
+      if (MODE == 0 || !(nearv > farv)) {
+        if (leaf(w1, as_u(n.x), w0 >> 2, farv)) return;
+      }
+    } else if (!(nearv > farv)) {
+      if (COUNT) cnt.bih++;
+      float dirr = vcomp(rcp, axis), o = vcomp(r.o, axis);
+      float dl = (n.x - o) * dirr, dr = (n.y - o) * dirr;
+      uint32_t left = w0 >> 2, right = w1;
+      uint32_t c1, c2; float c1far, c2near; bool go1, go2;
+      if (dirr > 0) { c1 = left; go1 = nearv < dl; c1far = gminf(dl, farv); c2 = right; go2 = dr < farv; c2near = gmaxf(dr, nearv); }
+      else { c1 = right; go1 = nearv < dr; c1far = gminf(dr, farv); c2 = left; go2 = dl < farv; c2near = gmaxf(dl, nearv); }
+      if (go1) {
+        if (go2 && sp < stack_cap) { stk.push(sp, c2, c2near, farv); sp++; }
+        node = c1; farv = c1far; popit = false;
+      } else if (go2) {
+        node = c2; nearv = c2near; popit = false;
+      }
+    }
+    if (popit) {
+      if (sp == 0) return;
+      sp--;
+      stk.pop(sp, node, nearv, farv);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ Mesh 2-box BVH (Mesh.hs:136-198; Q12)
+// Child refs are one word: bit 31 = leaf, bits 30..27 = triangle count (15 = read it from mtrimeta[first].z),
+// bits 26..0 = first triangle (leaf order); a branch ref is a node index.  Ordered traversal: the child
+// entered first is followed, the other is pushed and re-tested on pop against the best hit of this mesh,
+// which is <= the depth of the first child's result that the reference clips with (Mesh.hs:178, 190).
+// Leaves use the box interval `far` as tmax, not `depth` -- as written in the reference (Mesh.hs:163, 198).
+constexpr uint32_t MREF_LEAF = 0x80000000u;
+template <bool COUNT, class STK>
+GD void mesh_closest(const DScene& S, uint32_t mh, const Ray& ray, float depth, STK& stk, int stack_cap, Cnt& cnt, float& best_t, uint32_t& best_tri) {
+  F4 h0 = ld4(S.meshhdr, 2 * mh), h1 = ld4(S.meshhdr, 2 * mh + 1);
+  V3 rcp = v3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+  float nearv, farv;
+  bbclip_ub_rcp(ray.o, rcp, v3(h0), v3(h1), nearv, farv);
+  best_t = kInf; best_tri = 0xffffffffu;  // ridepth RayMiss = infinity
+  if (nearv > farv || nearv > depth || farv < 0) return;
+  uint32_t ref = as_u(h0.w);
+  int sp = 0;
+  for (;;) {
+    bool popit = true;
+    if (ref & MREF_LEAF) {  // Leaf: foldl' nearest over the triangles, each tested with tmax = far
+      uint32_t first = ref & 0x07ffffffu, count = (ref >> 27) & 15u;
+      if (count == 15u) count = ldu4(S.mtrimeta, first).z;
+      float tmax = pminf(farv, best_t);
+      for (uint32_t k = 0; k < count; k++) {
+        uint32_t ti = first + k;
+        F4 q0 = ld4(S.mtris, 3 * ti), q1 = ld4(S.mtris, 3 * ti + 1), q2 = ld4(S.mtris, 3 * ti + 2);
+        float t, b1, b2;
+        if (COUNT) cnt.prim++;
+        if (tri_test(q0, q1, q2, ray, tmax, t, b1, b2)) { best_t = t; best_tri = ti; tmax = t; }
+      }
+    } else {
+      if (COUNT) cnt.mesh++;
+      F4 a0 = ld4(S.meshnodes, 4 * ref), a1 = ld4(S.meshnodes, 4 * ref + 1), b0 = ld4(S.meshnodes, 4 * ref + 2), b1 = ld4(S.meshnodes, 4 * ref + 3);
+      float lnp, lfp, rnp, rfp;
+      bbclip_ub_rcp(ray.o, rcp, v3(a0), v3(a1), lnp, lfp);
+      bbclip_ub_rcp(ray.o, rcp, v3(b0), v3(b1), rnp, rfp);
+      float lnear = pmaxf(nearv, lnp), lfar = pminf(farv, lfp), rnear = pmaxf(nearv, rnp), rfar = pminf(farv, rfp);
+      bool lfirst = lnear < rnear;
+      uint32_t fref = lfirst ? as_u(a0.w) : as_u(b0.w), sref = lfirst ? as_u(b0.w) : as_u(a0.w);
+      float fnear = lfirst ? lnear : rnear, ffar = lfirst ? lfar : rfar;
+      float snear = lfirst ? rnear : lnear, sfar = lfirst ? rfar : lfar;
+      bool gof = !(fnear > ffar || fnear > depth || ffar < 0);
+      float sfar2 = pminf(sfar, best_t);
+      bool gos = !(snear > sfar2 || snear > depth || sfar2 < 0);
+      if (gof) {
+        if (gos && sp < stack_cap) { stk.push(sp, sref, snear, sfar); sp++; }
+        ref = fref; nearv = fnear; farv = ffar; popit = false;
+      } else if (gos) {
+        ref = sref; nearv = snear; farv = sfar; popit = false;
+      }
+    }
+    while (popit) {
+      if (sp == 0) return;
+      sp--;
+      stk.pop(sp, ref, nearv, farv);
+      float f2 = pminf(farv, best_t);  // rfar' = min rfar (ridepth lresult)
+      if (!(nearv > f2 || nearv > depth || f2 < 0)) popit = false;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ flat tier
+// A candidate is (t, id, aux): id = record index of the primitive (or mesh-triangle index when aux has
+// CAND_MESH); aux = entry index.  Normals are derived after traversal (finalize_flat).
+struct Cand { float t; uint32_t id; uint32_t aux; };
+constexpr uint32_t CAND_NONE = 0xffffffffu;
+constexpr uint32_t CAND_MESH = 0x80000000u;
+
+struct HitG {  // a full Rayint (Solid.hs:20-28 minus riray / riuvw, which the shader never reads)
+  bool hit;
+  float t;
+  V3 p, n;
+  TexStack tex;
+  uint32_t uid;
+};
+GD HitG hit_miss() { HitG h; h.hit = false; h.t = kInf; h.p = v3(0, 0, 0); h.n = v3(0, 0, 0); h.tex = 0; h.uid = 0xffffffffu; return h; }
+
+// closest hit over the flat root program = the list instance's `foldl' nearest RayMiss` (Solid.hs:327) over
+// simple primitives, homogeneous BIHs and meshes.  Every entry is tested with the same d (Q9).
+template <bool FAITHFUL, bool COUNT, class STK>
+GD Cand closest_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt) {
+  Cand best; best.t = kInf; best.id = CAND_NONE; best.aux = 0;
+  for (uint32_t e = 0; e < S.n_entries; e++) {
+    U4 ent = ldu4(S.entries, e);
+    if (ent.z & RF_NOVIS) continue;
+    U4 rec = ldu4(S.recs, ent.x);
+    uint32_t kind = rec.x & RF_KINDMASK;
+    // tmax for this entry; a hit replaces the running best when !(best.t < t)  (nearest: ties -> later)
+    float dd = (FAITHFUL || best.id == CAND_NONE) ? d : gminf(d, best.t);
+    if (kind == R_BIH) {
+      uint32_t cls = as_u(ld4(S.bihhdr, 2 * rec.y + 1).w);
+      auto bestt = [&]() { return best.id == CAND_NONE ? kInf * 4.0f : best.t; };
+      auto accept = [&](float t, uint32_t id) { if (best.id == CAND_NONE || !(best.t < t)) { best.t = t; best.id = id; best.aux = e; } };
+      if (cls == BC_TRI) {
+        bih_traverse<FAITHFUL ? 0 : 1, COUNT>(S, rec.y, r, dd, stk, stk.cap, cnt,
+          [&](uint32_t frec, uint32_t fprim, uint32_t count, float tmax) {
+            for (uint32_t k = 0; k < count; k++) {
+              uint32_t a = fprim + k;
+              F4 q0 = ld4(S.tris, 3 * a), q1 = ld4(S.tris, 3 * a + 1), q2 = ld4(S.tris, 3 * a + 2);
+              float t, b1, b2;
+              if (COUNT) cnt.prim++;
+              if (tri_test(q0, q1, q2, r, tmax, t, b1, b2)) { accept(t, frec + k); if (!FAITHFUL) tmax = gminf(tmax, best.t); }
+            }
+            return false;
+          }, bestt);
+      } else if (cls == BC_SPHERE) {
+        bih_traverse<FAITHFUL ? 0 : 1, COUNT>(S, rec.y, r, dd, stk, stk.cap, cnt,
+          [&](uint32_t frec, uint32_t fprim, uint32_t count, float tmax) {
+            for (uint32_t k = 0; k < count; k++) {
+              float t;
+              if (COUNT) cnt.prim++;
+              if (sphere_test(ld4(S.spheres, fprim + k), r, tmax, t)) { accept(t, frec + k); if (!FAITHFUL) tmax = gminf(tmax, best.t); }
+            }
+            return false;
+          }, bestt);
+      } else {  // BC_SIMPLE: mixed simple primitives, possibly with NoShadow / OnlyShadow flags
+        bih_traverse<FAITHFUL ? 0 : 1, COUNT>(S, rec.y, r, dd, stk, stk.cap, cnt,
+          [&](uint32_t frec, uint32_t, uint32_t count, float tmax) {
+            for (uint32_t k = 0; k < count; k++) {
+              U4 it = ldu4(S.recs, frec + k);
+              if (it.x & RF_NOVIS) continue;
+              float t; V3 n;
+              if (COUNT) cnt.prim++;
+              if (prim_test<false>(S, it.x & RF_KINDMASK, it.y, r, tmax, t, n)) { accept(t, frec + k); if (!FAITHFUL) tmax = gminf(tmax, best.t); }
+            }
+            return false;
+          }, bestt);
+      }
+    } else if (kind == R_MESH) {
+      float mt; uint32_t mtri;
+      mesh_closest<COUNT>(S, rec.y, r, d, stk, stk.cap, cnt, mt, mtri);  // depth = the list's d (Q12)
+      if (mtri != 0xffffffffu && (best.id == CAND_NONE || !(best.t < mt))) { best.t = mt; best.id = mtri; best.aux = e | CAND_MESH; }
+    } else if (kind != R_VOID) {
+      float t; V3 n;
+      if (COUNT) cnt.prim++;
+      if (prim_test<false>(S, kind, rec.y, r, dd, t, n) && (best.id == CAND_NONE || !(best.t < t))) { best.t = t; best.id = ent.x; best.aux = e; }
+    }
+  }
+  return best;
+}
+
+// Turn a candidate into a full hit: position (vscaleadd o dir t), normal, texture stack, primitive id.
+GD HitG finalize_flat(const DScene& S, const Ray& r, const Cand& c) {
+  HitG h = hit_miss();
+  if (c.id == CAND_NONE) return h;
+  h.hit = true; h.t = c.t;
+  h.p = vscaleadd(r.o, r.d, c.t);
+  U4 ent = ldu4(S.entries, c.aux & ~CAND_MESH);
+  if (c.aux & CAND_MESH) {
+    U4 rec = ldu4(S.recs, ent.x);
+    uint32_t ti = c.id;
+    U4 meta = ldu4(S.mtrimeta, ti);
+    F4 q0 = ld4(S.mtris, 3 * ti), q1 = ld4(S.mtris, 3 * ti + 1), q2 = ld4(S.mtris, 3 * ti + 2);
+    if (meta.x == 0) h.n = v3(q0.w, q1.w, q2.w);
+    else {  // rayint_trianglenorm with the mesh's normals (Mesh.hs:158-161)
+      float t, b1, b2;
+      tri_test(q0, q1, q2, r, kInf * 8.0f, t, b1, b2);
+      uint32_t nb = meta.x - 1;
+      V3 n1 = v3(ld4(S.trinorms, nb)), n2 = v3(ld4(S.trinorms, nb + 1)), n3 = v3(ld4(S.trinorms, nb + 2));
+      V3 a1 = n1 * (1 - (b1 + b2)), a2 = n2 * b1, a3 = n3 * b2;
+      h.n = vnorm(v3(a1.x + a2.x + a3.x, a1.y + a2.y + a3.y, a1.z + a2.z + a3.z));
+    }
+    TexStack own = meta.y ? (TexStack)meta.y : 0;  // (texv ! texi) : texs, Mesh.hs:148-150 (already id+1)
+    h.tex = tex_cat(own, (TexStack)ent.y);
+    h.uid = rec.w;
+    return h;
+  }
+  U4 rec = ldu4(S.recs, c.id);
+  float t;
+  prim_test<true>(S, rec.x & RF_KINDMASK, rec.y, r, kInf * 8.0f, t, h.n);
+  h.tex = tex_cat((TexStack)rec.z, (TexStack)ent.y);
+  h.uid = rec.w;
+  return h;
+}
+
+// shadow over the flat root program: `foldl' (||) False (map shadow xs)` (Solid.hs:330); Mesh casts none (Mesh.hs:210)
+template <bool COUNT, class STK>
+GD bool occluded_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt) {
+  for (uint32_t e = 0; e < S.n_entries; e++) {
+    U4 ent = ldu4(S.entries, e);
+    if (ent.z & RF_NOSHADOW) continue;
+    U4 rec = ldu4(S.recs, ent.x);
+    uint32_t kind = rec.x & RF_KINDMASK;
+    if (kind == R_BIH) {
+      uint32_t cls = as_u(ld4(S.bihhdr, 2 * rec.y + 1).w);
+      bool occ = false;
+      auto nobest = [&]() { return 0.0f; };
+      if (cls == BC_TRI) {
+        bih_traverse<2, COUNT>(S, rec.y, r, d, stk, stk.cap, cnt,
+          [&](uint32_t, uint32_t fprim, uint32_t count, float tmax) {
+            float dd = gminf(d, tmax);  // `shadow s r (fmin d far)`, Bih.hs:515
+            for (uint32_t k = 0; k < count; k++) {
+              uint32_t a = fprim + k;
+              float t, b1, b2;
+              if (COUNT) cnt.prim++;
+              if (tri_test(ld4(S.tris, 3 * a), ld4(S.tris, 3 * a + 1), ld4(S.tris, 3 * a + 2), r, dd, t, b1, b2)) { occ = true; return true; }
+            }
+            return false;
+          }, nobest);
+      } else if (cls == BC_SPHERE) {
+        bih_traverse<2, COUNT>(S, rec.y, r, d, stk, stk.cap, cnt,
+          [&](uint32_t, uint32_t fprim, uint32_t count, float tmax) {
+            float dd = gminf(d, tmax);
+            for (uint32_t k = 0; k < count; k++) {
+              if (COUNT) cnt.prim++;
+              if (sphere_shadow(ld4(S.spheres, fprim + k), r, dd)) { occ = true; return true; }
+            }
+            return false;
+          }, nobest);
+      } else {
+        bih_traverse<2, COUNT>(S, rec.y, r, d, stk, stk.cap, cnt,
+          [&](uint32_t frec, uint32_t, uint32_t count, float tmax) {
+            float dd = gminf(d, tmax);
+            for (uint32_t k = 0; k < count; k++) {
+              U4 it = ldu4(S.recs, frec + k);
+              if (it.x & RF_NOSHADOW) continue;
+              if (COUNT) cnt.prim++;
+              if (prim_shadow(S, it.x & RF_KINDMASK, it.y, r, dd)) { occ = true; return true; }
+            }
+            return false;
+          }, nobest);
+      }
+      if (occ) return true;
+    } else if (kind != R_MESH && kind != R_VOID) {
+      if (COUNT) cnt.prim++;
+      if (prim_shadow(S, kind, rec.y, r, d)) return true;
+    }
+  }
+  return false;
+}
+
+// ------------------------------------------------------------------ colour algebra (Clr.hs)
+struct CA { float r, g, b, a; };
+GD CA ca(float r, float g, float b, float a) { CA c; c.r = r; c.g = g; c.b = b; c.a = a; return c; }
+GD CA cafold(CA c1, CA c2) {  // Clr.hs:106-113
+  float trans = 1 - c1.a;
+  return ca(c1.r + (c2.r * trans * c2.a), c1.g + (c2.g * trans * c2.a), c1.b + (c2.b * trans * c2.a), c1.a + (c2.a * trans));
+}
+GD CA caweight(CA c1, CA c2, float w) {  // Clr.hs:87-91
+  return ca((c1.r * w) + (c2.r * (1 - w)), (c1.g * w) + (c2.g * (1 - w)), (c1.b * w) + (c2.b * (1 - w)), (c1.a * w) + (c2.a * (1 - w)));
+}
+GD float aclamp(float x) { return x > 1 ? 1.0f : (x < 0 ? 0.0f : x); }  // Clr.hs:75-79
+
+// ------------------------------------------------------------------ trace / shade (Trace.hs:59-82, Shader.hs:65-184)
+// TIER supplies closest / occluded (force-inlined, for the primary path) and closest_ni / occluded_ni (one shared
+// out-of-line copy each, for secondary rays), and carries the lights + counters.
+//
+// glome's trace <-> mpostshade recursion is bounded by `recurs` (maxdepth, Glome.hs:25).  On the device the bound
+// is static: TraceFn<R> only calls TraceFn<R-1>, PostFn<R,MD> only PostFn<R,MD-1>, each one out-of-line function,
+// so the call graph is a DAG and every stack frame is fixed.  The runtime `recurs` (<= R) carries the scene's
+// actual maxdepth.
+struct LightCache { bool done; uint32_t mask; };  // the lazily evaluated ctxb of Trace.hs:63: visibility per light
+
+template <bool INL, class TIER>
+GD uint32_t preshade(TIER& T, const HitG& h) {  // mpreshade, Shader.hs:65-80 (Q18)
+  uint32_t mask = 0;
+  for (int i = 0; i < T.nlights; i++) {
+    const DLight& L = T.lights[i];
+    V3 lvec = v3(L.pos[0], L.pos[1], L.pos[2]) - h.p;
+    if (vdot(lvec, h.n) < 0) continue;
+    float llen = sqrtf(vdot(lvec, lvec));
+    V3 ldir = lvec * (1.0f / llen);
+    if (llen > L.rad) continue;
+    if (L.shadow) {
+      T.cnt.shadow++;
+      Ray sr; sr.o = vscaleadd(h.p, h.n, kDel); sr.d = ldir;
+      bool occ = INL ? T.occluded(sr, llen - (2 * kDel)) : T.occluded_ni(sr, llen - (2 * kDel));
+      if (occ) continue;
+    }
+    mask |= 1u << i;
+  }
+  return mask;
+}
+
+template <int R, class TIER> struct TraceFn;
+template <int R, int MD, class TIER> struct PostFn;
+
+// mpostshade, Shader.hs:82-184 (Q17)
+template <int R, int MD, bool INL, class TIER>
+GD CA postshade_body(TIER& T, LightCache& lc, uint32_t mat, const Ray& ray, const HitG& h, int recurs) {
+  const DScene& S = T.S;
+  F4 m0 = ld4(S.mats, 3 * mat), m1 = ld4(S.mats, 3 * mat + 1);
+  uint32_t kind = as_u(m0.x);
+  V3 dir = ray.d, n = h.n, p = h.p;
+  V3 eyedir = vneg(dir);
+  if (kind == DM_SURFACE) {
+    F4 m2 = ld4(S.mats, 3 * mat + 2);
+    float amb = m2.x, kd = m2.y, ks = m2.z, shine = m2.w;
+    if (!lc.done) { lc.mask = preshade<INL>(T, h); lc.done = true; }
+    float ar = m1.x * amb, ag = m1.y * amb, ab = m1.z * amb;  // cscale color amb
+    float dr = 0, dg = 0, db = 0;                             // foldl' cadd c_black
+    for (int i = 0; i < T.nlights; i++) {
+      if (!((lc.mask >> i) & 1u)) continue;
+      const DLight& L = T.lights[i];
+      V3 lvec = v3(L.pos[0], L.pos[1], L.pos[2]) - p;
+      float llen = sqrtf(vdot(lvec, lvec));
+      V3 ldir = lvec * (1.0f / llen);
+      float fall = 1.0f / (llen * llen);  // falloff, Shader.hs:23
+      V3 half = vnorm(ldir + eyedir);     // bisect, Vec.hs:331-332
+      float ldotn = gmaxf(0, vdot(ldir, n));
+      float blinn = 0;
+      if (!(ks <= kDel)) {
+        float b = gmaxf(0, powf(vdot(half, n), shine) * ldotn);
+        blinn = (b != b) ? 0.0f : b;  // isNaN b
+      }
+      float diffuse = vdot(ldir, n);
+      float w = (blinn * ks) + (diffuse * kd);
+      dr = dr + (L.color[0] * fall) * w; dg = dg + (L.color[1] * fall) * w; db = db + (L.color[2] * fall) * w;
+    }
+    return ca(ar + dr, ag + dg, ab + db, m1.w);
+  }
+  if (kind == DM_REFLECT) {  // Shader.hs:107-118; recurs > 0 always holds here (trace returns early at 0)
+    float refl = m1.x;
+    if ((refl > 0) && (recurs > 0)) {
+      // lean kernels are only launched when no secondary trace can do work (maxdepth == 1 or no Reflect/Refract
+      // material): the child is `trace ... 0` = traceMiss
+      if constexpr (!TIER::FULL) return ca(0, 0, 0, 0 * refl);
+      V3 outdir = vscaleadd(dir, n, (-2.0f) * vdot(dir, n));  // reflect, Vec.hs:340-342
+      Ray rr; rr.o = vscaleadd(p, outdir, kDel); rr.d = outdir;
+      CA c = TraceFn<R - 1, TIER>::run(T, rr, kInf, recurs - 1);
+      return ca(c.r, c.g, c.b, c.a * refl);
+    }
+    return ca(0, 0, 0, 1);
+  }
+  if (kind == DM_REFRACT) {  // Shader.hs:120-155
+    float refl = m1.x, refr = m1.y, ior = m1.z;
+    if ((refl > 0 || refr > 0) && (recurs > 0)) {
+      if constexpr (!TIER::FULL) {  // both children are traceMiss, except total internal reflection -> ca_black
+        float eta0 = (vdot(n, eyedir) > 0) ? ior : 1.0f / ior;
+        float c10 = vdot(dir, n);
+        float cs20 = 1 - (eta0 * eta0) * (1 - (c10 * c10));
+        return ca(0, 0, 0, (cs20 < 0) ? (0 * refl + 1 * refr) : 0.0f);
+      }
+      V3 outdir = vscaleadd(dir, n, (-2.0f) * vdot(dir, n));
+      Ray rr; rr.o = vscaleadd(p, outdir, kDel); rr.d = outdir;
+      CA cr = TraceFn<R - 1, TIER>::run(T, rr, kInf, recurs - 1);
+      float eta = (vdot(n, eyedir) > 0) ? ior : 1.0f / ior;
+      float c1 = vdot(dir, n);
+      float cs2 = 1 - (eta * eta) * (1 - (c1 * c1));
+      CA ct = ca(0, 0, 0, 1);  // ca_black on total internal reflection
+      if (!(cs2 < 0)) {
+        V3 tv = (dir * eta) + (n * (eta * c1 - sqrtf(cs2)));  // unnormalised, as written
+        Ray tr; tr.o = vscaleadd(p, tv, kDel); tr.d = tv;
+        ct = TraceFn<R - 1, TIER>::run(T, tr, kInf, recurs - 1);
+      }
+      return ca(cr.r * refl + ct.r * refr, cr.g * refl + ct.g * refr, cr.b * refl + ct.b * refr, cr.a * refl + ct.a * refr);
+    }
+    return ca(0, 0, 0, 0);
+  }
+  if constexpr (MD > 0 && TIER::FULL) {
+    if (kind == DM_LAYERS) {  // casum, Clr.hs:93-103 (alphas :82-85)
+      uint32_t first = as_u(m0.y), count = as_u(m0.z);
+      float r = 0, g = 0, b = 0, prod = 1;
+      for (uint32_t k = 0; k < count; k++) {
+        CA c = PostFn<R, MD - 1, TIER>::run(T, lc, S.matkids[first + k], ray, h, recurs);
+        r = r + c.r * c.a; g = g + c.g * c.a; b = b + c.b * c.a;
+        prod = prod * (1 - aclamp(c.a));
+      }
+      return ca(r, g, b, 1 - prod);
+    }
+    if (kind == DM_BLEND) {  // Shader.hs:181-184
+      CA a = PostFn<R, MD - 1, TIER>::run(T, lc, as_u(m0.y), ray, h, recurs);
+      CA b = PostFn<R, MD - 1, TIER>::run(T, lc, as_u(m0.z), ray, h, recurs);
+      return caweight(a, b, m0.w);
+    }
+  }
+  return ca(0, 0, 0, 0);
+}
+template <int R, int MD, class TIER> struct PostFn {
+  static GDN CA run(TIER& T, LightCache& lc, uint32_t mat, const Ray& ray, const HitG& h, int recurs) {
+    return postshade_body<R, MD, false>(T, lc, mat, ray, h, recurs);
+  }
+};
+
+// trace, Trace.hs:59-82 (Q16)
+template <int R, bool INL, class TIER>
+GD CA trace_body(TIER& T, const Ray& ray, float tmax, int recurs, HitG* hout) {
+  HitG h = INL ? T.closest(ray, tmax) : T.closest_ni(ray, tmax);
+  if (hout) *hout = h;
+  if (!h.hit) return ca(0, 0, 0, 0);  // mmissshade: transparent (Shader.hs:186-187)
+  LightCache lc; lc.done = false; lc.mask = 0;
+  CA acc = ca(0, 0, 0, 0);
+  TexStack ts = h.tex;
+  for (int k = 0; k < kMaxTexDepth; k++) {
+    uint32_t id = (uint32_t)(ts & 0xffffu);
+    if (id == 0) break;
+    if (acc.a + kDel >= 1) break;  // opaque, Trace.hs:50-51
+    acc = cafold(acc, postshade_body<R, kMaxMatNest, INL>(T, lc, id - 1, ray, h, recurs));
+    ts >>= 16;
+  }
+  return acc;
+}
+template <int R, class TIER> struct TraceFn {
+  static GDN CA run(TIER& T, const Ray& ray, float tmax, int recurs) {
+    if (recurs <= 0) return ca(0, 0, 0, 0);  // `trace _ _ _ _ _ 0 = traceMiss`
+    T.cnt.secondary++;
+    return trace_body<R, false>(T, ray, tmax, recurs, (HitG*)0);
+  }
+};
+template <class TIER> struct TraceFn<0, TIER> {
+  static GD CA run(TIER&, const Ray&, float, int) { return ca(0, 0, 0, 0); }
+};
+// the pixel loop's entry: `Trace.trace lights shader sld ray infinity maxdepth` (Glome.hs:33), maxdepth <= kMaxTraceDepth
+template <class TIER> GD CA trace_primary(TIER& T, const Ray& ray, float tmax, int maxdepth, HitG* hout) {
+  if (maxdepth <= 0) { *hout = hit_miss(); return ca(0, 0, 0, 0); }
+  return trace_body<kMaxTraceDepth, true>(T, ray, tmax, maxdepth, hout);
+}
+
+// ------------------------------------------------------------------ pixel mapping (Glome.hs:27-33, 119-140; Q19)
+GD void get_coordsf(int width, int height, float xf, float yf, float& xc, float& yc) {
+  float widthf = (float)width, heightf = (float)height;
+  xc = (((xf / widthf) * 2) - 1) * (widthf / heightf);
+  yc = -(((yf / heightf) * 2) - 1);
+}
+GD Ray primary_ray(const DCamera& c, float xc, float yc) {  // get_rayint, Glome.hs:27-33
+  V3 fwd = v3(c.fwd[0], c.fwd[1], c.fwd[2]), right = v3(c.right[0], c.right[1], c.right[2]), up = v3(c.up[0], c.up[1], c.up[2]);
+  V3 a = right * (-xc), b = up * yc;
+  Ray r;
+  r.o = v3(c.pos[0], c.pos[1], c.pos[2]);
+  r.d = vnorm(v3(fwd.x + a.x + b.x, fwd.y + a.y + b.y, fwd.z + a.z + b.z));  // vadd3
+  return r;
+}
+GD float cap1(float x) { return x >= 1 ? 1 - kDel : x; }  // Glome.hs:98-101
+GD uint32_t rgbf(float r, float g, float b) {            // Glome.hs:107-110 (wraps like Word32 arithmetic)
+  int ri = (int)floorf(cap1(r) * 256), gi = (int)floorf(cap1(g) * 256), bi = (int)floorf(cap1(b) * 256);
+  return (uint32_t)ri * 65536u + (uint32_t)gi * 256u + (uint32_t)bi;
+}
+
+}  // namespace glome

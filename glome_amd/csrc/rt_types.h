@@ -1,0 +1,111 @@
+// rt_types.h -- the packed scene layout in HBM, shared by the host flattener and the HIP kernels.
+//
+// Everything is a pool of 16-byte words (float4 / uint4) so every fetch is one dwordx4:
+//
+//   recs      uint4   one record per scene-graph reference: {kind|flags, a, b, c}
+//   spheres   float4  (cx, cy, cz, r)                                               16 B / sphere
+//   tris      float4  x3: (p1.xyz, n.x) (e1.xyz, n.y) (e2.xyz, n.z)                 48 B / triangle
+//                     e1 = p2-p1, e2 = p3-p1, n = normalize(e1 x e2), all evaluated in double on
+//                     the host (Triangle.hs:47-48,73) and rounded once
+//   trinorms  float4  heap: TriangleNorm = 6 words (p1,e1,e2,n1,n2,n3); mesh vertex normals = 3 words per triangle
+//   boxes     float4  x2: (min, -) (max, -)
+//   planes    float4  (n.xyz, offset)
+//   discs     float4  x2: (p.xyz, r^2) (n.xyz, -)
+//   quadrics  float4  cylinder (r, h1, h2, -) / cone (r, clip1, clip2, height)
+//   xfms      float4  x6: forward rows 0..2, inverse rows 0..2
+//   bihhdr    float4  x2: (bb.min, root node) (bb.max, leaf class)
+//   bihnodes  float4  branch (lsplit, rsplit, axis | left<<2, right); leaf (first prim, -, 3 | count<<2, first rec)
+//   meshhdr   float4  x2: (bb.min, root ref) (bb.max, root count)
+//   meshnodes float4  x4: (lbb.min, lref) (lbb.max, lcnt) (rbb.min, rref) (rbb.max, rcnt)
+//   mtris     float4  x3 per mesh triangle in leaf order, same layout as `tris`
+//   mtrimeta  uint4   per mesh triangle: (normal base+1 or 0, material+1 or 0, -, -)
+//   mats      float4  x3: (kind, a, b, w) (r, g, b, alpha | refl, refr, ior) (amb, kd, ks, shine)
+//   matkids   uint    AdditiveLayers children
+//   entries   uint4   flat-tier root program: (rec, incoming tex stack, flags, -)
+#pragma once
+#include <stdint.h>
+
+namespace glome {
+
+enum RecKind : uint32_t {
+  R_VOID = 0, R_SPHERE = 1, R_TRI = 2, R_TRIN = 3, R_BOX = 4, R_PLANE = 5, R_DISC = 6, R_CYL = 7, R_CONE = 8,
+  R_LIST = 9, R_INSTANCE = 10, R_DIFF = 11, R_ISECT = 12, R_BOUND = 13, R_INNERBOUND = 14, R_BIH = 15, R_MESH = 16, R_TEX = 17
+};
+constexpr uint32_t RF_KINDMASK = 0xffu;
+constexpr uint32_t RF_NOVIS = 1u << 8;     // OnlyShadow: rayint misses (Tex.hs:89)
+constexpr uint32_t RF_NOSHADOW = 1u << 9;  // NoShadow: shadow is False (Tex.hs:81)
+
+enum BihLeafClass : uint32_t { BC_GENERIC = 0, BC_TRI = 1, BC_SPHERE = 2, BC_SIMPLE = 3 };
+constexpr uint32_t MESH_BRANCH = 0xffffffffu;  // count value marking "ref is a branch node"
+
+enum DMatKind : uint32_t { DM_SURFACE = 0, DM_REFLECT = 1, DM_REFRACT = 2, DM_LAYERS = 3, DM_BLEND = 4 };
+
+// A texture stack is at most 4 material ids, innermost first, 16 bits each, stored as id+1 (0 = end).
+typedef uint64_t TexStack;
+constexpr int kMaxTexDepth = 4;
+constexpr int kMaxLights = 8;
+constexpr int kFlatStack = 32;     // LDS traversal-stack entries per lane in the flat-tier kernels
+constexpr int kGenericStack = 32;  // scratch traversal-stack entries per BIH/Mesh level in the generic tier
+constexpr int kGenericDepth = 6;   // composite nesting levels the generic interpreter is instantiated for
+constexpr int kCsgMaxAdvance = 32; // ray-advance steps per CSG node before giving up (reference: unbounded)
+constexpr int kIsectFrames = 40;   // explicit frames for rayint_intersection's list recursion
+constexpr int kMaxTraceDepth = 4;  // maxdepth values the render kernels are instantiated for
+constexpr int kMaxMatNest = 2;     // Blend / AdditiveLayers nesting the shader is instantiated for
+
+struct F4 { float x, y, z, w; };
+struct U4 { uint32_t x, y, z, w; };
+
+struct DScene {
+  const U4* recs;
+  const F4* spheres;
+  const F4* tris;
+  const F4* trinorms;
+  const F4* boxes;
+  const F4* planes;
+  const F4* discs;
+  const F4* quadrics;
+  const F4* xfms;
+  const F4* bihhdr;
+  const F4* bihnodes;
+  const F4* meshhdr;
+  const F4* meshnodes;
+  const F4* mtris;
+  const U4* mtrimeta;
+  const F4* mats;
+  const uint32_t* matkids;
+  const U4* entries;
+  uint32_t n_entries;
+  uint32_t root_rec;
+  uint32_t tier;
+  uint32_t n_mats;
+};
+
+struct DCamera { float pos[3], fwd[3], up[3], right[3]; };
+struct DLight { float pos[3], color[3], rad; int32_t shadow; };
+
+struct DTile { int32_t x, y, w, h; uint32_t wave_base; uint32_t pix_base; };  // pix_base: offset of the tile in a dense payload
+
+struct DCounters {  // device-side atomics, one block per launch
+  unsigned long long rays_primary, rays_shadow, rays_secondary, bih_nodes, mesh_nodes, prim_tests;
+  unsigned int next_work;  // persistent-kernel work queue head
+  unsigned int error;      // set when a device-side limit was hit (stack overflow guard, CSG cap)
+};
+
+struct DRenderArgs {
+  DScene S;
+  DCamera cam;
+  DLight lights[kMaxLights];
+  int32_t nlights;
+  int32_t width, height;
+  int32_t fog;
+  int32_t maxdepth;
+  float thresholds[4];
+  const DTile* tiles;  // owned tiles
+  int32_t ntiles;
+  uint32_t total_waves;
+  float* out5;         // width*height*5
+  uint32_t* packed;    // width*height or null
+  DCounters* counters;
+};
+
+}  // namespace glome

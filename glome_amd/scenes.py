@@ -1,0 +1,131 @@
+"""Benchmark / parity scenes S1..S5, written in TestScene.hs vocabulary
+(GlomeView/TestScene.hs:17-19 lights, :138 cust_cam, :201-245 materials).  Every generator uses only IEEE-exact
++ - * / and integer hashing, evaluated in double and rounded to fp32 by SceneDesc.
+"""
+import numpy as np
+
+from .scene import SceneDesc
+
+LIGHTS = [((-100.0, 70.0, 140.0), (7000.0 * 1.0, 7000.0 * 0.8, 7000.0 * 0.8)),  # TestScene.hs:17
+          ((-3.0, 5.0, 8.0), (10.0 * 1.5, 10.0 * 2.0, 10.0 * 2.0))]             # TestScene.hs:18
+CUST_CAM = ((-2.0, 4.3, 15.0), (0.0, 2.0, 0.0), (0.0, 1.0, 0.0), 45.0)          # TestScene.hs:138
+
+
+def _common(sd, nlights):
+    for pos, col in LIGHTS[:nlights]:
+        sd.add_light(pos, col)
+    sd.set_camera(*CUST_CAM)
+
+
+def materials(sd):
+    m = {}
+    m["shiny_white"] = sd.material_surface((1, 1, 1), 1, 0.2, 0.8, 0.4, 10)  # TestScene.hs:201-202
+    m["shiny_red"] = sd.material_surface((1, 0, 0), 1, 0.2, 0.8, 0.4, 10)    # TestScene.hs:204
+    m["mirror"] = sd.material_reflect(0.8)                                   # TestScene.hs:243
+    return m
+
+
+def matte(sd, c):  # m_matte, TestScene.hs:236-237
+    return sd.material_surface(c, 1, 0.2, 1, 0, 0)
+
+
+def s1(nlights=1, shadows=True, n=5):
+    """C.1: group [tex plane matte-green, bih [tex (sphere (x,0.5,z) 0.4) mat | x,z in -n..n]]  (S1/S2)."""
+    sd = SceneDesc()
+    m = materials(sd)
+    mats = [m["shiny_white"], m["shiny_red"], matte(sd, (0.5, 0, 1))]
+    green = matte(sd, (0, 0.8, 0.3))
+    pl = sd.tex(sd.plane((0, 0, 0), (0, 1, 0)), green)
+    sph = []
+    for ix, x in enumerate(range(-n, n + 1)):
+        for iz, z in enumerate(range(-n, n + 1)):
+            sph.append(sd.tex(sd.sphere((float(x), 0.5, float(z)), 0.4), mats[(ix + iz) % 3]))
+    root = sd.group([pl, sd.bih(sph)])
+    sd.set_root(root)
+    _common(sd, nlights)
+    if not shadows:
+        sd.lights = [(p, c, r, False) for (p, c, r, _) in sd.lights]
+    return sd
+
+
+def heightfield_vertices(N):
+    """C.2: (N+1)^2 vertices, evaluated in double."""
+    i = np.arange(N + 1, dtype=np.int64)
+
+    def s(k):
+        u = (k % 32).astype(np.float64) / 32.0
+        sign = np.where((k // 32) % 2 == 0, 1.0, -1.0)
+        return sign * (4.0 * u * (1.0 - u))
+
+    x = i.astype(np.float64) * 20.0 / N - 10.0
+    I, J = np.meshgrid(i, i, indexing="ij")
+    h = ((I.astype(np.uint64) * 73856093) & 0xFFFFFFFF).astype(np.uint32) ^ ((J.astype(np.uint64) * 19349663) & 0xFFFFFFFF).astype(np.uint32)
+    y = 1.5 * s(I) * s(J + 17) + 0.05 * ((h & 1023).astype(np.float64) / 1024.0)
+    V = np.stack([x[I], y, x[J]], axis=-1)  # V[i, j] = (x_i, y_ij, z_j)
+    return V
+
+
+def heightfield_triangles(N):
+    """Cell (i,j) -> (v(i,j), v(i,j+1), v(i+1,j)) and (v(i+1,j), v(i,j+1), v(i+1,j+1)); normals face +y."""
+    V = heightfield_vertices(N)
+    a, b, c, d = V[:-1, :-1], V[:-1, 1:], V[1:, :-1], V[1:, 1:]
+    t1 = np.concatenate([a, b, c], axis=-1)
+    t2 = np.concatenate([c, b, d], axis=-1)
+    return np.stack([t1, t2], axis=2).reshape(-1, 9)
+
+
+def s3(N=224, as_mesh=False, nlights=1):
+    """C.2: heightfield of 2*N*N triangles as `tex (bih (map triangle ...)) matte` or as `mesh` (S3: N=224, S5: N=708)."""
+    sd = SceneDesc()
+    mat = matte(sd, (0.8, 0.5, 0.4))
+    if as_mesh:
+        V = heightfield_vertices(N).reshape(-1, 3)
+        idx = np.arange((N + 1) * (N + 1)).reshape(N + 1, N + 1)
+        a, b, c, d = idx[:-1, :-1], idx[:-1, 1:], idx[1:, :-1], idx[1:, 1:]
+        t1 = np.stack([a, b, c], -1)
+        t2 = np.stack([c, b, d], -1)
+        tri = np.stack([t1, t2], axis=2).reshape(-1, 3)
+        tris = np.full((tri.shape[0], 8), -1, dtype=np.int32)
+        tris[:, :3] = tri
+        tris[:, 6] = 0  # Tri a b c (-1) (-1) (-1) 0 (-1)
+        root = sd.mesh(V, np.zeros((0, 3)), tris, [mat])
+    else:
+        ids = sd.triangles_bulk(heightfield_triangles(N))
+        root = sd.tex(sd.bih(ids), mat)
+    sd.set_root(root)
+    _common(sd, nlights)
+    return sd
+
+
+def sphereint(sd):  # TestScene.hs:112-115
+    return sd.intersection([sd.sphere((-1, 0, 0), 2), sd.sphere((1, 0, 0), 2), sd.sphere((0, -1, 0), 2), sd.sphere((0, 1, 0), 2)])
+
+
+def s4(nlights=2):
+    """C.3: CSG difference / intersection of spheres + boxes, Reflect 0.8, an instanced sphereint (S4)."""
+    from . import api
+    sd = SceneDesc()
+    m = materials(sd)
+    green = matte(sd, (0, 0.8, 0.3))
+    pl = sd.tex(sd.plane((0, 0, 0), (0, 1, 0)), green)
+    items = [
+        sd.difference(sd.tex(sd.sphere((0, 1.5, 0), 1.5), m["mirror"]), sd.sphere((0.9, 2.2, 1.0), 1.0)),
+        sd.difference(sd.tex(sd.box((-4, 0, -1), (-2, 2, 1)), matte(sd, (0.4, 0.4, 0.8))), sd.sphere((-3, 1, 1), 0.9)),
+        sd.tex(sd.intersection([sd.sphere((3, 1, 0), 1.2), sd.box((2.2, 0.2, -0.8), (3.8, 1.8, 0.8))]), m["shiny_red"]),
+        sd.transform(sd.tex(sphereint(sd), matte(sd, (0.5, 0, 1))), [api.scale(np.float32([0.6, 0.6, 0.6])), api.translate(np.float32([-5.2, 1, 5]))]),
+        sd.tex(sd.difference(sd.sphere((0, -4, 5), 4.7), sd.sphere((1.5, 1.5, 5.2), 1.6)), m["mirror"]),  # TestScene.hs:127 (Q13 texture loss)
+    ]
+    root = sd.group([pl, sd.bih(items)])
+    sd.set_root(root)
+    _common(sd, nlights)
+    return sd
+
+
+CONFIGS = {
+    "S1": dict(make=lambda: s1(nlights=2, shadows=False), width=720, height=480, maxdepth=1),
+    "S2": dict(make=lambda: s1(nlights=1), width=720, height=480, maxdepth=1),
+    "S3": dict(make=lambda: s3(224), width=1920, height=1080, maxdepth=1),
+    "S3mesh": dict(make=lambda: s3(224, as_mesh=True), width=1920, height=1080, maxdepth=1),
+    "S4": dict(make=lambda: s4(), width=1920, height=1080, maxdepth=3),
+    "S5": dict(make=lambda: s3(708), width=3840, height=2160, maxdepth=1),
+}

@@ -1,0 +1,181 @@
+/* glome_hip.h -- C ABI of libglome_hip.so: the MI355X (gfx950) ray-tracing core that replaces
+ * glome's per-ray hot path behind glome's own constructor vocabulary.
+ *
+ * The reference (jimsnow/glome, Haskell) has no FFI boundary of its own; the seams this library
+ * sits behind are (paths relative to the reference tree):
+ *   - the `Solid` class methods  rayint / shadow / inside   GlomeTrace/Data/Glome/Solid.hs:146-166
+ *   - the tile map               renderTiles                 GlomeView/Glome.hs:379-386
+ *   - the scene constructors     sphere, triangle, box, ...  (cited per function below)
+ * Each entry point cites the reference interface it replaces.  INTEGRATION.md shows the Haskell
+ * `foreign import ccall` stubs a maintainer would add.
+ *
+ * Conventions
+ *   - Every function returning `int` returns 0 on success, <0 (a glome_status) on error; builder
+ *     functions returning int32_t return a node/material id >= 0, or <0 on error.  The message is
+ *     read with glome_sb_last_error / glome_last_error.  No C++ exception crosses the boundary.
+ *   - Scene constants cross as `double` (glome's `Flt = Double`, Vec.hs:9); the device computes in
+ *     fp32.  Ray / hit / framebuffer arrays are caller-owned fp32 SoA buffers, valid for the call.
+ *   - `_dev` variants take DEVICE pointers and run asynchronously on the context's HIP stream.
+ *   - A glome_ctx owns one device + one stream and is single-threaded; distinct contexts may be
+ *     driven from distinct threads.  A glome_scene is immutable after commit.
+ *   - There is NO CPU fallback: every compute entry point fails with GLOME_E_NO_DEVICE when no
+ *     gfx950 device is usable.  Builder and flatten-inspection calls are host-only.
+ */
+#ifndef GLOME_HIP_H
+#define GLOME_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct glome_ctx glome_ctx;     /* one GPU + one HIP stream */
+typedef struct glome_sb glome_sb;       /* scene builder: the host-side scene graph */
+typedef struct glome_scene glome_scene; /* flattened scene resident in HBM */
+
+enum glome_status {
+  GLOME_OK = 0,
+  GLOME_E_INVALID = -1,   /* bad argument / bad id */
+  GLOME_E_SCENE = -2,     /* scene validation failed (infinite bound in bih, corrupt matrix, ...) */
+  GLOME_E_NO_DEVICE = -3, /* no usable gfx950 device */
+  GLOME_E_HIP = -4,       /* HIP runtime error */
+  GLOME_E_LIMIT = -5      /* scene exceeds a device-side limit (nesting depth, texture stack, ...) */
+};
+
+/* ---- context ---- */
+glome_ctx* glome_ctx_create(int device_ordinal); /* NULL on failure; see glome_global_error() */
+void glome_ctx_destroy(glome_ctx*);
+const char* glome_last_error(const glome_ctx*);
+const char* glome_global_error(void);  /* error text when no ctx/sb exists yet */
+void* glome_ctx_stream(glome_ctx*);    /* the hipStream_t, for interop */
+int glome_ctx_synchronize(glome_ctx*);
+int glome_ctx_device_info(glome_ctx*, char* name, int cap, int* cu_count, int* warp_size);
+
+/* ---- transforms: Xfm = forward 3x4 (12 doubles, row major) + inverse 3x4 (12 doubles) ---- */
+int glome_xfm_translate(const double v[3], double out[24]);                          /* Vec.hs:564-567 */
+int glome_xfm_scale(const double v[3], double out[24]);                              /* Vec.hs:571-574 */
+int glome_xfm_rotate(const double axis[3], double angle_rad, double out[24]);        /* Vec.hs:577-598 */
+int glome_xfm_xyz_to_uvw(const double u[3], const double v[3], const double w[3], double out[24]); /* Vec.hs:602-622 */
+int glome_xfm_compose(const double* xfms /* n*24 */, int n, double out[24]);         /* Vec.hs:461-462 */
+
+/* ---- scene builder: one call per reference constructor ---- */
+glome_sb* glome_sb_new(void);
+void glome_sb_free(glome_sb*);
+const char* glome_sb_last_error(const glome_sb*);
+int32_t glome_sb_sphere(glome_sb*, const double c[3], double r);                                 /* Sphere.hs:15-17 */
+int32_t glome_sb_triangle(glome_sb*, const double p[9]);                                         /* Triangle.hs:18-20 */
+int32_t glome_sb_trianglenorm(glome_sb*, const double p[9], const double n[9]);                  /* Triangle.hs:34-35 */
+int32_t glome_sb_box(glome_sb*, const double a[3], const double b[3]);                           /* Box.hs:12-15 */
+int32_t glome_sb_plane(glome_sb*, const double pt[3], const double n[3]);                        /* Plane.hs:17-20 */
+int32_t glome_sb_plane_offset(glome_sb*, const double n[3], double off);                         /* Plane.hs:24-25 */
+int32_t glome_sb_disc(glome_sb*, const double pos[3], const double n[3], double r);              /* Cone.hs:29-31 */
+int32_t glome_sb_cylinder(glome_sb*, const double p1[3], const double p2[3], double r);          /* Cone.hs:40-48 */
+int32_t glome_sb_cone(glome_sb*, const double p1[3], double r1, const double p2[3], double r2);  /* Cone.hs:52-67 */
+int32_t glome_sb_group(glome_sb*, const int32_t* ids, int n);                                    /* Solid.hs:293-296 */
+int32_t glome_sb_transform(glome_sb*, int32_t id, const double* xfms /* n*24 */, int n);         /* Solid.hs:184,235 */
+int32_t glome_sb_difference(glome_sb*, int32_t a, int32_t b);                                    /* Csg.hs:26-27 */
+int32_t glome_sb_intersection(glome_sb*, const int32_t* ids, int n);                             /* Csg.hs:64-65 */
+int32_t glome_sb_bih(glome_sb*, const int32_t* ids, int n);                                      /* Bih.hs:309-324 */
+/* tris: 8 ints per triangle = a b c na nb nc tex tag (-1 = none), Mesh.hs:27-29; mats = the mesh's texture vector */
+int32_t glome_sb_mesh(glome_sb*, const double* verts, int nv, const double* norms, int nn,
+                      const int32_t* tris, int nt, const int32_t* mats, int nm);                 /* Mesh.hs:50-55 */
+int32_t glome_sb_tex(glome_sb*, int32_t id, int32_t material);                                   /* Tex.hs:33-34 */
+int32_t glome_sb_tag(glome_sb*, int32_t id);                                                     /* Tex.hs:38-39 (tags feed picking only) */
+int32_t glome_sb_noshadow(glome_sb*, int32_t id);                                                /* Tex.hs:43 */
+int32_t glome_sb_onlyshadow(glome_sb*, int32_t id);                                              /* Tex.hs:48 */
+int32_t glome_sb_bound_object(glome_sb*, int32_t bounding, int32_t bounded);                     /* Bound.hs:27-28 */
+int32_t glome_sb_innerbound(glome_sb*, int32_t inner, int32_t outer);                            /* Bound.hs:116 */
+int32_t glome_sb_flatten_transform(glome_sb*, int32_t id);  /* `SolidItem (flatten_transform s)`, Solid.hs:192,273 */
+int32_t glome_sb_tolist(glome_sb*, int32_t id);             /* `tolist`, Solid.hs:177,230: a list node of the flattened items */
+/* materials (the defunctionalised `Material`, Shader.hs:43-52; a texture is a material id = t_uniform, Shader.hs:55-56) */
+int32_t glome_sb_material_surface(glome_sb*, const double color[3], double alpha, double amb, double kd, double ks, double shine);
+int32_t glome_sb_material_reflect(glome_sb*, double refl);
+int32_t glome_sb_material_refract(glome_sb*, double refl, double refr, double ior);
+int32_t glome_sb_material_layers(glome_sb*, const int32_t* mats, int n);
+int32_t glome_sb_material_blend(glome_sb*, int32_t a, int32_t b, double weight);
+/* host-side inspection (no GPU needed) */
+int glome_sb_primcount(glome_sb*, int32_t id, long out3[3]);  /* primcount, Solid.hs:197,251 */
+int glome_sb_bound(glome_sb*, int32_t id, double out6[6]);    /* bound, Solid.hs:171 */
+/* Preorder dump of the BIH built for node `id` (axis = -1 marks a leaf; nleaf = its item count;
+ * leaf_prims = builder ids of leaf items in order).  Returns the node count, <0 on error. */
+long glome_sb_bih_dump(glome_sb*, int32_t id, long cap, double* lsplit, double* rsplit, int* axis, int* nleaf,
+                       int32_t* leaf_prims, long cap_prims);
+
+/* ---- commit: validate + flatten to packed SoA pools + upload to HBM ---- */
+glome_scene* glome_scene_commit(glome_ctx*, glome_sb*, int32_t root);
+void glome_scene_release(glome_scene*);
+typedef struct glome_scene_info {
+  int32_t tier;            /* 0 = flat fast path (LDS-stack kernels), 1 = generic interpreter */
+  int32_t nesting_depth;   /* composite nesting depth of the generic graph */
+  int64_t n_records, n_bih_nodes, n_mesh_nodes, n_triangles, n_spheres, n_other_prims, n_xfms, n_materials;
+  int32_t max_bih_depth, max_mesh_depth;
+  int64_t device_bytes;
+} glome_scene_info;
+int glome_scene_get_info(const glome_scene*, glome_scene_info* out);
+
+/* ---- per-ray seams (Solid.hs:146-166), host buffers ---- */
+/* closest hit: t < 0 marks a miss (RayMiss); prim = builder id of the primitive hit; tex4 = the hit's
+ * texture stack, innermost first, -1 padded (4 per ray).  Any output pointer may be NULL. */
+int glome_rayint_batch(glome_scene*, size_t n, const float* ox, const float* oy, const float* oz, const float* dx,
+                       const float* dy, const float* dz, const float* tmax, float* t, int32_t* prim, float* nx,
+                       float* ny, float* nz, int32_t* tex4);
+int glome_shadow_batch(glome_scene*, size_t n, const float* ox, const float* oy, const float* oz, const float* dx,
+                       const float* dy, const float* dz, const float* tmax, uint8_t* occluded);
+int glome_inside_batch(glome_scene*, size_t n, const float* px, const float* py, const float* pz, uint8_t* inside);
+/* the same on device pointers, asynchronous on the ctx stream */
+int glome_rayint_batch_dev(glome_scene*, size_t n, const float* ox, const float* oy, const float* oz, const float* dx,
+                           const float* dy, const float* dz, const float* tmax, float* t, int32_t* prim, float* nx,
+                           float* ny, float* nz, int32_t* tex4);
+int glome_shadow_batch_dev(glome_scene*, size_t n, const float* ox, const float* oy, const float* oz, const float* dx,
+                           const float* dy, const float* dz, const float* tmax, uint8_t* occluded);
+
+/* ---- whole-frame seam (renderTiles, Glome.hs:379-386; Scene tuple, TestScene.hs:15) ---- */
+typedef struct glome_camera { float pos[3], fwd[3], up[3], right[3]; } glome_camera; /* Scene.hs:35 */
+int glome_camera_lookat(const double pos[3], const double at[3], const double up[3], double angle_deg,
+                        glome_camera* out); /* camera, Scene.hs:48-57 */
+typedef struct glome_light {               /* Light, Shader.hs:13-23; falloff is fixed to 1/d^2 as `light` builds it */
+  float pos[3], color[3], rad;
+  int32_t shadow;
+} glome_light;
+enum { GLOME_MODE_TILE = 0 /* renderTile, Glome.hs:162-176 */, GLOME_MODE_SUBSAMPLE = 1 /* renderTileSubsample, :226-323 */ };
+typedef struct glome_render_params {
+  int32_t width, height;
+  int32_t mode;          /* GLOME_MODE_* */
+  int32_t blocksize;     /* tile edge, Glome.hs:116 (65) */
+  int32_t maxdepth;      /* Glome.hs:25 (3); 1..4 supported */
+  int32_t fog;           /* 1: TILE mode stores r + depth/400 like Glome.hs:174; 0: the get_color tuple */
+  float thresholds[4];   /* Glome.hs:221-224 */
+  int32_t tile_first, tile_stride; /* shard: render tiles tile_first, tile_first+tile_stride, ... (x-major order) */
+  int32_t faithful;      /* 1: BIH traversal without ordered early-out, exactly as Bih.hs:332-368 visits nodes */
+  int32_t count_work;    /* 1: count node visits / primitive tests (slower).  Either flag selects the analysis
+                            kernel, which does both (flat tier); the generic tier always counts. */
+} glome_render_params;
+void glome_render_params_default(glome_render_params*);
+typedef struct glome_stats {
+  uint64_t rays_primary, rays_shadow, rays_secondary; /* rays actually traversed */
+  uint64_t bih_nodes, mesh_nodes, prim_tests;         /* only when count_work */
+  float kernel_ms;                                    /* HIP-event time of the render kernel(s) on the ctx stream */
+  int32_t n_tiles, n_pixels;
+} glome_stats;
+/* rgbad: width*height*5 floats (r,g,b,a,depth per pixel, row major; pixels of tiles this call does not own are
+ * left untouched); packed: width*height 0x00RRGGBB words as blitTile/rgbf produce (Glome.hs:353-358, 107-110) or NULL. */
+int glome_render(glome_scene*, const glome_camera*, const glome_light* lights, int nlights,
+                 const glome_render_params*, float* rgbad, uint32_t* packed, glome_stats*);
+/* Device-pointer variant.  Asynchronous on the ctx stream unless stats != NULL (then it synchronizes to read
+ * the counters and the event timer). */
+int glome_render_dev(glome_scene*, const glome_camera*, const glome_light* lights, int nlights,
+                     const glome_render_params*, float* rgbad_dev, uint32_t* packed_dev, glome_stats*);
+/* Tile payload transport for multi-GPU sharding (Tile = Rect + pixel vector, Glome.hs:153-154).
+ * pack: copy this rank's owned tiles from a full frame into a dense payload (tiles in owned order, row major
+ * inside a tile, 5 floats per pixel).  blit: scatter a payload of the tiles owned by (tile_first, tile_stride)
+ * back into a full frame (blitTile, Glome.hs:353-358).  glome_tiles_payload_floats gives the payload size. */
+int64_t glome_tiles_payload_floats(const glome_render_params*, int tile_first, int tile_stride);
+int glome_tiles_pack_dev(glome_ctx*, const glome_render_params*, const float* rgbad_dev, float* payload_dev);
+int glome_tiles_blit_dev(glome_ctx*, const glome_render_params*, int tile_first, int tile_stride,
+                         const float* payload_dev, float* rgbad_dev, uint32_t* packed_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLOME_HIP_H */
