@@ -120,6 +120,13 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP extension has not been built (run `python glome_amd/build.py`). "
             "glome_amd has no CPU fallback.")
+    # torch bundles its own HIP runtime under the same soname (libamdhip64.so.7).  Two HIP runtimes cannot share
+    # one process, so when torch is installed let it load first; this library then binds to the same runtime and
+    # torch tensors / torch.distributed (RCCL) can be used beside it.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, res, args in SYMBOLS:
         f = getattr(lib, name)  # AttributeError if a declared symbol is not exported

@@ -370,8 +370,8 @@ GD void bih_traverse(const DScene& S, uint32_t hdr, const Ray& r, float d, STK& 
       if (MODE == 0 || !(nearv > farv)) {
         if (leaf(w1, as_u(n.x), w0 >> 2, farv)) return;
       }
+    } else if (COUNT && (cnt.bih++, false)) {  // rayint_debug_bih counts every branch entered, before the near > far test (Bih.hs:389-410)
     } else if (!(nearv > farv)) {
-      if (COUNT) cnt.bih++;
       float dirr = vcomp(rcp, axis), o = vcomp(r.o, axis);
       float dl = (n.x - o) * dirr, dr = (n.y - o) * dirr;
       uint32_t left = w0 >> 2, right = w1;

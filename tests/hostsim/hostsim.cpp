@@ -1,0 +1,147 @@
+// hostsim.cpp -- TEST INFRASTRUCTURE ONLY.  Compiles the per-ray device headers (rt_device.hpp / rt_generic.hpp)
+// as plain host C++ so their logic -- and the flattened layout they index -- can be checked against the oracle on a
+// machine without a GPU, before a kernel is ever launched.  It is not part of libglome_hip.so, nothing in glome_amd
+// imports it, and bench.py never times it.  GPU parity tests (-m gpu) go through the real C ABI.
+#include <cstring>
+
+#include "../../glome_amd/csrc/capi_shared.hpp"
+#include "../../glome_amd/csrc/flatten.hpp"
+#include "../../glome_amd/csrc/rt_device.hpp"
+#include "../../glome_amd/csrc/rt_generic.hpp"
+
+using namespace glome;
+
+struct SimScene {
+  FlatScene F;
+  DScene D;
+  std::string err;
+};
+
+template <bool ANALYSIS, bool FULL_> struct HostFlatTier {
+  static constexpr bool FULL = FULL_;
+  const DScene& S;
+  const DLight* lights;
+  int nlights;
+  LaneStack stk;
+  Cnt cnt;
+  HitG closest(const Ray& r, float tmax) { Cand c = closest_flat<ANALYSIS, ANALYSIS>(S, r, tmax, stk, cnt); return finalize_flat(S, r, c); }
+  bool occluded(const Ray& r, float d) { return occluded_flat<ANALYSIS>(S, r, d, stk, cnt); }
+  HitG closest_ni(const Ray& r, float tmax) { return closest(r, tmax); }
+  bool occluded_ni(const Ray& r, float d) { return occluded(r, d); }
+};
+struct HostGenericTier {
+  static constexpr bool FULL = true;
+  const DScene& S;
+  const DLight* lights;
+  int nlights;
+  Cnt cnt;
+  unsigned int err = 0;
+  HitG closest(const Ray& r, float tmax) { GCtx<true> g{S, cnt, err}; HitG h = rayint_g<kGenericDepth>(g, S.recs[S.root_rec], r, tmax, (TexStack)0); err = g.err; return h; }
+  bool occluded(const Ray& r, float d) { GCtx<true> g{S, cnt, err}; bool o = shadow_g<kGenericDepth>(g, S.recs[S.root_rec], r, d); err = g.err; return o; }
+  HitG closest_ni(const Ray& r, float tmax) { return closest(r, tmax); }
+  bool occluded_ni(const Ray& r, float d) { return occluded(r, d); }
+};
+
+struct HostStack {
+  uint32_t node[kFlatStack]; float nearv[kFlatStack], farv[kFlatStack];
+  LaneStack lane(int cap) { LaneStack s; s.node = node; s.nearv = nearv; s.farv = farv; s.cap = cap; return s; }
+};
+
+extern "C" {
+void* hostsim_commit(glome_sb* sb, int root, char* errbuf, int cap) {
+  SimScene* s = new SimScene();
+  try {
+    Flattener fl(sb_graph(sb), s->F);
+    fl.run(root);
+  } catch (std::exception& e) { snprintf(errbuf, cap, "%s", e.what()); delete s; return nullptr; }
+  FlatScene& F = s->F;
+  DScene& D = s->D;
+  D.recs = F.recs.data(); D.spheres = F.spheres.data(); D.tris = F.tris.data(); D.trinorms = F.trinorms.data(); D.boxes = F.boxes.data();
+  D.planes = F.planes.data(); D.discs = F.discs.data(); D.quadrics = F.quadrics.data(); D.xfms = F.xfms.data(); D.bihhdr = F.bihhdr.data();
+  D.bihnodes = F.bihnodes.data(); D.meshhdr = F.meshhdr.data(); D.meshnodes = F.meshnodes.data(); D.mtris = F.mtris.data();
+  D.mtrimeta = F.mtrimeta.data(); D.mats = F.mats.data(); D.matkids = F.matkids.data(); D.entries = F.entries.data();
+  D.n_entries = F.tier == 0 ? (uint32_t)F.entries.size() : 0; D.root_rec = F.root_rec; D.tier = F.tier; D.n_mats = (uint32_t)sb_graph(sb).mats.size();
+  return s;
+}
+void hostsim_free(void* s) { delete (SimScene*)s; }
+int hostsim_info(void* sv, int* out) {  // tier, nesting, max_bih_depth, max_mesh_depth, n_entries, n_recs
+  SimScene* s = (SimScene*)sv;
+  out[0] = (int)s->F.tier; out[1] = s->F.nesting_depth; out[2] = s->F.max_bih_depth; out[3] = s->F.max_mesh_depth;
+  out[4] = (int)s->D.n_entries; out[5] = (int)s->F.recs.size();
+  return 0;
+}
+// tier: -1 = the scene's own tier, 0 = flat (must be legal), 1 = generic; analysis: faithful traversal + counters
+int hostsim_rayint(void* sv, int tier, int analysis, size_t n, const float* ox, const float* oy, const float* oz, const float* dx, const float* dy,
+                   const float* dz, const float* tmax, float* t, int* prim, float* nrm, int* tex4, unsigned long long* counters) {
+  SimScene* s = (SimScene*)sv;
+  if (tier < 0) tier = (int)s->D.tier;
+  if (tier == 0 && s->D.tier != 0) return -1;
+  HostStack hs;
+  Cnt total;
+  unsigned int err = 0;
+  for (size_t i = 0; i < n; i++) {
+    Ray r; r.o = v3(ox[i], oy[i], oz[i]); r.d = v3(dx[i], dy[i], dz[i]);
+    HitG h;
+    if (tier == 0) {
+      if (analysis) { HostFlatTier<true, false> T{s->D, nullptr, 0, hs.lane(kFlatStack), Cnt()}; h = T.closest(r, tmax[i]); total.bih += T.cnt.bih; total.prim += T.cnt.prim; total.mesh += T.cnt.mesh; }
+      else { HostFlatTier<false, false> T{s->D, nullptr, 0, hs.lane(kFlatStack), Cnt()}; h = T.closest(r, tmax[i]); }
+    } else {
+      HostGenericTier T{s->D, nullptr, 0, Cnt()};
+      h = T.closest(r, tmax[i]);
+      err |= T.err; total.bih += T.cnt.bih; total.prim += T.cnt.prim; total.mesh += T.cnt.mesh;
+    }
+    t[i] = h.hit ? h.t : -1.0f;
+    if (prim) prim[i] = h.hit ? (int)h.uid : -1;
+    if (nrm) { nrm[3 * i] = h.n.x; nrm[3 * i + 1] = h.n.y; nrm[3 * i + 2] = h.n.z; }
+    if (tex4) for (int k = 0; k < 4; k++) tex4[4 * i + k] = h.hit ? (int)((h.tex >> (16 * k)) & 0xffff) - 1 : -1;
+  }
+  if (counters) { counters[0] = total.bih; counters[1] = total.mesh; counters[2] = total.prim; }
+  return err ? -2 : 0;
+}
+int hostsim_shadow(void* sv, int tier, size_t n, const float* ox, const float* oy, const float* oz, const float* dx, const float* dy, const float* dz,
+                   const float* tmax, unsigned char* occ) {
+  SimScene* s = (SimScene*)sv;
+  if (tier < 0) tier = (int)s->D.tier;
+  if (tier == 0 && s->D.tier != 0) return -1;
+  HostStack hs;
+  unsigned int err = 0;
+  for (size_t i = 0; i < n; i++) {
+    Ray r; r.o = v3(ox[i], oy[i], oz[i]); r.d = v3(dx[i], dy[i], dz[i]);
+    if (tier == 0) { HostFlatTier<false, false> T{s->D, nullptr, 0, hs.lane(kFlatStack), Cnt()}; occ[i] = T.occluded(r, tmax[i]); }
+    else { HostGenericTier T{s->D, nullptr, 0, Cnt()}; occ[i] = T.occluded(r, tmax[i]); err |= T.err; }
+  }
+  return err ? -2 : 0;
+}
+int hostsim_inside(void* sv, size_t n, const float* px, const float* py, const float* pz, unsigned char* in) {
+  SimScene* s = (SimScene*)sv;
+  Cnt cnt; unsigned int err = 0;
+  GCtx<true> g{s->D, cnt, err};
+  for (size_t i = 0; i < n; i++) in[i] = inside_g<kGenericDepth>(g, s->D.recs[s->D.root_rec], v3(px[i], py[i], pz[i]));
+  return g.err ? -2 : 0;
+}
+// whole-frame, 1 ray per pixel (renderTile); cam = 12 floats, lights = nl x 8 floats (pos3 col3 rad shadow)
+int hostsim_render(void* sv, int tier, const float* cam, const float* lights, int nl, int width, int height, int maxdepth, float* out5, unsigned long long* counters) {
+  SimScene* s = (SimScene*)sv;
+  if (tier < 0) tier = (int)s->D.tier;
+  if (tier == 0 && s->D.tier != 0) return -1;
+  DCamera C; memcpy(&C, cam, sizeof(C));
+  DLight L[kMaxLights];
+  for (int i = 0; i < nl; i++) { memcpy(L[i].pos, lights + 8 * i, 12); memcpy(L[i].color, lights + 8 * i + 3, 12); L[i].rad = lights[8 * i + 6]; L[i].shadow = lights[8 * i + 7] != 0; }
+  HostStack hs;
+  Cnt total;
+  unsigned int err = 0;
+  for (int py = 0; py < height; py++)
+    for (int px = 0; px < width; px++) {
+      float xc, yc;
+      get_coordsf(width, height, (float)px, (float)py, xc, yc);
+      Ray ray = primary_ray(C, xc, yc);
+      HitG h; CA c;
+      if (tier == 0) { HostFlatTier<false, true> T{s->D, L, nl, hs.lane(kFlatStack), Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, &h); total.shadow += T.cnt.shadow; total.secondary += T.cnt.secondary; }
+      else { HostGenericTier T{s->D, L, nl, Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, &h); err |= T.err; total.shadow += T.cnt.shadow; total.secondary += T.cnt.secondary; }
+      float* o = out5 + ((size_t)py * width + px) * 5;
+      o[0] = c.r; o[1] = c.g; o[2] = c.b; o[3] = c.a; o[4] = h.hit ? h.t : kInf;
+    }
+  if (counters) { counters[0] = (unsigned long long)width * height; counters[1] = total.shadow; counters[2] = total.secondary; }
+  return err ? -2 : 0;
+}
+}
