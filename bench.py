@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline metric on MI355X: Mrays/s (and fps) of whole-frame rendering at 1920x1080,
+primary + shadow rays, on the 100k-triangle BIH scene (BASELINE.json configs[2] = SURVEY.md scene S3).
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one frame: every pixel's primary ray + its shadow rays through the hot path (raygen -> BIH closest hit ->
+shadow any-hit -> shade), scene resident in HBM.  With N GPUs the frame's 65x65 reference tiles are sharded round-robin
+and gathered to rank 0 with one RCCL gather (strong scaling: the frame is fixed).  Rank 0 prints ONE JSON line.
+
+The line carries `roofline` (dominant kernel vs the 8 TB/s HBM roofline, algorithmic bytes per SURVEY.md 8(d), kernel
+time from HIP events recorded on the launch stream over the timed region) and `cpu_baseline` (the CPU oracle -- a C++
+restatement of the reference algorithm, kind "port" -- timed on this box's host cores on a bounded tile sample).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--scene", default="S3", help="S1 S2 S3 S3mesh S4 S5 (default: the headline workload S3)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    import torch  # device memory, streams, torch.distributed (RCCL)
+
+    from glome_amd import _lib as L
+    from glome_amd import api, dist, scenes
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device is visible (there is no CPU path to time)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as tdist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        tdist.init_process_group("nccl", device_id=device)
+
+    cfg = scenes.CONFIGS[args.scene]
+    sd = cfg["make"]()
+    W, H, maxdepth = cfg["width"], cfg["height"], cfg["maxdepth"]
+    t0 = time.time()
+    b = api.Builder()
+    nmap, _ = sd.replay(b)
+    ctx = api.Context(local)
+    scene = ctx.commit(b, nmap[sd.root])
+    setup_s = time.time() - t0
+    info = scene.info()
+    cam = api.camera(*sd.cam)
+    lights = [api.light(p, c, r, s) for (p, c, r, s) in sd.lights]
+    P = api.render_params(width=W, height=H, maxdepth=maxdepth)
+
+    sf = dist.ShardedFrame(scene, P, rank, world, device)
+
+    def barrier():
+        if world > 1:
+            tdist.barrier()
+        torch.cuda.synchronize(device)
+
+    # ray count of one frame (identical every step: the scene and camera are fixed)
+    st = sf.step(cam, lights, stats=True)
+    rays_local = torch.tensor([st["rays_primary"], st["rays_shadow"], st["rays_secondary"]], dtype=torch.float64, device=device) if world > 1 else None
+    if world > 1:
+        tdist.all_reduce(rays_local)
+        rays = [int(x) for x in rays_local.tolist()]
+    else:
+        rays = [st["rays_primary"], st["rays_shadow"], st["rays_secondary"]]
+    rays_per_step = sum(rays)
+
+    for _ in range(args.warmup):
+        sf.step(cam, lights)
+    barrier()
+    ctx.lib.glome_ctx_timing_begin(ctx.h, args.steps)
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        sf.step(cam, lights)
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    kms = np.zeros(args.steps, np.float32)
+    nk = ctx.lib.glome_ctx_timing_end(ctx.h, kms.ctypes.data_as(L.c_fp), args.steps)
+    if world > 1:
+        e = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tdist.all_reduce(e, op=tdist.ReduceOp.MAX)
+        elapsed = float(e.item())
+
+    if rank != 0:
+        if world > 1:
+            tdist.barrier()
+            tdist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = rays_per_step / (elapsed / args.steps) / 1e6
+
+    # ---- roofline of the dominant kernel (rank 0's render launch) ----
+    # algorithmic bytes: 32 B ray in + 32 B hit out per closest-hit ray, 32 + 4 per shadow ray,
+    # 16 B per BIH node visited, S_prim per primitive tested (48 B triangle, 16 B sphere); node / primitive visits are
+    # the reference algorithm's (no early-out, rayint_debug convention, Bih.hs:378-412), counted by the faithful kernel
+    # on this very frame (tests pin those counts to the CPU oracle's).
+    Pl = dist._clone_params(P, tile_first=(rank if world > 1 else 0), tile_stride=world)
+    tmp = torch.zeros((H, W, 5), dtype=torch.float32, device=device)
+    Pf = dist._clone_params(Pl, faithful=1, count_work=1)
+    stf = scene.render_dev(cam, lights, Pf, tmp.data_ptr())
+    Pc = dist._clone_params(Pl, faithful=0, count_work=1)
+    stc = scene.render_dev(cam, lights, Pc, tmp.data_ptr())
+    s_prim = 48 if info["n_triangles"] >= info["n_spheres"] else 16
+    node_b = 64 if info["n_mesh_nodes"] > info["n_bih_nodes"] else 16
+
+    def algo_bytes(s):
+        return (s["rays_primary"] + s["rays_secondary"]) * 64 + s["rays_shadow"] * 36 + (s["bih_nodes"] * 16 + s["mesh_nodes"] * 64) + s["prim_tests"] * s_prim
+
+    kavg_ms = float(np.mean(kms[:nk])) if nk > 0 else float("nan")
+    bytes_ref = algo_bytes(stf)
+    achieved = bytes_ref / (kavg_ms * 1e-3) / 1e9
+    traffic = None
+    pmc = os.path.join(HERE, "profiles", "pmc_traffic.json")  # written from a separate rocprofv3 --pmc run (profiles/README.md)
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get(args.scene, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {
+        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": traffic,
+        "kernel": "k_render_flat" if info["tier"] == 0 else "k_render_generic", "kernel_ms_avg": round(kavg_ms, 4), "launches_timed": int(nk),
+        "algorithmic_bytes_per_launch": int(bytes_ref),
+        "per_ray": {"nodes": round((stf["bih_nodes"] + stf["mesh_nodes"]) / max(1, sum(rays) // world), 2), "prims": round(stf["prim_tests"] / max(1, sum(rays) // world), 2)},
+        "visited_bytes_per_launch_early_out": int(algo_bytes(stc)),
+        "frac_of_measured_copy_ceiling_6290GBs": round(achieved / 6290.0, 4),
+    }
+
+    # ---- cpu_baseline: the oracle on a bounded sample of the same frame (every 4th tile), all host cores ----
+    cpu = None
+    if not args.no_cpu:
+        sys.path.insert(0, os.path.join(HERE, "tests"))
+        from oracle import oracle_py as O  # the checker, timed as the CPU baseline (kind "port")
+        o, onmap, _ = O.load_scene(sd)
+        o.set_camera_vectors(list(cam.pos), list(cam.fwd), list(cam.up), list(cam.right))
+        # threads actually used: this process's CPU share, capped at the 16 host cores a one-GPU box is given
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        cores = max(1, min(avail, 16))
+        stride = 1  # the whole frame: ~40 core-seconds of oracle work at 1920x1080
+        tc = time.perf_counter()
+        _, _, oc = o.render(W, H, maxdepth=maxdepth, tile_first=0, tile_stride=stride, nthreads=cores, want_packed=False)
+        cpu_s = time.perf_counter() - tc
+        cpu_rays = oc["rays_primary"] + oc["rays_shadow"] + oc["rays_secondary"]
+        cpu = {"value": round(cpu_rays / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+               "sample": f"the same {W}x{H} frame, all 65x65 tiles ({cpu_rays} rays, {cpu_s:.1f} s wall on {cores} threads), fp64 C++ restatement of the reference algorithm (oracle/), tiles handed out dynamically like parMap",
+               "seconds": round(cpu_s, 2)}
+
+    out = {
+        "metric": "Mrays/sec + fps at 1920x1080 primary+shadow; 1/2/4/8 MI355X" if (W, H) == (1920, 1080) else f"Mrays/sec + fps at {W}x{H}",
+        "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "fps": round(1e3 / ms_per_step, 1), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.scene}: " + {"S3": "100,352-triangle heightfield under bih (BASELINE configs[2]), 1 light, primary + shadow rays, maxdepth 1",
+                                                     "S3mesh": "100,352-triangle heightfield as mesh (2-box BVH)", "S5": "1,002,528-triangle heightfield under bih"}.get(args.scene, args.scene),
+                   "width": W, "height": H, "rays_per_frame": {"primary": rays[0], "shadow": rays[1], "secondary": rays[2]},
+                   "sampling": "renderTile, 1 primary ray/pixel", "tiles": "65x65 reference tiles, round-robin over ranks, RCCL gather to rank 0" if world > 1 else "65x65 reference tiles, one GPU",
+                   "scene_setup_s": round(setup_s, 2), "device_bytes": info["device_bytes"]},
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        tdist.barrier()
+        tdist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -51,6 +51,9 @@ SYMBOLS = [
     ("glome_global_error", C.c_char_p, []),
     ("glome_ctx_stream", vp, [vp]),
     ("glome_ctx_synchronize", C.c_int, [vp]),
+    ("glome_ctx_use_stream", C.c_int, [vp, vp]),
+    ("glome_ctx_timing_begin", C.c_int, [vp, C.c_int]),
+    ("glome_ctx_timing_end", C.c_int, [vp, c_fp, C.c_int]),
     ("glome_ctx_device_info", C.c_int, [vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("glome_xfm_translate", C.c_int, [c_dp, c_dp]),
     ("glome_xfm_scale", C.c_int, [c_dp, c_dp]),
@@ -103,7 +106,9 @@ SYMBOLS = [
     ("glome_render_params_default", None, [C.POINTER(RenderParams)]),
     ("glome_render", C.c_int, [vp, C.POINTER(Camera), C.POINTER(Light), C.c_int, C.POINTER(RenderParams), c_fp, c_up, C.POINTER(Stats)]),
     ("glome_render_dev", C.c_int, [vp, C.POINTER(Camera), C.POINTER(Light), C.c_int, C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]),
+    ("glome_render_tiles_dev", C.c_int, [vp, C.POINTER(Camera), C.POINTER(Light), C.c_int, C.POINTER(RenderParams), vp, C.POINTER(Stats)]),
     ("glome_tiles_payload_floats", C.c_int64, [C.POINTER(RenderParams), C.c_int, C.c_int]),
+    ("glome_tiles_layout", C.c_int, [C.POINTER(RenderParams), C.c_int, C.c_int, c_ip, C.c_int]),
     ("glome_tiles_pack_dev", C.c_int, [vp, C.POINTER(RenderParams), vp, vp]),
     ("glome_tiles_blit_dev", C.c_int, [vp, C.POINTER(RenderParams), C.c_int, C.c_int, vp, vp, vp]),
 ]

@@ -4,6 +4,7 @@
 
 #include "../../include/glome_hip.h"
 #include "capi_shared.hpp"
+#include "tiles.hpp"
 
 using namespace glome;
 
@@ -151,6 +152,16 @@ long glome_sb_bih_dump(glome_sb* sb, int32_t id, long cap, double* lsplit, doubl
     }
     return cnt;
   } catch (const std::exception& e) { sb->err = e.what(); return GLOME_E_INVALID; }
+}
+
+int glome_tiles_layout(const glome_render_params* P, int tile_first, int tile_stride, int32_t* xywh_base, int cap) {
+  if (!P || P->width <= 0 || P->height <= 0 || P->blocksize <= 0 || tile_stride <= 0 || tile_first < 0) return GLOME_E_INVALID;
+  std::vector<DTile> t; uint32_t w; int64_t px;
+  owned_tiles(P->width, P->height, P->blocksize, tile_first, tile_stride, t, w, px);
+  for (size_t k = 0; k < t.size() && (int)k < cap; k++) {
+    xywh_base[5 * k] = t[k].x; xywh_base[5 * k + 1] = t[k].y; xywh_base[5 * k + 2] = t[k].w; xywh_base[5 * k + 3] = t[k].h; xywh_base[5 * k + 4] = (int32_t)t[k].pix_base;
+  }
+  return (int)t.size();
 }
 
 }  // extern "C"

@@ -21,16 +21,17 @@
 #include "../../include/glome_hip.h"
 #include "capi_shared.hpp"
 #include "flatten.hpp"
+#include "tiles.hpp"
 #include "rt_device.hpp"
 #include "rt_generic.hpp"
 
 using namespace glome;
 
 // ------------------------------------------------------------------------------------------------ tiers
-// ANALYSIS = the reference's exact node-visit order (no ordered early-out, Bih.hs:332-368) + work counters; it
-// backs the `faithful` / `count_work` render params (byte-model measurement, parity tests).  The production
-// variant traverses with early-out and counts rays only.
-template <bool ANALYSIS, bool FULL_>
+// FAITHFUL = the reference's exact node-visit order (no ordered early-out, Bih.hs:332-368); COUNT = node / primitive
+// work counters.  They back the `faithful` / `count_work` render params (byte-model measurement, parity tests).
+// The production variant traverses with early-out and counts rays only.
+template <bool FAITHFUL, bool COUNT, bool FULL_>
 struct FlatTier {
   static constexpr bool FULL = FULL_;  // false: lean kernel -- no out-of-line calls at all (no secondary rays, no Blend/Layers)
   const DScene& S;
@@ -39,10 +40,10 @@ struct FlatTier {
   LaneStack stk;
   Cnt cnt;
   __device__ __forceinline__ HitG closest(const Ray& r, float tmax) {
-    Cand c = closest_flat<ANALYSIS, ANALYSIS>(S, r, tmax, stk, cnt);
+    Cand c = closest_flat<FAITHFUL, COUNT>(S, r, tmax, stk, cnt);
     return finalize_flat(S, r, c);
   }
-  __device__ __forceinline__ bool occluded(const Ray& r, float d) { return occluded_flat<ANALYSIS>(S, r, d, stk, cnt); }
+  __device__ __forceinline__ bool occluded(const Ray& r, float d) { return occluded_flat<COUNT>(S, r, d, stk, cnt); }
   __device__ __noinline__ HitG closest_ni(const Ray& r, float tmax) { return closest(r, tmax); }
   __device__ __noinline__ bool occluded_ni(const Ray& r, float d) { return occluded(r, d); }
 };
@@ -102,7 +103,7 @@ __device__ __forceinline__ void flush_counters(DCounters* c, const Cnt& cnt, uns
 
 // work item w -> tile + 64 pixels.  A tile is cut into 8x8 blocks (coherent rays per wave); the pixels left over on
 // the right and bottom edges (65 = 8*8 + 1) are packed 64 at a time, so lanes are not wasted on partial blocks.
-__device__ __forceinline__ bool work_to_pixel(const DRenderArgs& A, uint32_t w, int lane, int& px, int& py) {
+__device__ __forceinline__ bool work_to_pixel(const DRenderArgs& A, uint32_t w, int lane, int& px, int& py, size_t& dense_off) {
   int lo = 0, hi = A.ntiles - 1;
   while (lo < hi) {
     int mid = (lo + hi + 1) >> 1;
@@ -126,6 +127,7 @@ __device__ __forceinline__ bool work_to_pixel(const DRenderArgs& A, uint32_t w, 
     }
   }
   px = t.x + lx; py = t.y + ly;
+  dense_off = (size_t)t.pix_base + (size_t)ly * t.w + lx;
   return true;
 }
 
@@ -138,7 +140,8 @@ __device__ __forceinline__ void render_loop(const DRenderArgs& A, TIER& T) {
     w = __shfl(w, 0, 64);
     if (w >= A.total_waves) break;
     int px, py;
-    if (!work_to_pixel(A, w, lane, px, py)) continue;
+    size_t dense_off;
+    if (!work_to_pixel(A, w, lane, px, py, dense_off)) continue;
     float xc, yc;
     get_coordsf(A.width, A.height, (float)px, (float)py, xc, yc);
     Ray ray = primary_ray(A.cam, xc, yc);
@@ -148,17 +151,17 @@ __device__ __forceinline__ void render_loop(const DRenderArgs& A, TIER& T) {
     float depth = h.hit ? h.t : kInf;      // ridepth
     float r = c.r;
     if (A.fog) r = r + (depth / 400);      // renderTile's debug fog (Glome.hs:174, Q20)
-    size_t o = (size_t)py * A.width + px;
+    size_t o = A.dense ? dense_off : (size_t)py * A.width + px;
     float* out = A.out5 + o * 5;
     out[0] = r; out[1] = c.g; out[2] = c.b; out[3] = c.a; out[4] = depth;
     if (A.packed) A.packed[o] = rgbf(r * c.a, c.g * c.a, c.b * c.a);  // blitTile (Glome.hs:353-358)
   }
 }
 
-template <bool ANALYSIS, bool FULL>
+template <bool FAITHFUL, bool COUNT, bool FULL>
 __global__ void __launch_bounds__(64) k_render_flat(DRenderArgs A, int stack_cap) {
   extern __shared__ uint32_t lds[];
-  FlatTier<ANALYSIS, FULL> T{A.S, A.lights, A.nlights, lane_stack(lds, stack_cap), Cnt()};
+  FlatTier<FAITHFUL, COUNT, FULL> T{A.S, A.lights, A.nlights, lane_stack(lds, stack_cap), Cnt()};
   render_loop(A, T);
   flush_counters(A.counters, T.cnt, 0);
 }
@@ -189,16 +192,16 @@ __device__ __forceinline__ Ray load_ray(const RayStream& R, size_t i) {
   r.d = v3(R.dx[i], R.dy[i], R.dz[i]);
   return r;
 }
-template <bool ANALYSIS>
+template <bool FAITHFUL>
 __global__ void __launch_bounds__(64) k_rayint_batch_flat(DScene S, size_t n, RayStream R, HitStream H, int stack_cap) {
   extern __shared__ uint32_t lds[];
-  FlatTier<ANALYSIS, false> T{S, nullptr, 0, lane_stack(lds, stack_cap), Cnt()};
+  FlatTier<FAITHFUL, false, false> T{S, nullptr, 0, lane_stack(lds, stack_cap), Cnt()};
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     store_hit(H, i, T.closest(load_ray(R, i), R.tmax[i]));
 }
 __global__ void __launch_bounds__(64) k_shadow_batch_flat(DScene S, size_t n, RayStream R, uint8_t* occ, int stack_cap) {
   extern __shared__ uint32_t lds[];
-  FlatTier<false, false> T{S, nullptr, 0, lane_stack(lds, stack_cap), Cnt()};
+  FlatTier<false, false, false> T{S, nullptr, 0, lane_stack(lds, stack_cap), Cnt()};
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     occ[i] = T.occluded(load_ray(R, i), R.tmax[i]) ? 1 : 0;
 }
@@ -253,6 +256,11 @@ __global__ void k_tiles_blit(const DTile* tiles, int ntiles, int width, const fl
 struct glome_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;
+  // event pool: while timing is on, every render launch records its own (start, stop) pair
+  std::vector<hipEvent_t> pool;
+  int pool_used = 0;
+  bool timing = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipDeviceProp_t prop;
   DCounters* d_counters = nullptr;
@@ -280,36 +288,6 @@ static std::string g_global_error;
     }                                                                                              \
   } while (0)
 
-static std::vector<std::pair<int, int>> chunk(int size, int blocksize) {  // Glome.hs:371-377
-  std::vector<std::pair<int, int>> o;
-  int pos = 0;
-  for (;;) {
-    if (pos + blocksize >= size) { o.push_back({pos, size - pos}); break; }
-    o.push_back({pos, blocksize});
-    pos += blocksize;
-  }
-  return o;
-}
-static uint32_t tile_waves(int w, int h) {
-  uint32_t nbx = w >> 3, nby = h >> 3;
-  uint32_t rest = (uint32_t)(w * h) - nbx * nby * 64;
-  return nbx * nby + (rest + 63) / 64;
-}
-// tiles owned by (first, stride) in renderTiles' order: x chunks outer, y chunks inner (Glome.hs:382-384)
-static void owned_tiles(int width, int height, int blocksize, int first, int stride, std::vector<DTile>& out, uint32_t& total_waves, int64_t& pixels) {
-  out.clear(); total_waves = 0; pixels = 0;
-  int k = 0;
-  for (auto& xc : chunk(width, blocksize))
-    for (auto& yc : chunk(height, blocksize)) {
-      if (k >= first && (k - first) % stride == 0) {
-        DTile t{xc.first, yc.first, xc.second, yc.second, total_waves, (uint32_t)pixels};
-        out.push_back(t);
-        total_waves += tile_waves(t.w, t.h);
-        pixels += (int64_t)t.w * t.h;
-      }
-      k++;
-    }
-}
 static int check_params(glome_ctx* ctx, const glome_render_params* P) {
   if (!P || P->width <= 0 || P->height <= 0 || P->blocksize <= 0 || P->tile_stride <= 0 || P->tile_first < 0) { ctx->err = "bad render params"; return GLOME_E_INVALID; }
   if ((int64_t)P->width * P->height > (1ll << 30)) { ctx->err = "frame too large"; return GLOME_E_INVALID; }
@@ -361,6 +339,7 @@ glome_ctx* glome_ctx_create(int device_ordinal) {
     return nullptr;
   }
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+  c->own_stream = c->stream;
   if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return fail("hipEventCreate", e);
   if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return fail("hipEventCreate", e);
   if ((e = hipMalloc((void**)&c->d_counters, sizeof(DCounters))) != hipSuccess) return fail("hipMalloc", e);
@@ -373,11 +352,37 @@ void glome_ctx_destroy(glome_ctx* c) {
   if (c->d_counters) (void)hipFree(c->d_counters);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  for (hipEvent_t ev : c->pool) (void)hipEventDestroy(ev);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
 const char* glome_last_error(const glome_ctx* c) { return c ? c->err.c_str() : g_global_error.c_str(); }
 void* glome_ctx_stream(glome_ctx* c) { return c ? (void*)c->stream : nullptr; }
+int glome_ctx_use_stream(glome_ctx* c, void* stream) {
+  if (!c) return GLOME_E_INVALID;
+  c->stream = stream ? (hipStream_t)stream : c->own_stream;
+  return 0;
+}
+int glome_ctx_timing_begin(glome_ctx* c, int max_launches) {
+  if (!c || max_launches <= 0) return GLOME_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  while ((int)c->pool.size() < 2 * max_launches) {
+    hipEvent_t ev;
+    HIPCHK(c, hipEventCreate(&ev));
+    c->pool.push_back(ev);
+  }
+  c->pool_used = 0;
+  c->timing = true;
+  return 0;
+}
+int glome_ctx_timing_end(glome_ctx* c, float* ms_out, int cap) {
+  if (!c) return GLOME_E_INVALID;
+  c->timing = false;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int n = c->pool_used / 2;
+  for (int i = 0; i < n && i < cap; i++) HIPCHK(c, hipEventElapsedTime(&ms_out[i], c->pool[2 * i], c->pool[2 * i + 1]));
+  return n;
+}
 int glome_ctx_synchronize(glome_ctx* c) {
   if (!c) return GLOME_E_INVALID;
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -459,19 +464,23 @@ static int check_device_error(glome_ctx* ctx) {
 
 static void launch_render(glome_scene* s, const DRenderArgs& A, const glome_render_params* P, int grid, size_t lds) {
   hipStream_t st = s->ctx->stream;
-  bool analysis = P->faithful != 0 || P->count_work != 0;
+  bool faithful = P->faithful != 0, count = P->count_work != 0 || faithful;
   if (s->dev.tier == 0) {
     // lean kernel: legal when no secondary trace can do work and no material nests (Blend / AdditiveLayers)
     bool full = s->has_nested_mats || (s->has_secondary_mats && P->maxdepth > 1);
-    if (analysis) { if (full) hipLaunchKernelGGL((k_render_flat<true, true>), dim3(grid), dim3(64), lds, st, A, s->stack_cap); else hipLaunchKernelGGL((k_render_flat<true, false>), dim3(grid), dim3(64), lds, st, A, s->stack_cap); }
-    else { if (full) hipLaunchKernelGGL((k_render_flat<false, true>), dim3(grid), dim3(64), lds, st, A, s->stack_cap); else hipLaunchKernelGGL((k_render_flat<false, false>), dim3(grid), dim3(64), lds, st, A, s->stack_cap); }
+    dim3 g(grid), blk(64);
+#define GLOME_LAUNCH(F, C, U) hipLaunchKernelGGL((k_render_flat<F, C, U>), g, blk, lds, st, A, s->stack_cap)
+    if (faithful) { if (full) GLOME_LAUNCH(true, true, true); else GLOME_LAUNCH(true, true, false); }
+    else if (count) { if (full) GLOME_LAUNCH(false, true, true); else GLOME_LAUNCH(false, true, false); }
+    else { if (full) GLOME_LAUNCH(false, false, true); else GLOME_LAUNCH(false, false, false); }
+#undef GLOME_LAUNCH
   } else {
     hipLaunchKernelGGL(k_render_generic, dim3(grid), dim3(64), 0, st, A);
   }
 }
 
-int glome_render_dev(glome_scene* s, const glome_camera* cam, const glome_light* lights, int nlights, const glome_render_params* P,
-                     float* rgbad_dev, uint32_t* packed_dev, glome_stats* stats) {
+static int render_impl(glome_scene* s, const glome_camera* cam, const glome_light* lights, int nlights, const glome_render_params* P,
+                       float* rgbad_dev, uint32_t* packed_dev, glome_stats* stats, int dense) {
   if (!s) return GLOME_E_INVALID;
   glome_ctx* ctx = s->ctx;
   if (!cam || !rgbad_dev || nlights < 0 || (nlights > 0 && !lights)) { ctx->err = "bad argument"; return GLOME_E_INVALID; }
@@ -493,15 +502,20 @@ int glome_render_dev(glome_scene* s, const glome_camera* cam, const glome_light*
   A.nlights = nlights; A.width = P->width; A.height = P->height; A.fog = P->fog; A.maxdepth = P->maxdepth;
   memcpy(A.thresholds, P->thresholds, 16);
   A.tiles = tt->dev; A.ntiles = (int)tt->host.size(); A.total_waves = tt->total_waves;
-  A.out5 = rgbad_dev; A.packed = packed_dev; A.counters = ctx->d_counters;
+  A.out5 = rgbad_dev; A.packed = dense ? nullptr : packed_dev; A.counters = ctx->d_counters; A.dense = dense;
   HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(DCounters), ctx->stream));
+  hipEvent_t ev_start = ctx->ev0, ev_stop = ctx->ev1;
   if (A.ntiles > 0) {
     size_t lds = s->dev.tier == 0 ? (size_t)s->stack_cap * 64 * 12 : 0;
     int grid = persistent_grid(ctx, lds, A.total_waves);
-    HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    bool pooled = ctx->timing && ctx->pool_used + 2 <= (int)ctx->pool.size();
+    hipEvent_t e0 = pooled ? ctx->pool[ctx->pool_used] : ctx->ev0, e1 = pooled ? ctx->pool[ctx->pool_used + 1] : ctx->ev1;
+    if (pooled) ctx->pool_used += 2;
+    ev_start = e0; ev_stop = e1;
+    HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
     launch_render(s, A, P, grid, lds);
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
   }
   if (stats) {
     memset(stats, 0, sizeof(*stats));
@@ -510,11 +524,20 @@ int glome_render_dev(glome_scene* s, const glome_camera* cam, const glome_light*
     HIPCHK(ctx, hipMemcpy(&c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
     stats->rays_primary = c.rays_primary; stats->rays_shadow = c.rays_shadow; stats->rays_secondary = c.rays_secondary;
     stats->bih_nodes = c.bih_nodes; stats->mesh_nodes = c.mesh_nodes; stats->prim_tests = c.prim_tests;
-    if (A.ntiles > 0) HIPCHK(ctx, hipEventElapsedTime(&stats->kernel_ms, ctx->ev0, ctx->ev1));
+    if (A.ntiles > 0) HIPCHK(ctx, hipEventElapsedTime(&stats->kernel_ms, ev_start, ev_stop));
     stats->n_tiles = A.ntiles; stats->n_pixels = (int32_t)tt->pixels;
     if (c.error) { ctx->err = "device-side limit hit (traversal stack or CSG advance cap)"; return GLOME_E_LIMIT; }
   }
   return 0;
+}
+
+int glome_render_dev(glome_scene* s, const glome_camera* cam, const glome_light* lights, int nlights, const glome_render_params* P,
+                     float* rgbad_dev, uint32_t* packed_dev, glome_stats* stats) {
+  return render_impl(s, cam, lights, nlights, P, rgbad_dev, packed_dev, stats, 0);
+}
+int glome_render_tiles_dev(glome_scene* s, const glome_camera* cam, const glome_light* lights, int nlights, const glome_render_params* P,
+                           float* payload_dev, glome_stats* stats) {
+  return render_impl(s, cam, lights, nlights, P, payload_dev, nullptr, stats, 1);
 }
 
 int glome_render(glome_scene* s, const glome_camera* cam, const glome_light* lights, int nlights, const glome_render_params* P, float* rgbad,

@@ -103,6 +103,7 @@ struct DRenderArgs {
   const DTile* tiles;  // owned tiles
   int32_t ntiles;
   uint32_t total_waves;
+  int32_t dense;       // 1: out5 is a dense tile payload (tile order, row major inside a tile) instead of a frame
   float* out5;         // width*height*5
   uint32_t* packed;    // width*height or null
   DCounters* counters;

@@ -50,6 +50,13 @@ const char* glome_last_error(const glome_ctx*);
 const char* glome_global_error(void);  /* error text when no ctx/sb exists yet */
 void* glome_ctx_stream(glome_ctx*);    /* the hipStream_t, for interop */
 int glome_ctx_synchronize(glome_ctx*);
+/* Run on an external HIP stream (e.g. torch's current stream) instead of the context's own; NULL restores it. */
+int glome_ctx_use_stream(glome_ctx*, void* hip_stream);
+/* Per-launch kernel timing without extra synchronisation: between begin and end every render launch records its own
+ * HIP-event pair on the context's stream; end synchronises once and returns the number of launches, writing their
+ * durations (ms) to ms_out[0..cap). */
+int glome_ctx_timing_begin(glome_ctx*, int max_launches);
+int glome_ctx_timing_end(glome_ctx*, float* ms_out, int cap);
 int glome_ctx_device_info(glome_ctx*, char* name, int cap, int* cu_count, int* warp_size);
 
 /* ---- transforms: Xfm = forward 3x4 (12 doubles, row major) + inverse 3x4 (12 doubles) ---- */
@@ -148,8 +155,8 @@ typedef struct glome_render_params {
   float thresholds[4];   /* Glome.hs:221-224 */
   int32_t tile_first, tile_stride; /* shard: render tiles tile_first, tile_first+tile_stride, ... (x-major order) */
   int32_t faithful;      /* 1: BIH traversal without ordered early-out, exactly as Bih.hs:332-368 visits nodes */
-  int32_t count_work;    /* 1: count node visits / primitive tests (slower).  Either flag selects the analysis
-                            kernel, which does both (flat tier); the generic tier always counts. */
+  int32_t count_work;    /* 1: count node visits / primitive tests (slower; implied by faithful).  The generic
+                            tier always counts and always traverses with early-out. */
 } glome_render_params;
 void glome_render_params_default(glome_render_params*);
 typedef struct glome_stats {
@@ -166,11 +173,19 @@ int glome_render(glome_scene*, const glome_camera*, const glome_light* lights, i
  * the counters and the event timer). */
 int glome_render_dev(glome_scene*, const glome_camera*, const glome_light* lights, int nlights,
                      const glome_render_params*, float* rgbad_dev, uint32_t* packed_dev, glome_stats*);
+/* Render the tiles owned by (params->tile_first, params->tile_stride) straight into a dense tile payload (what a
+ * rank sends to the gather): tiles in owned order, row major inside a tile, 5 floats per pixel = the reference's
+ * `Tile Rect (UV.Vector TColor)` (Glome.hs:153-154). */
+int glome_render_tiles_dev(glome_scene*, const glome_camera*, const glome_light* lights, int nlights,
+                           const glome_render_params*, float* payload_dev, glome_stats*);
 /* Tile payload transport for multi-GPU sharding (Tile = Rect + pixel vector, Glome.hs:153-154).
  * pack: copy this rank's owned tiles from a full frame into a dense payload (tiles in owned order, row major
  * inside a tile, 5 floats per pixel).  blit: scatter a payload of the tiles owned by (tile_first, tile_stride)
  * back into a full frame (blitTile, Glome.hs:353-358).  glome_tiles_payload_floats gives the payload size. */
 int64_t glome_tiles_payload_floats(const glome_render_params*, int tile_first, int tile_stride);
+/* Host-only: the tiles owned by (tile_first, tile_stride) in renderTiles' order (Glome.hs:382-384).  Writes 5 ints per
+ * tile (x, y, w, h, pixel offset of the tile inside the dense payload) and returns the tile count. */
+int glome_tiles_layout(const glome_render_params*, int tile_first, int tile_stride, int32_t* xywh_base, int cap);
 int glome_tiles_pack_dev(glome_ctx*, const glome_render_params*, const float* rgbad_dev, float* payload_dev);
 int glome_tiles_blit_dev(glome_ctx*, const glome_render_params*, int tile_first, int tile_stride,
                          const float* payload_dev, float* rgbad_dev, uint32_t* packed_dev);

@@ -17,15 +17,15 @@ struct SimScene {
   std::string err;
 };
 
-template <bool ANALYSIS, bool FULL_> struct HostFlatTier {
+template <bool FAITHFUL, bool COUNT, bool FULL_> struct HostFlatTier {
   static constexpr bool FULL = FULL_;
   const DScene& S;
   const DLight* lights;
   int nlights;
   LaneStack stk;
   Cnt cnt;
-  HitG closest(const Ray& r, float tmax) { Cand c = closest_flat<ANALYSIS, ANALYSIS>(S, r, tmax, stk, cnt); return finalize_flat(S, r, c); }
-  bool occluded(const Ray& r, float d) { return occluded_flat<ANALYSIS>(S, r, d, stk, cnt); }
+  HitG closest(const Ray& r, float tmax) { Cand c = closest_flat<FAITHFUL, COUNT>(S, r, tmax, stk, cnt); return finalize_flat(S, r, c); }
+  bool occluded(const Ray& r, float d) { return occluded_flat<COUNT>(S, r, d, stk, cnt); }
   HitG closest_ni(const Ray& r, float tmax) { return closest(r, tmax); }
   bool occluded_ni(const Ray& r, float d) { return occluded(r, d); }
 };
@@ -83,8 +83,8 @@ int hostsim_rayint(void* sv, int tier, int analysis, size_t n, const float* ox, 
     Ray r; r.o = v3(ox[i], oy[i], oz[i]); r.d = v3(dx[i], dy[i], dz[i]);
     HitG h;
     if (tier == 0) {
-      if (analysis) { HostFlatTier<true, false> T{s->D, nullptr, 0, hs.lane(kFlatStack), Cnt()}; h = T.closest(r, tmax[i]); total.bih += T.cnt.bih; total.prim += T.cnt.prim; total.mesh += T.cnt.mesh; }
-      else { HostFlatTier<false, false> T{s->D, nullptr, 0, hs.lane(kFlatStack), Cnt()}; h = T.closest(r, tmax[i]); }
+      if (analysis) { HostFlatTier<true, true, false> T{s->D, nullptr, 0, hs.lane(kFlatStack), Cnt()}; h = T.closest(r, tmax[i]); total.bih += T.cnt.bih; total.prim += T.cnt.prim; total.mesh += T.cnt.mesh; }
+      else { HostFlatTier<false, false, false> T{s->D, nullptr, 0, hs.lane(kFlatStack), Cnt()}; h = T.closest(r, tmax[i]); }
     } else {
       HostGenericTier T{s->D, nullptr, 0, Cnt()};
       h = T.closest(r, tmax[i]);
@@ -107,7 +107,7 @@ int hostsim_shadow(void* sv, int tier, size_t n, const float* ox, const float* o
   unsigned int err = 0;
   for (size_t i = 0; i < n; i++) {
     Ray r; r.o = v3(ox[i], oy[i], oz[i]); r.d = v3(dx[i], dy[i], dz[i]);
-    if (tier == 0) { HostFlatTier<false, false> T{s->D, nullptr, 0, hs.lane(kFlatStack), Cnt()}; occ[i] = T.occluded(r, tmax[i]); }
+    if (tier == 0) { HostFlatTier<false, false, false> T{s->D, nullptr, 0, hs.lane(kFlatStack), Cnt()}; occ[i] = T.occluded(r, tmax[i]); }
     else { HostGenericTier T{s->D, nullptr, 0, Cnt()}; occ[i] = T.occluded(r, tmax[i]); err |= T.err; }
   }
   return err ? -2 : 0;
@@ -136,7 +136,7 @@ int hostsim_render(void* sv, int tier, const float* cam, const float* lights, in
       get_coordsf(width, height, (float)px, (float)py, xc, yc);
       Ray ray = primary_ray(C, xc, yc);
       HitG h; CA c;
-      if (tier == 0) { HostFlatTier<false, true> T{s->D, L, nl, hs.lane(kFlatStack), Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, &h); total.shadow += T.cnt.shadow; total.secondary += T.cnt.secondary; }
+      if (tier == 0) { HostFlatTier<false, false, true> T{s->D, L, nl, hs.lane(kFlatStack), Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, &h); total.shadow += T.cnt.shadow; total.secondary += T.cnt.secondary; }
       else { HostGenericTier T{s->D, L, nl, Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, &h); err |= T.err; total.shadow += T.cnt.shadow; total.secondary += T.cnt.secondary; }
       float* o = out5 + ((size_t)py * width + px) * 5;
       o[0] = c.r; o[1] = c.g; o[2] = c.b; o[3] = c.a; o[4] = h.hit ? h.t : kInf;
