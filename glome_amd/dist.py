@@ -50,6 +50,26 @@ def _clone_params(p, **kw):
     return q
 
 
+class ShardPlan:
+    """Who owns which tiles, how big each rank's payload is, and the one exchange step.  Backend agnostic: the GPU
+    path (ShardedFrame) and the CPU multi-process test drive the same plan."""
+
+    def __init__(self, params, rank, world):
+        self.rank, self.world = rank, world
+        self.P = _clone_params(params, tile_first=0, tile_stride=1)
+        self.P_local = _clone_params(params, tile_first=rank, tile_stride=world)
+        self.sizes = [payload_floats(self.P, r, world) for r in range(world)]
+        self.maxp = max(self.sizes + [5])  # gather needs equal-sized tensors: pad to the largest shard
+
+    def layout(self, r):
+        return owned_layout(self.P, r, self.world)
+
+    def gather(self, payload, gathered):
+        """The path's only collective: every rank's (padded) tile payload -> rank 0."""
+        import torch.distributed as dist
+        dist.gather(payload, gathered if self.rank == 0 else None, dst=0)
+
+
 class ShardedFrame:
     """Renders one frame per step() over all ranks of the default process group; the frame lands on rank 0."""
 
@@ -57,16 +77,14 @@ class ShardedFrame:
         import torch
         self.torch = torch
         self.scene, self.ctx, self.lib = scene, scene.ctx, scene.lib
+        self.plan = ShardPlan(params, rank, world)
         self.rank, self.world = rank, world
-        self.P = _clone_params(params, tile_first=0, tile_stride=1)
-        self.P_local = _clone_params(params, tile_first=rank, tile_stride=world)
+        self.P, self.P_local = self.plan.P, self.plan.P_local
         h, w = params.height, params.width
-        self.sizes = [payload_floats(self.P, r, world) for r in range(world)]
-        self.maxp = max(self.sizes + [5])
         self.frame = torch.zeros((h, w, 5), dtype=torch.float32, device=device) if rank == 0 else None
         if world > 1:
-            self.payload = torch.zeros(self.maxp, dtype=torch.float32, device=device)
-            self.gathered = [torch.zeros(self.maxp, dtype=torch.float32, device=device) for _ in range(world)] if rank == 0 else None
+            self.payload = torch.zeros(self.plan.maxp, dtype=torch.float32, device=device)
+            self.gathered = [torch.zeros(self.plan.maxp, dtype=torch.float32, device=device) for _ in range(world)] if rank == 0 else None
         # run on torch's current stream: kernels, the collective and the blit are ordered without host syncs
         self.lib.glome_ctx_use_stream(self.ctx.h, C.c_void_p(torch.cuda.current_stream(device).cuda_stream))
 
@@ -74,14 +92,13 @@ class ShardedFrame:
         """One frame.  Returns the per-rank stats dict when stats=True (that synchronises)."""
         if self.world == 1:
             return self.scene.render_dev(cam, lights, self.P, self.frame.data_ptr(), None, want_stats=stats)
-        import torch.distributed as dist
         la = (L.Light * max(1, len(lights)))(*lights)
         st = L.Stats()
         rc = self.lib.glome_render_tiles_dev(self.scene.h, C.byref(cam), la, len(lights), C.byref(self.P_local),
                                              C.c_void_p(self.payload.data_ptr()), C.byref(st) if stats else None)
         if rc != 0:
             raise api.GlomeError("glome_render_tiles_dev: " + self.ctx.err())
-        dist.gather(self.payload, self.gathered, dst=0)  # the one exchange step: tile payloads -> rank 0 (RCCL over xGMI)
+        self.plan.gather(self.payload, self.gathered)  # tile payloads -> rank 0 (RCCL over xGMI)
         if self.rank == 0:
             for r in range(self.world):
                 rc = self.lib.glome_tiles_blit_dev(self.ctx.h, C.byref(self.P), r, self.world, C.c_void_p(self.gathered[r].data_ptr()),

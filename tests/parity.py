@@ -1,0 +1,64 @@
+"""The parity checks shared by the host-compiled mirror (CPU suite) and the real C ABI (GPU suite): same rays, same
+thresholds, different backend.  Tolerances: fp32 device arithmetic vs the fp64 oracle, 1e-4 relative as the north
+star states, with a bounded fraction of silhouette outliers (fp32 can flip hit/miss on grazing rays)."""
+import numpy as np
+
+from helpers import compare_hits, compare_images, oracle_for, product_camera_lights, random_rays
+
+T_RTOL = 1e-4          # relative t tolerance (north star: 1e-4 relative fp32)
+MISMATCH_MAX = 1e-3    # fraction of rays allowed to flip hit/miss vs fp64
+OUTLIER_MAX = 2e-3     # fraction of hits allowed beyond T_RTOL (CSG boundaries under fp32)
+PIXEL_OUTLIER_MAX = 0.02
+
+
+def id_maps(nm, om):
+    inv = np.full(max(nm) + 2, -1); inv[np.asarray(nm)] = np.arange(len(nm))
+    invo = np.full(max(om) + 2, -1); invo[np.asarray(om)] = np.arange(len(om))
+    return inv, invo
+
+
+def check_rays(backend_rayint, backend_shadow, backend_inside, sd, nm, n=20000, seed=11):
+    """backend_* take float32 arrays; returns a dict of measured error levels after asserting the bounds."""
+    o, om, _ = oracle_for(sd)
+    ro, rd = random_rays(n, seed, center=(0, 1.5, 0), radius=13, spread=7)
+    ref = o.rayint(om[sd.root], ro.astype(np.float64), rd.astype(np.float64))
+    got = backend_rayint(ro, rd)
+    mism, emax, err = compare_hits(got["t"], ref["t"])
+    assert mism <= MISMATCH_MAX, f"hit/miss mismatch {mism}"
+    assert np.mean(err > T_RTOL) <= OUTLIER_MAX, f"t outliers {np.mean(err > T_RTOL)} (max {emax})"
+    both = (got["t"] >= 0) & (ref["t"] >= 0)
+    inv, invo = id_maps(nm, om)
+    same_prim = inv[got["prim"][both]] == invo[ref["prim"][both]]
+    assert same_prim.mean() > 0.99, f"primitive agreement {same_prim.mean()}"  # coplanar faces tie differently in fp32
+    tex_ok = np.all(got["tex"][both] == ref["tex"][both], axis=1)
+    assert np.mean(tex_ok[same_prim]) > 0.999, "texture stacks differ on the same primitive"
+    nerr = np.abs(got["n"][both] - ref["n"][both]).max(axis=1)
+    assert np.mean(nerr[same_prim] > 2e-3) < 5e-3, "normals differ on the same primitive"
+    tm = np.random.default_rng(seed + 1).uniform(1, 30, size=n).astype(np.float32)
+    so = o.shadow(om[sd.root], ro.astype(np.float64), rd.astype(np.float64), tm.astype(np.float64))
+    sg = backend_shadow(ro, rd, tm)
+    assert np.mean(so != sg) <= MISMATCH_MAX, f"shadow mismatch {np.mean(so != sg)}"
+    pts = np.random.default_rng(seed + 2).uniform(-7, 7, size=(n, 3)).astype(np.float32)
+    pts[:, 1] = np.abs(pts[:, 1]) * 0.6
+    io = o.inside(om[sd.root], pts.astype(np.float64))
+    ig = backend_inside(pts)
+    assert np.mean(io != ig) <= MISMATCH_MAX, f"inside mismatch {np.mean(io != ig)}"
+    return {"mismatch": mism, "t_err_max": emax, "shadow_mismatch": float(np.mean(so != sg)), "hit_frac": float(np.mean(ref["t"] >= 0))}
+
+
+def check_image(img, counts, sd, w, h, maxdepth):
+    """img [h,w,5] float32 from the backend; counts = (primary, shadow, secondary) rays it traced."""
+    o, om, _ = oracle_for(sd)
+    ref, _, rc = o.render(w, h, maxdepth=maxdepth, want_packed=False)
+    c = compare_images(img, ref)
+    assert c["frac_over"] <= PIXEL_OUTLIER_MAX, c
+    assert c["mean"] <= 5e-4, c
+    hit_g, hit_r = img[..., 4] < 1e6, ref[..., 4] < 1e6
+    assert np.mean(hit_g != hit_r) <= 2e-3
+    bothhit = hit_g & hit_r
+    drel = np.abs(img[..., 4][bothhit] - ref[..., 4][bothhit]) / np.maximum(1, ref[..., 4][bothhit])
+    assert np.mean(drel > T_RTOL) <= 5e-3
+    assert counts[0] == rc["rays_primary"]
+    for got, want in ((counts[1], rc["rays_shadow"]), (counts[2], rc["rays_secondary"])):
+        assert abs(int(got) - int(want)) <= max(8, int(want) // 200), (counts, rc)  # a flipped silhouette pixel adds / drops a few rays
+    return c

@@ -1,0 +1,211 @@
+"""GPU suite (-m gpu): the HIP path through the C ABI (include/glome_hip.h) against the oracle on seeded inputs, the
+committed golden vectors, and -- at BASELINE.json's full sizes -- size-independent properties."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import parity
+import zoo
+from helpers import oracle_for, product_camera_lights, random_rays
+from glome_amd import _lib as L
+from glome_amd import api, dist, scenes
+
+pytestmark = pytest.mark.gpu
+
+SCENES = dict(zoo.ALL)
+SCENES.update({"S1": lambda: scenes.s1(nlights=2), "S3small": lambda: scenes.s3(24), "S3mesh_small": lambda: scenes.s3(24, as_mesh=True), "S4": scenes.s4})
+
+
+def commit(ctx, sd):
+    b = api.Builder()
+    nm, _ = sd.replay(b)
+    return b, nm, ctx.commit(b, nm[sd.root])
+
+
+@pytest.fixture(scope="module")
+def s3_full(gpu_ctx):
+    sd = scenes.s3(224)
+    b, nm, sc = commit(gpu_ctx, sd)
+    yield sd, sc
+    sc.release()
+
+
+@pytest.mark.parametrize("name", sorted(SCENES))
+def test_rayint_shadow_inside_vs_oracle(gpu_ctx, name):
+    sd = SCENES[name]()
+    b, nm, sc = commit(gpu_ctx, sd)
+    parity.check_rays(lambda o, d: sc.rayint(o, d), lambda o, d, t: sc.shadow(o, d, t), sc.inside, sd, nm, n=40000)
+    sc.release()
+
+
+@pytest.mark.parametrize("name", sorted(SCENES))
+def test_render_vs_oracle(gpu_ctx, name):
+    sd = SCENES[name]()
+    b, nm, sc = commit(gpu_ctx, sd)
+    cam, lights = product_camera_lights(sd)
+    img, packed, st = sc.render(cam, lights, api.render_params(width=320, height=180, maxdepth=3))
+    parity.check_image(img, (st["rays_primary"], st["rays_shadow"], st["rays_secondary"]), sd, 320, 180, 3)
+    # blitTile / rgbf (Glome.hs:353-358, 107-110): packed pixels follow from the float tuple
+    r, g, bl, a = [img[..., k].astype(np.float32) for k in range(4)]
+    cap = lambda x: np.where(x >= 1, np.float32(1 - 1e-4), x)
+    want = (np.floor(cap(r * a) * 256).astype(np.int64) * 65536 + np.floor(cap(g * a) * 256).astype(np.int64) * 256 + np.floor(cap(bl * a) * 256).astype(np.int64)) & 0xFFFFFFFF
+    assert np.mean(packed.astype(np.int64) == want) > 0.9999
+    sc.release()
+
+
+def test_golden_vectors_through_c_abi(gpu_ctx):
+    import test_golden as tg
+    for name in tg.NAMES:
+        mg, g = tg.load_gold(name)
+        sd = mg.SCENES[name]()
+        b, nm, sc = commit(gpu_ctx, sd)
+        ro, rd = mg.golden_inputs()
+        cam, lights = product_camera_lights(sd)
+        img, _, _ = sc.render(cam, lights, api.render_params(width=g["image"]["w"], height=g["image"]["h"], maxdepth=g["image"]["maxdepth"]))
+        tg.compare_backend_to_gold(g, sc.rayint(ro, rd), sc.shadow(ro, rd, np.full(len(ro), g["shadow_tmax"], np.float32)), img, nm)
+        sc.release()
+
+
+# ------------------------------------------------------------------ full-size properties (1920x1080, 100k triangles)
+def test_full_size_faithful_equals_early_out_and_is_deterministic(s3_full):
+    sd, sc = s3_full
+    cam, lights = product_camera_lights(sd)
+    a, pa, sa = sc.render(cam, lights, api.render_params(width=1920, height=1080, maxdepth=1))
+    b, pb, sb = sc.render(cam, lights, api.render_params(width=1920, height=1080, maxdepth=1))
+    f, pf, sf = sc.render(cam, lights, api.render_params(width=1920, height=1080, maxdepth=1, faithful=1))
+    assert np.array_equal(a, b) and np.array_equal(pa, pb)  # deterministic whatever the work-queue order
+    assert np.array_equal(a, f) and np.array_equal(pa, pf)  # ordered early-out picks the same hits as the reference's traversal
+    assert sa["rays_primary"] == 1920 * 1080 and (sa["rays_shadow"], sa["rays_secondary"]) == (sf["rays_shadow"], sf["rays_secondary"])
+    assert sf["bih_nodes"] > 0 and sa["bih_nodes"] == 0
+    hit = a[..., 3] > 0
+    assert 0.3 < hit.mean() < 0.7 and np.all(a[..., 4][~hit] == 1e6) and np.all(a[..., :4][~hit] == 0)  # misses are transparent at depth = infinity
+
+
+def test_full_size_counts_and_pixels_match_oracle_on_a_tile_sample(s3_full):
+    """Every 37th 65x65 tile of the 1080p frame (14 tiles, ~59k pixels) rendered by the oracle; the GPU renders the same
+    tiles: pixels within tolerance, ray counts equal, faithful node / primitive visit counts equal to the oracle's."""
+    sd, sc = s3_full
+    cam, lights = product_camera_lights(sd)
+    o, om, _ = oracle_for(sd)
+    ref, _, rc = o.render(1920, 1080, maxdepth=1, tile_first=3, tile_stride=37, nthreads=8, want_packed=False)
+    init = np.zeros((1080, 1920, 5), np.float32)
+    img, _, st = sc.render(cam, lights, api.render_params(width=1920, height=1080, maxdepth=1, tile_first=3, tile_stride=37, faithful=1), want_packed=False, init=init)
+    owned = np.zeros((1080, 1920), bool)
+    for x, y, w, h, _ in dist.owned_layout(api.render_params(width=1920, height=1080), 3, 37):
+        owned[y:y + h, x:x + w] = True
+    assert owned.sum() == st["n_pixels"] == rc["rays_primary"] == st["rays_primary"]
+    assert np.all(img[~owned] == 0)  # tiles this call does not own are left untouched
+    e = (np.abs(img[owned][:, :4] - ref[owned][:, :4]) / np.maximum(1, np.abs(ref[owned][:, :4]))).max(-1)
+    assert np.mean(e > 1e-4) < 2e-3
+    assert st["rays_shadow"] == rc["rays_shadow"]
+    assert abs(st["bih_nodes"] - rc["bih_nodes"]) <= rc["bih_nodes"] // 5000 + 4
+    assert abs(st["prim_tests"] - rc["prim_tests"]) <= rc["prim_tests"] // 5000 + 4
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_full_size_tile_shards_reassemble_bit_exactly(gpu_ctx, s3_full, world):
+    """The multi-GPU data path on one GPU: each 'rank' renders its round-robin tiles into a dense payload, the payloads are
+    blitted into a frame -- identical to the whole-frame render, bit for bit."""
+    import torch
+    sd, sc = s3_full
+    cam, lights = product_camera_lights(sd)
+    dev = torch.device("cuda:0")
+    P = api.render_params(width=1920, height=1080, maxdepth=1)
+    whole = torch.zeros((1080, 1920, 5), dtype=torch.float32, device=dev)
+    sc.render_dev(cam, lights, P, whole.data_ptr())
+    frame = torch.full((1080, 1920, 5), float("nan"), dtype=torch.float32, device=dev)
+    la = (L.Light * len(lights))(*lights)
+    tot = 0
+    for r in range(world):
+        plan = dist.ShardPlan(P, r, world)
+        payload = torch.zeros(plan.maxp, dtype=torch.float32, device=dev)
+        st = L.Stats()
+        assert sc.lib.glome_render_tiles_dev(sc.h, C.byref(cam), la, len(lights), C.byref(plan.P_local), C.c_void_p(payload.data_ptr()), C.byref(st)) == 0
+        tot += st.n_pixels
+        assert sc.lib.glome_tiles_blit_dev(gpu_ctx.h, C.byref(plan.P), r, world, C.c_void_p(payload.data_ptr()), C.c_void_p(frame.data_ptr()), None) == 0
+        # pack(frame-of-this-rank) == payload
+        back = torch.zeros(plan.maxp, dtype=torch.float32, device=dev)
+        assert sc.lib.glome_tiles_pack_dev(gpu_ctx.h, C.byref(plan.P_local), C.c_void_p(frame.data_ptr()), C.c_void_p(back.data_ptr())) == 0
+        gpu_ctx.synchronize()
+        assert torch.equal(back[:plan.sizes[r]], payload[:plan.sizes[r]])
+    gpu_ctx.synchronize()
+    assert tot == 1920 * 1080 and torch.equal(frame, whole)
+
+
+def test_full_size_csg_generic_tier_vs_oracle_tile_sample(gpu_ctx):
+    sd = scenes.s4()
+    b, nm, sc = commit(gpu_ctx, sd)
+    assert sc.info()["tier"] == 1
+    cam, lights = product_camera_lights(sd)
+    o, om, _ = oracle_for(sd)
+    ref, _, rc = o.render(1920, 1080, maxdepth=3, tile_first=5, tile_stride=23, nthreads=8, want_packed=False)
+    img, _, st = sc.render(cam, lights, api.render_params(width=1920, height=1080, maxdepth=3, tile_first=5, tile_stride=23), want_packed=False)
+    owned = np.zeros((1080, 1920), bool)
+    for x, y, w, h, _ in dist.owned_layout(api.render_params(width=1920, height=1080), 5, 23):
+        owned[y:y + h, x:x + w] = True
+    e = (np.abs(img[owned][:, :4] - ref[owned][:, :4]) / np.maximum(1, np.abs(ref[owned][:, :4]))).max(-1)
+    assert np.mean(e > 1e-4) < 5e-3
+    assert st["rays_primary"] == rc["rays_primary"]
+    assert abs(st["rays_shadow"] - rc["rays_shadow"]) <= rc["rays_shadow"] // 500 + 8 and abs(st["rays_secondary"] - rc["rays_secondary"]) <= rc["rays_secondary"] // 200 + 8
+    sc.release()
+
+
+# ------------------------------------------------------------------ edge cases
+def test_edge_cases(gpu_ctx):
+    b = api.Builder()
+    m = b.material_surface((1, 1, 1), 1, 0.2, 0.8, 0, 0)
+    void = b.group([])
+    sc = gpu_ctx.commit(b, void)  # empty scene: everything misses
+    cam = api.camera((0, 0, -5), (0, 0, 0), (0, 1, 0), 45)
+    img, packed, st = sc.render(cam, [api.light((0, 5, 0), (10, 10, 10))], api.render_params(width=7, height=5, maxdepth=3))
+    assert np.all(img[..., :4] == 0) and np.all(img[..., 4] == 1e6) and np.all(packed == 0) and st["rays_shadow"] == 0
+    assert sc.rayint(np.zeros((0, 3)), np.zeros((0, 3)))["t"].shape == (0,)  # zero rays
+    r = sc.rayint([[0, 0, -3]], [[0, 0, 1]])
+    assert r["t"][0] == -1 and r["prim"][0] == -1 and np.all(r["tex"][0] == -1)
+    sc.release()
+    sph = b.sphere((0, 0, 0), 1)
+    s = b.tex(sph, m)
+    sc = gpu_ctx.commit(b, s)
+    for n in (1, 63, 64, 65, 1000):  # ragged batch sizes
+        o = np.tile([[0, 0, -3]], (n, 1)); d = np.tile([[0, 0, 1]], (n, 1))
+        r = sc.rayint(o, d)
+        assert np.allclose(r["t"], 2) and np.all(r["prim"] == sph) and np.all(r["tex"][:, 0] == m) and np.all(r["tex"][:, 1] == -1)
+        assert sc.shadow(o, d, 5.0).all() and not sc.shadow(o, d, 1.5).any()
+    assert np.array_equal(sc.rayint([[0, 0, -3]], [[0, 0, 1]], 1.5)["t"], [-1])  # beyond tmax (D4)
+    for (w, h) in [(1, 1), (7, 5), (65, 65), (66, 131), (130, 64)]:  # frames that are not multiples of 8 or 65
+        img, _, st = sc.render(cam, [], api.render_params(width=w, height=h, maxdepth=1), want_packed=False)
+        assert st["rays_primary"] == w * h == st["n_pixels"] and np.isfinite(img).all()
+    with pytest.raises(api.GlomeError):
+        sc.render(cam, [], api.render_params(width=16, height=16, maxdepth=0))
+    with pytest.raises(api.GlomeError):
+        sc.render(cam, [api.light((0, 1, 0), (1, 1, 1))] * 9, api.render_params(width=16, height=16))
+    with pytest.raises(api.GlomeError):
+        sc.render(cam, [], api.render_params(width=16, height=16, mode=7))
+    sc.release()
+    with pytest.raises(api.GlomeError, match="nests composites deeper"):
+        n = b.sphere((0, 0, 0), 1)
+        for _ in range(8):
+            n = b.group([b.transform(n, [api.translate((0.1, 0, 0))]), b.sphere((9, 9, 9), 0.1)])
+        gpu_ctx.commit(b, n)
+
+
+def test_device_pointer_seams_match_host_seams(gpu_ctx):
+    import torch
+    sd = scenes.s1(nlights=1)
+    b, nm, sc = commit(gpu_ctx, sd)
+    ro, rd = random_rays(10000, 5)
+    host = sc.rayint(ro, rd)
+    dev = torch.device("cuda:0")
+    cols = [torch.tensor(np.ascontiguousarray(a), device=dev) for a in (ro[:, 0], ro[:, 1], ro[:, 2], rd[:, 0], rd[:, 1], rd[:, 2], np.full(len(ro), 1e6, np.float32))]
+    t = torch.zeros(len(ro), dtype=torch.float32, device=dev)
+    prim = torch.zeros(len(ro), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    rc = sc.lib.glome_rayint_batch_dev(sc.h, len(ro), *[C.c_void_p(c.data_ptr()) for c in cols], C.c_void_p(t.data_ptr()), C.c_void_p(prim.data_ptr()), None, None, None, None)
+    assert rc == 0
+    occ = torch.zeros(len(ro), dtype=torch.uint8, device=dev)
+    assert sc.lib.glome_shadow_batch_dev(sc.h, len(ro), *[C.c_void_p(c.data_ptr()) for c in cols], C.c_void_p(occ.data_ptr())) == 0
+    gpu_ctx.synchronize()
+    assert np.array_equal(t.cpu().numpy(), host["t"]) and np.array_equal(prim.cpu().numpy(), host["prim"])
+    assert np.array_equal(occ.cpu().numpy().astype(bool), sc.shadow(ro, rd, 1e6))
+    sc.release()

@@ -1,0 +1,106 @@
+"""CPU suite: the device per-ray headers compiled for the host (tests/hostsim) against the oracle, over scenes that
+reach every primitive / composite / wrapper / material kind.  This proves the kernel logic and the flattened layout
+without a GPU; tests/test_gpu_parity.py repeats the same checks through the real C ABI on an MI355X."""
+import numpy as np
+import pytest
+
+import parity
+import zoo
+from helpers import HostSim, product_camera_lights
+from glome_amd import api, scenes
+
+SCENES = dict(zoo.ALL)
+SCENES.update({"S1": lambda: scenes.s1(nlights=2), "S3small": lambda: scenes.s3(24), "S3mesh_small": lambda: scenes.s3(24, as_mesh=True), "S4": scenes.s4})
+
+
+def load(name):
+    sd = SCENES[name]()
+    b = api.Builder()
+    nm, _ = sd.replay(b)
+    return sd, b, nm, HostSim(b, nm[sd.root])
+
+
+@pytest.mark.parametrize("name", sorted(SCENES))
+def test_rayint_shadow_inside(built, name):
+    sd, b, nm, hs = load(name)
+    parity.check_rays(lambda o, d: hs.rayint(o, d), lambda o, d, t: hs.shadow(o, d, t), hs.inside, sd, nm, n=12000)
+
+
+@pytest.mark.parametrize("name", sorted(SCENES))
+def test_render(built, name):
+    sd, b, nm, hs = load(name)
+    cam, lights = product_camera_lights(sd)
+    img, cnt = hs.render(cam, lights, 160, 90, 3)
+    parity.check_image(img, [int(x) for x in cnt], sd, 160, 90, 3)
+
+
+@pytest.mark.parametrize("name", ["S1", "S3small", "S3mesh_small", "flat_mixed", "mesh", "materials"])
+def test_flat_tier_equals_generic_tier_and_faithful_traversal(built, name):
+    """Three traversals of the same flattened scene must pick the same hits: the flat tier with ordered early-out, the
+    flat tier visiting exactly the reference's nodes (Bih.hs:332-368), and the generic interpreter."""
+    sd, b, nm, hs = load(name)
+    from helpers import random_rays
+    ro, rd = random_rays(8000, 3, center=(0, 1.5, 0), radius=13, spread=7)
+    a = hs.rayint(ro, rd)
+    f = hs.rayint(ro, rd, analysis=1)
+    g = hs.rayint(ro, rd, tier=1)
+    for other in (f, g):
+        assert np.array_equal(a["t"], other["t"]) and np.array_equal(a["prim"], other["prim"]) and np.array_equal(a["tex"], other["tex"])
+        assert np.allclose(a["n"], other["n"], atol=1e-6)
+    tm = np.full(len(ro), 9.0, np.float32)
+    assert np.array_equal(hs.shadow(ro, rd, tm), hs.shadow(ro, rd, tm, tier=1))
+
+
+def test_faithful_traversal_counts_match_reference_convention(built):
+    """Node / primitive visit counts of the faithful traversal equal the oracle's rayint_debug-style counters
+    (Bih.hs:378-412): these counts feed the roofline's algorithmic bytes."""
+    from helpers import oracle_for, random_rays, O
+    sd, b, nm, hs = load("S3small")
+    o, om, _ = oracle_for(sd)
+    ro, rd = random_rays(5000, 9, center=(0, 0.5, 0), radius=13, spread=8)
+    import ctypes as C
+    before = np.zeros(6, np.uint64)
+    # count through a 1-thread render-free path: batch rayint on the oracle updates thread-local counters we cannot read,
+    # so compare on a tiny frame instead (render returns the counters)
+    cam, lights = product_camera_lights(sd)
+    _, _, rc = o.render(64, 36, maxdepth=1, want_packed=False)
+    from glome_amd import api as A
+    # hostsim counters come from rayint on the same primary rays: regenerate them like get_rayint (Glome.hs:27-33)
+    camv = [np.array(list(v), np.float32) for v in (cam.pos, cam.fwd, cam.up, cam.right)]
+    px, py = np.meshgrid(np.arange(64, dtype=np.float32), np.arange(36, dtype=np.float32))
+    xc = (((px / np.float32(64)) * 2) - 1) * (np.float32(64) / np.float32(36)); yc = -(((py / np.float32(36)) * 2) - 1)
+    d = camv[1][None, None, :] + camv[3][None, None, :] * (-xc)[..., None] + camv[2][None, None, :] * yc[..., None]
+    d = (d / np.sqrt((d.astype(np.float64) ** 2).sum(-1, keepdims=True))).astype(np.float32).reshape(-1, 3)
+    orig = np.broadcast_to(camv[0], d.shape)
+    got = hs.rayint(orig, d, analysis=1)
+    oc = o.rayint(om[sd.root], orig.astype(np.float64), d.astype(np.float64))
+    # primary-ray part of the oracle's counters: re-render without lights to isolate it
+    o.clear_lights()
+    _, _, rc0 = o.render(64, 36, maxdepth=1, want_packed=False)
+    assert abs(int(got["counters"][0]) - rc0["bih_nodes"]) <= 2 + rc0["bih_nodes"] // 2000
+    assert abs(int(got["counters"][2]) - rc0["prim_tests"]) <= 2 + rc0["prim_tests"] // 2000
+
+
+def test_quirks_survive_flattening(built):
+    """Q1 (+0 direction misses a box / bih), Q4 (shadow_sphere vs rayint_sphere from inside), Mesh casts no shadow (Q12),
+    NoShadow / OnlyShadow, Q13 texture loss -- on the device code path."""
+    b = api.Builder()
+    m = b.material_surface((1, 1, 1), 1, 0.2, 0.8, 0, 0)
+    box = b.box((-1, -1, -1), (1, 1, 1))
+    hs = HostSim(b, box)
+    r = hs.rayint([[0, 0, -3], [0, 0, -3]], [[0.0, 0.0, 1], [-0.0, -0.0, 1]])
+    assert r["t"][0] == -1 and r["t"][1] == pytest.approx(2)
+    sph = b.sphere((0, 0, 0), 1)
+    hs = HostSim(b, sph)
+    assert hs.rayint([[0, 0, 0]], [[0, 0, 1]])["t"][0] == pytest.approx(1) and not hs.shadow([[0, 0, 0]], [[0, 0, 1]], 10.0)[0]
+    root = b.group([b.noshadow(b.sphere((0, 0, 5), 1)), b.onlyshadow(b.sphere((0, 0, 10), 1))])
+    hs = HostSim(b, root)
+    assert hs.rayint([[0, 0, 0]], [[0, 0, 1]])["t"][0] == pytest.approx(4)          # OnlyShadow sphere is invisible
+    assert hs.shadow([[0, 0, 7]], [[0, 0, 1]], 20.0)[0] and not hs.shadow([[0, 0, 0]], [[0, 0, 1]], 7.0)[0]
+    d = b.tex(b.difference(b.sphere((0, 0, 0), 2), b.sphere((0, 0, -2), 1)), m)
+    hs = HostSim(b, d)
+    r = hs.rayint([[0, 0, -10]], [[0, 0, 1]])
+    assert r["t"][0] == pytest.approx(9, abs=1e-4) and r["tex"][0][0] == -1 and np.allclose(r["n"][0], [0, 0, -1])
+    me = b.mesh([[0, 0, 0], [1, 0, 0], [0, 1, 0]], [], [[0, 1, 2, -1, -1, -1, -1, -1]], [])
+    hs = HostSim(b, me)
+    assert hs.rayint([[.25, .25, -1]], [[0, 0, 1]])["t"][0] == pytest.approx(1) and not hs.shadow([[.25, .25, -1]], [[0, 0, 1]], 5.0)[0]

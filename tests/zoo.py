@@ -1,0 +1,136 @@
+"""A zoo of small scenes in TestScene.hs vocabulary that together reach every primitive, composite, wrapper and
+material kind on the hot path.  Used by the host-side and the GPU parity tests."""
+import numpy as np
+
+from glome_amd import api, scenes
+from glome_amd.scene import SceneDesc
+
+
+def _finish(sd, root, nlights=2):
+    sd.set_root(root)
+    for pos, col in scenes.LIGHTS[:nlights]:
+        sd.add_light(pos, col)
+    sd.set_camera(*scenes.CUST_CAM)
+    return sd
+
+
+def flat_mixed():
+    """flat tier, mixed leaf class: bih of simple primitives with Tex stacks and shadow flags, plus a plane and a disc."""
+    sd = SceneDesc()
+    m = scenes.materials(sd)
+    blue = scenes.matte(sd, (0.2, 0.3, 0.9))
+    items = [
+        sd.tex(sd.sphere((-3, 1, 0), 1.0), m["shiny_red"]),
+        sd.tex(sd.tex(sd.sphere((0, 1.2, -1), 1.2), m["shiny_white"]), blue),  # nested Tex: innermost first
+        sd.tex(sd.triangle((1, 0.1, 2), (3, 0.2, 2.5), (2, 2.5, 1.5)), blue),
+        sd.tex(sd.trianglenorm((-2, 0.2, 3), (0, 0.3, 3.5), (-1, 2.0, 3.2), (0, 0, 1), (0.6, 0, 0.8), (0, 0.6, 0.8)), m["shiny_white"]),
+        sd.tex(sd.box((3, 0, -3), (4.5, 2, -1.5)), m["shiny_red"]),
+        sd.tex(sd.disc((-4.5, 1.5, 2), (0.3, 0.9, 0.3162277), 0.9), blue),
+        sd.noshadow(sd.tex(sd.sphere((2, 3.5, 0), 0.7), blue)),
+        sd.onlyshadow(sd.box((-1, 3, -0.5), (0, 3.4, 0.5))),
+        sd.tag(sd.tex(sd.sphere((5, 0.5, 3), 0.5), m["shiny_white"]), "tagged"),
+    ]
+    pl = sd.tex(sd.plane((0, 0, 0), (0, 1, 0)), scenes.matte(sd, (0, 0.8, 0.3)))
+    free = sd.tex(sd.disc((0, 4.5, -4), (0, 0.7071068, 0.7071068), 1.5), m["shiny_red"])
+    return _finish(sd, sd.group([pl, sd.bih(items), free]))
+
+
+def quadrics():
+    """cylinders / cones (canonical z-axis primitives inside Instances, Cone.hs:40-67), every cap case."""
+    sd = SceneDesc()
+    m = scenes.materials(sd)
+    pl = sd.tex(sd.plane((0, 0, 0), (0, 1, 0)), scenes.matte(sd, (0, 0.8, 0.3)))
+    items = [
+        sd.tex(sd.cylinder((-3, 0.2, 0), (-3, 2.5, 0.5), 0.6), m["shiny_red"]),
+        sd.tex(sd.cone((0, 0.1, 0), 1.0, (0.5, 3.0, 0), 0.0), m["shiny_white"]),        # TestScene.hs:126 style
+        sd.tex(sd.cone((3, 0.5, 1), 0.3, (4.5, 2.0, 2), 0.9), scenes.matte(sd, (0.5, 0, 1))),  # swapped radii (r1 < r2)
+        sd.tex(sd.cone((-1, 3, -2), 0.5, (1, 3.2, -2), 0.50001), m["shiny_red"]),       # degenerates to a cylinder (r1-r2 < delta)
+    ]
+    return _finish(sd, sd.group([pl, sd.bih(items)]))
+
+
+def csg():
+    """S4 plus a plane-cut polyhedron (TestScene.hs:45-54), Bound / InnerBound, and nested differences."""
+    sd = scenes.s4()
+    # rebuild root with extras appended to a new outer group
+    m_gold = sd.material_surface((0.9, 0.7, 0.2), 1, 0.2, 0.8, 0.4, 10)
+    gr = (1 + 5 ** 0.5) / 2
+    pos, r = np.array([6.0, 1.5, -2.0]), 1.0
+    pts = [(0, y, z) for y in (-r, r) for z in (-gr * r, gr * r)] + [(x, 0, z) for z in (-r, r) for x in (-gr * r, gr * r)] + \
+          [(x, y, 0) for x in (-r, r) for y in (-gr * r, gr * r)]
+    planes = []
+    for p in pts:
+        n = np.array(p, dtype=np.float64); n /= np.linalg.norm(n)
+        planes.append(sd.plane_offset(n, r + float(n @ pos)))
+    dodeca = sd.tex(sd.tag(sd.intersection([sd.sphere(pos, 1.26 * r)] + planes), "dodecahedron"), m_gold)  # TestScene.hs:45-54
+    bounded = sd.bound_object(sd.sphere((-6, 2, -3), 1.6), sd.tex(sd.group([sd.sphere((-6.5, 2, -3), 0.8), sd.box((-6, 1.5, -3.5), (-5, 2.5, -2.5))]), m_gold))
+    inner = sd.innerbound(sd.sphere((0, 5, -6), 0.5), sd.tex(sd.sphere((0, 5, -6), 1.0), m_gold))
+    nested = sd.tex(sd.difference(sd.difference(sd.box((7, 0, 2), (9, 2, 4)), sd.sphere((8, 2, 3), 0.8)), sd.box((7.5, 0.5, 1.5), (8.5, 1.5, 2.5))), m_gold)
+    root = sd.group([sd.root, sd.bih([dodeca, bounded, inner, nested])])
+    sd.set_root(root)
+    return sd
+
+
+def nested():
+    """bih -> instance -> bih (TestScene.hs lattice style), group inside an instance, a difference whose operand is an
+    instanced bih (TestScene.hs:191-193), a rotated + scaled instance, Tex stacks three deep."""
+    sd = SceneDesc()
+    m = scenes.materials(sd)
+    teal, pink = scenes.matte(sd, (0.1, 0.7, 0.7)), scenes.matte(sd, (1, 0.4, 0.7))
+    lattice = sd.bih([sd.sphere((float(x), float(y), float(z)), 0.3) for x in range(-2, 3) for y in range(-2, 3) for z in range(-2, 3)])
+    carved = sd.tex(sd.difference(sd.transform(lattice, [api.rotate((0, 0, 1), api.deg(23)), api.rotate((1, 0, 0), api.deg(43)), api.scale((0.8, 0.8, 0.8)),
+                                                         api.translate((-3, 2.5, 0))]), sd.sphere((-3, 2.5, 0), 1.2)), m["shiny_red"])
+    pair = sd.group([sd.tex(sd.sphere((0, 0, 0), 0.6), teal), sd.tex(sd.box((0.5, -0.4, -0.4), (1.4, 0.4, 0.4)), pink)])
+    inst_pair = sd.transform(pair, [api.scale((1.5, 0.7, 1.2)), api.rotate((0, 1, 0), api.deg(30)), api.translate((3, 1.0, 1))])
+    deep = sd.tex(sd.tex(sd.tex(sd.sphere((0, 1, 4), 0.8), teal), pink), m["shiny_white"])
+    instinst = sd.transform(sd.transform(sd.tex(sd.sphere((0, 0, 0), 0.5), pink), [api.translate((1, 0, 0))]), [api.scale((2, 2, 2)), api.translate((2, 3, -3))])  # merges (Solid.hs:494-496)
+    tri_moved = sd.tex(sd.transform(sd.triangle((0, 0, 0), (1, 0, 0), (0, 1, 0)), [api.scale((2, 2, 2)), api.translate((-6, 0.5, 3))]), teal)  # bakes (Triangle.hs:164-168)
+    pl = sd.tex(sd.plane((0, 0, 0), (0, 1, 0)), scenes.matte(sd, (0, 0.8, 0.3)))
+    return _finish(sd, sd.group([pl, sd.bih([carved, inst_pair, deep, instinst, tri_moved])]))
+
+
+def mesh_scene():
+    """mesh with vertex normals on some triangles and per-triangle textures (Mesh.hs:27-29, 143-161), plus a sphere."""
+    sd = SceneDesc()
+    m = scenes.materials(sd)
+    N = 12
+    V = scenes.heightfield_vertices(N).reshape(-1, 3) * np.array([0.5, 1.0, 0.5])
+    idx = np.arange((N + 1) * (N + 1)).reshape(N + 1, N + 1)
+    a, b, c, d = idx[:-1, :-1], idx[:-1, 1:], idx[1:, :-1], idx[1:, 1:]
+    tri = np.stack([np.stack([a, b, c], -1), np.stack([c, b, d], -1)], axis=2).reshape(-1, 3)
+    # vertex normals: normalised (0,1,0) + small tilt by position
+    nrm = np.stack([0.3 * np.sin(V[:, 0]), np.ones(len(V)), 0.3 * np.cos(V[:, 2])], -1)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    tris = np.full((len(tri), 8), -1, np.int32)
+    tris[:, :3] = tri
+    smooth = np.arange(len(tri)) % 3 == 0
+    tris[smooth, 3:6] = tri[smooth]
+    tris[:, 6] = np.arange(len(tri)) % 2  # alternate two textures
+    tris[::7, 6] = -1                     # some triangles carry no texture of their own
+    mats = [scenes.matte(sd, (0.8, 0.5, 0.4)), m["shiny_white"]]
+    me = sd.tex(sd.mesh(V, nrm, tris, mats), scenes.matte(sd, (0.3, 0.3, 0.3)))
+    sp = sd.tex(sd.sphere((0, 2.5, 0), 0.8), m["shiny_red"])
+    return _finish(sd, sd.group([me, sp]))
+
+
+def materials():
+    """every Material kind (Shader.hs:43-52 minus Warp): Surface, Reflect, Refract, Blend, AdditiveLayers, stacked Tex."""
+    sd = SceneDesc()
+    m = scenes.materials(sd)
+    glass = sd.material_refract(0.35, 0.8, 1.5)                      # TestScene.hs:196
+    blend = sd.material_blend(m["mirror"], scenes.matte(sd, (0.15, 0.3, 0.5)), 0.4)  # t_mottled at a fixed weight (TestScene.hs:220)
+    layers = sd.material_layers([sd.material_surface((1, 0.2, 0.2), 0.5, 0.3, 0.7, 0.3, 8), m["mirror"]])
+    thin = sd.material_surface((0.2, 0.9, 0.2), 0.4, 0.5, 0.5, 0, 0)  # translucent: the fold continues to the next Tex
+    pl = sd.tex(sd.plane((0, 0, 0), (0, 1, 0)), scenes.matte(sd, (0, 0.8, 0.3)))
+    items = [
+        sd.tex(sd.sphere((-4, 1, 0), 1.0), m["mirror"]),
+        sd.tex(sd.sphere((-1.5, 1, 1), 1.0), glass),
+        sd.tex(sd.sphere((1, 1, 0), 1.0), blend),
+        sd.tex(sd.sphere((3.5, 1, 1), 1.0), layers),
+        sd.tex(sd.tex(sd.box((-1, 0, -4), (1, 2, -3)), thin), m["shiny_red"]),  # thin over red
+        sd.tex(sd.box((5, 0, -2), (6, 3, 2)), m["mirror"]),
+    ]
+    return _finish(sd, sd.group([pl, sd.bih(items)]))
+
+
+ALL = {"flat_mixed": flat_mixed, "quadrics": quadrics, "csg": csg, "nested": nested, "mesh": mesh_scene, "materials": materials}
