@@ -104,10 +104,23 @@ GD void bbclip_ub_rcp(V3 o, V3 rcp, V3 lo, V3 hi, float& nearv, float& farv) {
 
 // ------------------------------------------------------------------ primitives
 // Sphere.hs:20-41 (Q4).  Returns the hit distance; the normal is vnorm(p - c), computed by the caller.
+// The discriminant rsqr - (csqr - vsqr) cancels catastrophically in fp32 for a small sphere far from the origin
+// (csqr ~ vsqr ~ 1e2, difference ~ 1e-2).  For a unit direction csqr - vsqr = |eo - v*dir|^2 exactly, and that form
+// keeps full precision, so the fp32 result lands on the reference's fp64 value.  glome's rays are unit length
+// except Refract's transmitted direction (Shader.hs:141, unnormalised as written); those keep the reference form,
+// which is what the fp64 path computes for them.
+GD float sphere_disc(V3 eo, V3 dir, float v, float r) {
+  float dd = vdot(dir, dir);
+  if (dd > 0.99999f && dd < 1.00001f) {
+    V3 perp = eo - dir * v;
+    return r * r - vdot(perp, perp);
+  }
+  return r * r - (vdot(eo, eo) - v * v);
+}
 GD bool sphere_test(const F4& s, const Ray& ray, float dist, float& t) {
   V3 eo = v3(s) - ray.o;
-  float v = vdot(eo, ray.d), vsqr = v * v, csqr = vdot(eo, eo), rsqr = s.w * s.w;
-  float disc = rsqr - (csqr - vsqr);
+  float v = vdot(eo, ray.d);
+  float disc = sphere_disc(eo, ray.d, v, s.w);
   if (disc < 0.0f) return false;
   float d = sqrtf(disc);
   float hitdist = ((v - d) > 0) ? (v - d) : (v + d);
@@ -120,8 +133,7 @@ GD bool sphere_shadow(const F4& s, const Ray& ray, float dist) {
   V3 eo = v3(s) - ray.o;
   float v = vdot(eo, ray.d);
   if (!((dist >= (v - s.w)) && (v > 0.0f))) return false;
-  float vsqr = v * v, csqr = vdot(eo, eo), rsqr = s.w * s.w;
-  float disc = rsqr - (csqr - vsqr);
+  float disc = sphere_disc(eo, ray.d, v, s.w);
   if (disc < 0.0f) return false;
   float d = sqrtf(disc);
   float hitdist = ((v - d) > 0) ? (v - d) : (v + d);

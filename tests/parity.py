@@ -8,7 +8,7 @@ from helpers import compare_hits, compare_images, oracle_for, product_camera_lig
 T_RTOL = 1e-4          # relative t tolerance (north star: 1e-4 relative fp32)
 MISMATCH_MAX = 1e-3    # fraction of rays allowed to flip hit/miss vs fp64
 OUTLIER_MAX = 2e-3     # fraction of hits allowed beyond T_RTOL (CSG boundaries under fp32)
-PIXEL_OUTLIER_MAX = 0.02
+PIXEL_OUTLIER_MAX = 5e-3
 
 
 def id_maps(nm, om):
@@ -52,7 +52,7 @@ def check_image(img, counts, sd, w, h, maxdepth):
     ref, _, rc = o.render(w, h, maxdepth=maxdepth, want_packed=False)
     c = compare_images(img, ref)
     assert c["frac_over"] <= PIXEL_OUTLIER_MAX, c
-    assert c["mean"] <= 5e-4, c
+    assert c["mean"] <= 3e-4, c
     hit_g, hit_r = img[..., 4] < 1e6, ref[..., 4] < 1e6
     assert np.mean(hit_g != hit_r) <= 2e-3
     bothhit = hit_g & hit_r
