@@ -256,6 +256,10 @@ class Context:
         return Scene(self, s)
 
 
+def _stats_dict(st):
+    return {k: getattr(st, k) for k, _ in L.Stats._fields_}
+
+
 def _f32(a):
     return np.ascontiguousarray(np.asarray(a, dtype=np.float32).ravel())
 
@@ -320,7 +324,7 @@ class Scene:
         st = L.Stats()
         self._chk(self.lib.glome_render(self.h, C.byref(cam), la, len(lights), C.byref(params), img.ctypes.data_as(L.c_fp),
                                         packed.ctypes.data_as(L.c_up) if want_packed else None, C.byref(st)), "glome_render")
-        return img, packed, {k: getattr(st, k) for k, _ in L.Stats._fields_}
+        return img, packed, _stats_dict(st)
 
     def render_dev(self, cam, lights, params, rgbad_ptr, packed_ptr=None, want_stats=True):
         """Device-pointer render (e.g. a torch tensor's data_ptr()); asynchronous unless want_stats."""
@@ -328,4 +332,4 @@ class Scene:
         st = L.Stats()
         self._chk(self.lib.glome_render_dev(self.h, C.byref(cam), la, len(lights), C.byref(params), C.c_void_p(rgbad_ptr),
                                             C.c_void_p(packed_ptr) if packed_ptr else None, C.byref(st) if want_stats else None), "glome_render_dev")
-        return {k: getattr(st, k) for k, _ in L.Stats._fields_} if want_stats else None
+        return _stats_dict(st) if want_stats else None

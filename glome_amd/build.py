@@ -7,7 +7,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libglome_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-hip-fp32-correctly-rounded-divide-sqrt"]
+# -ffp-contract=on: contraction decided per source expression, so every kernel instance rounds identically (the tests
+# require bit-identical frames across instances); denormals flushed so 1/x is a bare v_rcp_f32
+HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-ffp-contract=on",
+            "-fgpu-flush-denormals-to-zero"]
 
 
 def _stale(target, sources):

@@ -31,6 +31,8 @@ inline F4 mk4u(double x, double y, double z, uint32_t w) { return F4{f32(x), f32
 inline float round_up(double d) { float f = (float)d; return ((double)f < d) ? std::nextafterf(f, INFINITY) : f; }
 inline float round_down(double d) { float f = (float)d; return ((double)f > d) ? std::nextafterf(f, -INFINITY) : f; }
 
+constexpr uint32_t BREF_LEAF_BIT = 1u << 29, BREF_FIRST_LIMIT = 1u << 26;  // child references, see rt_device.hpp
+
 class Flattener {
  public:
   Flattener(const Graph& g, FlatScene& out) : G(g), F(out) {}
@@ -236,20 +238,19 @@ class Flattener {
       all_sph &= simple && c.kind == K_SPHERE && p.flags == 0;
     }
     uint32_t cls = all_tri ? BC_TRI : (all_sph ? BC_SPHERE : (all_simple ? BC_SIMPLE : BC_GENERIC));
-    uint32_t hdr = (uint32_t)(F.bihhdr.size() / 2);
+    uint32_t hdr = (uint32_t)(F.bihhdr.size() / 3);
+    F.bihhdr.resize(F.bihhdr.size() + 3);  // reserved now: items of a generic BIH may emit nested BIHs before we fill it
     uint32_t base = (uint32_t)F.bihnodes.size();
-    F.bihhdr.push_back(mk4u(round_down(T.bb.lo.x), round_down(T.bb.lo.y), round_down(T.bb.lo.z), base));
-    F.bihhdr.push_back(mk4u(round_up(T.bb.hi.x), round_up(T.bb.hi.y), round_up(T.bb.hi.z), cls));
-    F.bihnodes.resize(base + T.nodes.size());
-    if (base + T.nodes.size() >= (1u << 30)) throw limit_error("too many BIH nodes");
+    F.bihnodes.resize(base + T.nodes.size());  // one slot per tree node; leaf slots are only read for leaves of 7+ items
+    if (base + T.nodes.size() >= BREF_FIRST_LIMIT) throw limit_error("too many BIH nodes");
+    // pass 1: leaves -- emit the items fresh (no memo) so records and pool entries are consecutive, and build the
+    // child reference that describes each leaf (rt_device.hpp: BREF_*)
+    std::vector<uint32_t> ref(T.nodes.size(), 0);
+    uint32_t delta = 0;
+    bool have_delta = false;
     for (size_t k = 0; k < T.nodes.size(); k++) {
       const BihTree::Node& bn = T.nodes[k];
-      if (!bn.leaf) {
-        F.bihnodes[base + k] = F4{round_up(bn.lsplit), round_down(bn.rsplit), as_float_bits((uint32_t)bn.axis | ((base + (uint32_t)bn.left) << 2)),
-                                  as_float_bits(base + (uint32_t)bn.right)};
-        continue;
-      }
-      // leaf: emit the items fresh (no memo) so records and pool entries are consecutive
+      if (!bn.leaf) { ref[k] = base + (uint32_t)k; continue; }
       std::vector<U4> items;
       uint32_t first_prim = 0;
       for (size_t q = 0; q < bn.items.size(); q++) {
@@ -266,9 +267,27 @@ class Flattener {
       }
       uint32_t first_rec = (uint32_t)F.recs.size();
       F.recs.insert(F.recs.end(), items.begin(), items.end());
-      if (bn.items.size() >= (1u << 30)) throw limit_error("BIH leaf too large");
-      F.bihnodes[base + k] = F4{as_float_bits(first_prim), 0.0f, as_float_bits(3u | ((uint32_t)bn.items.size() << 2)), as_float_bits(first_rec)};
+      if (first_rec + items.size() >= BREF_FIRST_LIMIT) throw limit_error("too many records for the BIH leaf references");
+      uint32_t count = (uint32_t)items.size();
+      if (count && (cls == BC_TRI || cls == BC_SPHERE)) {
+        uint32_t dl = first_prim - first_rec;  // both are emitted in leaf order, so this is one constant per BIH
+        if (have_delta && dl != delta) throw scene_error("internal: BIH leaf pools are not contiguous");
+        delta = dl; have_delta = true;
+      }
+      F.bihnodes[base + k] = F4{0.0f, 0.0f, as_float_bits(count), as_float_bits(first_rec)};
+      if (count == 0) ref[k] = BREF_LEAF_BIT;
+      else if (count <= 6) ref[k] = BREF_LEAF_BIT | (count << 26) | first_rec;
+      else ref[k] = BREF_LEAF_BIT | (7u << 26) | (base + (uint32_t)k);
     }
+    // pass 2: branches
+    for (size_t k = 0; k < T.nodes.size(); k++) {
+      const BihTree::Node& bn = T.nodes[k];
+      if (bn.leaf) continue;
+      F.bihnodes[base + k] = F4{round_up(bn.lsplit), round_down(bn.rsplit), as_float_bits((uint32_t)bn.axis | (ref[bn.left] << 2)), as_float_bits(ref[bn.right])};
+    }
+    F.bihhdr[3 * hdr] = mk4u(round_down(T.bb.lo.x), round_down(T.bb.lo.y), round_down(T.bb.lo.z), ref[0]);
+    F.bihhdr[3 * hdr + 1] = mk4u(round_up(T.bb.hi.x), round_up(T.bb.hi.y), round_up(T.bb.hi.z), cls);
+    F.bihhdr[3 * hdr + 2] = F4{as_float_bits(delta), 0, 0, 0};
     return U4{R_BIH, hdr, 0, (uint32_t)n.uid};
   }
 
@@ -342,7 +361,7 @@ class Flattener {
       case K_BIH: {
         U4 r = emit(id);
         uint32_t cls;
-        std::memcpy(&cls, &F.bihhdr[2 * r.y + 1].w, 4);
+        std::memcpy(&cls, &F.bihhdr[3 * r.y + 1].w, 4);
         if (cls == BC_GENERIC) { F.tier = 1; F.why_generic = "BIH with composite items"; return; }
         F.entries.push_back(U4{slot(r), incoming, flags, 0});
         return;

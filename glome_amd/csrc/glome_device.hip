@@ -31,7 +31,7 @@ using namespace glome;
 // FAITHFUL = the reference's exact node-visit order (no ordered early-out, Bih.hs:332-368); COUNT = node / primitive
 // work counters.  They back the `faithful` / `count_work` render params (byte-model measurement, parity tests).
 // The production variant traverses with early-out and counts rays only.
-template <bool FAITHFUL, bool COUNT, bool FULL_>
+template <bool FAITHFUL, bool COUNT, bool FULL_, int CLS = CLS_ALL>
 struct FlatTier {
   static constexpr bool FULL = FULL_;  // false: lean kernel -- no out-of-line calls at all (no secondary rays, no Blend/Layers)
   const DScene& S;
@@ -40,10 +40,10 @@ struct FlatTier {
   LaneStack stk;
   Cnt cnt;
   __device__ __forceinline__ HitG closest(const Ray& r, float tmax) {
-    Cand c = closest_flat<FAITHFUL, COUNT>(S, r, tmax, stk, cnt);
-    return finalize_flat(S, r, c);
+    Cand c = closest_flat<FAITHFUL, COUNT, CLS>(S, r, tmax, stk, cnt);
+    return finalize_flat<CLS>(S, r, c);
   }
-  __device__ __forceinline__ bool occluded(const Ray& r, float d) { return occluded_flat<COUNT>(S, r, d, stk, cnt); }
+  __device__ __forceinline__ bool occluded(const Ray& r, float d) { return occluded_flat<COUNT, CLS>(S, r, d, stk, cnt); }
   __device__ __noinline__ HitG closest_ni(const Ray& r, float tmax) { return closest(r, tmax); }
   __device__ __noinline__ bool occluded_ni(const Ray& r, float d) { return occluded(r, d); }
 };
@@ -70,7 +70,8 @@ struct GenericTier {
   __device__ __forceinline__ bool occluded_ni(const Ray& r, float d) { return occluded(r, d); }
 };
 
-__device__ __forceinline__ LaneStack lane_stack(uint32_t* lds, int cap) {
+// LDS carve per wave: three stack columns of cap * 64 words
+__device__ __forceinline__ LaneStack lane_stack(uint32_t* lds, int cap, uint32_t* ovf_base, int ovf_cap) {
   int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t* base = lds + (size_t)wave * cap * 64 * 3;
   LaneStack s;
@@ -78,8 +79,12 @@ __device__ __forceinline__ LaneStack lane_stack(uint32_t* lds, int cap) {
   s.nearv = (float*)(base + cap * 64) + lane;
   s.farv = (float*)(base + 2 * cap * 64) + lane;
   s.cap = cap;
+  // overflow: one [entry*3][64] block per wave slot (blockIdx.x * waves_per_block + wave)
+  s.ovf_cap = ovf_base ? ovf_cap : 0;
+  s.ovf = ovf_base ? ovf_base + ((size_t)(blockIdx.x * (blockDim.x >> 6) + wave) * ovf_cap * 3) * 64 + lane : nullptr;
   return s;
 }
+static size_t flat_lds_bytes(int cap) { return (size_t)cap * 64 * 12; }
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned int v) {
   unsigned long long s = v;
@@ -158,10 +163,10 @@ __device__ __forceinline__ void render_loop(const DRenderArgs& A, TIER& T) {
   }
 }
 
-template <bool FAITHFUL, bool COUNT, bool FULL>
-__global__ void __launch_bounds__(64) k_render_flat(DRenderArgs A, int stack_cap) {
+template <bool FAITHFUL, bool COUNT, bool FULL, int CLS, int LB = 1>
+__global__ void __launch_bounds__(64, LB) k_render_flat(DRenderArgs A, int stack_cap, uint32_t* ovf, int ovf_cap) {
   extern __shared__ uint32_t lds[];
-  FlatTier<FAITHFUL, COUNT, FULL> T{A.S, A.lights, A.nlights, lane_stack(lds, stack_cap), Cnt()};
+  FlatTier<FAITHFUL, COUNT, FULL, CLS> T{A.S, A.lights, A.nlights, lane_stack(lds, stack_cap, ovf, ovf_cap), Cnt()};
   render_loop(A, T);
   flush_counters(A.counters, T.cnt, 0);
 }
@@ -193,15 +198,15 @@ __device__ __forceinline__ Ray load_ray(const RayStream& R, size_t i) {
   return r;
 }
 template <bool FAITHFUL>
-__global__ void __launch_bounds__(64) k_rayint_batch_flat(DScene S, size_t n, RayStream R, HitStream H, int stack_cap) {
+__global__ void __launch_bounds__(64) k_rayint_batch_flat(DScene S, size_t n, RayStream R, HitStream H, int stack_cap, uint32_t* ovf, int ovf_cap) {
   extern __shared__ uint32_t lds[];
-  FlatTier<FAITHFUL, false, false> T{S, nullptr, 0, lane_stack(lds, stack_cap), Cnt()};
+  FlatTier<FAITHFUL, false, false, CLS_ALL> T{S, nullptr, 0, lane_stack(lds, stack_cap, ovf, ovf_cap), Cnt()};
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     store_hit(H, i, T.closest(load_ray(R, i), R.tmax[i]));
 }
-__global__ void __launch_bounds__(64) k_shadow_batch_flat(DScene S, size_t n, RayStream R, uint8_t* occ, int stack_cap) {
+__global__ void __launch_bounds__(64) k_shadow_batch_flat(DScene S, size_t n, RayStream R, uint8_t* occ, int stack_cap, uint32_t* ovf, int ovf_cap) {
   extern __shared__ uint32_t lds[];
-  FlatTier<false, false, false> T{S, nullptr, 0, lane_stack(lds, stack_cap), Cnt()};
+  FlatTier<false, false, false, CLS_ALL> T{S, nullptr, 0, lane_stack(lds, stack_cap, ovf, ovf_cap), Cnt()};
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     occ[i] = T.occluded(load_ray(R, i), R.tmax[i]) ? 1 : 0;
 }
@@ -264,6 +269,8 @@ struct glome_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipDeviceProp_t prop;
   DCounters* d_counters = nullptr;
+  uint32_t* d_ovf = nullptr;  // traversal-stack overflow workspace (grown on demand)
+  size_t ovf_bytes = 0;
   std::string err;
   // tile tables cached per (w, h, blocksize, first, stride)
   struct TileTable { std::vector<DTile> host; DTile* dev = nullptr; uint32_t total_waves = 0; int64_t pixels = 0; };
@@ -271,11 +278,13 @@ struct glome_ctx {
 };
 struct glome_scene {
   glome_ctx* ctx = nullptr;
+  int ovf_cap = 0;  // stack entries per lane beyond the LDS part
   DScene dev{};
   std::vector<void*> allocs;
   glome_scene_info info{};
   int stack_cap = 8;
   bool has_secondary_mats = false, has_nested_mats = false;
+  int cls_mask = CLS_ALL;  // which entry classes the flat root program contains
 };
 
 static std::string g_global_error;
@@ -350,6 +359,7 @@ void glome_ctx_destroy(glome_ctx* c) {
   (void)hipSetDevice(c->device);
   for (auto& kv : c->tile_cache) if (kv.second.dev) (void)hipFree(kv.second.dev);
   if (c->d_counters) (void)hipFree(c->d_counters);
+  if (c->d_ovf) (void)hipFree(c->d_ovf);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   for (hipEvent_t ev : c->pool) (void)hipEventDestroy(ev);
@@ -430,8 +440,25 @@ glome_scene* glome_scene_commit(glome_ctx* ctx, glome_sb* sb, int32_t root) {
     if (m.kind == MAT_REFLECT || m.kind == MAT_REFRACT) s->has_secondary_mats = true;
     if (m.kind == MAT_LAYERS || m.kind == MAT_BLEND) s->has_nested_mats = true;
   }
+  if (F.tier == 0) {
+    int m = 0;
+    for (const U4& e : F.entries) {
+      const U4& r = F.recs[e.x];
+      uint32_t k = r.x & RF_KINDMASK;
+      if (k == R_BIH) { uint32_t c; memcpy(&c, &F.bihhdr[3 * r.y + 1].w, 4); m |= c == BC_TRI ? CLS_BIH_TRI : (c == BC_SPHERE ? CLS_BIH_SPHERE : CLS_BIH_SIMPLE); }
+      else if (k == R_MESH) m |= CLS_MESH;
+      else if (k != R_VOID) m |= CLS_PRIMS;
+    }
+    s->cls_mask = m;
+  }
   int need = std::max(F.max_bih_depth, F.max_mesh_depth);
-  s->stack_cap = std::min(kFlatStack, std::max(4, (need + 3) & ~3));
+  // LDS holds up to kLdsStack entries per lane (LDS per wave bounds occupancy); a deeper tree keeps its correctness
+  // through the global overflow columns.
+  constexpr int kLdsStack = 12;
+  int lds_cap = getenv("GLOME_DEBUG_STACK_CAP") ? atoi(getenv("GLOME_DEBUG_STACK_CAP")) : kLdsStack;
+  int total = std::min(kFlatStack, std::max(4, need));
+  s->stack_cap = std::max(4, std::min(lds_cap, total));
+  s->ovf_cap = std::max(0, total - s->stack_cap);
   return s;
 }
 void glome_scene_release(glome_scene* s) {
@@ -455,6 +482,14 @@ static int persistent_grid(glome_ctx* ctx, size_t lds_per_block, uint32_t total_
   long g = (long)cus * per_cu;
   return (int)std::max<long>(1, std::min<long>(g, total_work));
 }
+static int ensure_overflow(glome_ctx* ctx, int grid, int waves_per_block, int ovf_cap) {
+  size_t need = (size_t)grid * waves_per_block * ovf_cap * 3 * 64 * sizeof(uint32_t);
+  if (need <= ctx->ovf_bytes) return 0;
+  if (ctx->d_ovf) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->d_ovf)); ctx->d_ovf = nullptr; ctx->ovf_bytes = 0; }
+  HIPCHK(ctx, hipMalloc((void**)&ctx->d_ovf, need));
+  ctx->ovf_bytes = need;
+  return 0;
+}
 static int check_device_error(glome_ctx* ctx) {
   DCounters c;
   HIPCHK(ctx, hipMemcpy(&c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
@@ -469,10 +504,28 @@ static void launch_render(glome_scene* s, const DRenderArgs& A, const glome_rend
     // lean kernel: legal when no secondary trace can do work and no material nests (Blend / AdditiveLayers)
     bool full = s->has_nested_mats || (s->has_secondary_mats && P->maxdepth > 1);
     dim3 g(grid), blk(64);
-#define GLOME_LAUNCH(F, C, U) hipLaunchKernelGGL((k_render_flat<F, C, U>), g, blk, lds, st, A, s->stack_cap)
-    if (faithful) { if (full) GLOME_LAUNCH(true, true, true); else GLOME_LAUNCH(true, true, false); }
-    else if (count) { if (full) GLOME_LAUNCH(false, true, true); else GLOME_LAUNCH(false, true, false); }
-    else { if (full) GLOME_LAUNCH(false, false, true); else GLOME_LAUNCH(false, false, false); }
+    // scene class -> the smallest kernel instance that covers it (SPECIALIZE analogue, Bih.hs:370-374)
+    int m = s->cls_mask;
+    int cls = (m & ~CLS_BIH_TRI) == 0 ? CLS_BIH_TRI : ((m & ~(CLS_BIH_SPHERE | CLS_PRIMS)) == 0 ? (CLS_BIH_SPHERE | CLS_PRIMS) : ((m & ~CLS_MESH) == 0 ? CLS_MESH : CLS_ALL));
+    int lb = getenv("GLOME_DEBUG_LB") ? atoi(getenv("GLOME_DEBUG_LB")) : 0;
+#define GLOME_LAUNCH(F, C, U, K, B) hipLaunchKernelGGL((k_render_flat<F, C, U, K, B>), g, blk, lds, st, A, s->stack_cap, s->ovf_cap ? s->ctx->d_ovf : nullptr, s->ovf_cap)
+#define GLOME_BY_CLS(F, C, U)                                                   \
+    do {                                                                          \
+      if (cls == CLS_BIH_TRI) GLOME_LAUNCH(F, C, U, CLS_BIH_TRI, 1);              \
+      else if (cls == (CLS_BIH_SPHERE | CLS_PRIMS)) GLOME_LAUNCH(F, C, U, (CLS_BIH_SPHERE | CLS_PRIMS), 1); \
+      else if (cls == CLS_MESH) GLOME_LAUNCH(F, C, U, CLS_MESH, 1);               \
+      else GLOME_LAUNCH(F, C, U, CLS_ALL, 1);                                     \
+    } while (0)
+    if (faithful) { if (full) GLOME_LAUNCH(true, true, true, CLS_ALL, 1); else GLOME_LAUNCH(true, true, false, CLS_ALL, 1); }
+    else if (count) { if (full) GLOME_LAUNCH(false, true, true, CLS_ALL, 1); else GLOME_LAUNCH(false, true, false, CLS_ALL, 1); }
+    else if (full) GLOME_BY_CLS(false, false, true);
+    else if (cls == CLS_BIH_TRI && lb == 2) GLOME_LAUNCH(false, false, false, CLS_BIH_TRI, 2);
+    else if (cls == CLS_BIH_TRI && lb == 3) GLOME_LAUNCH(false, false, false, CLS_BIH_TRI, 3);
+    else if (cls == CLS_BIH_TRI && lb == 4) GLOME_LAUNCH(false, false, false, CLS_BIH_TRI, 4);
+    else if (cls == CLS_BIH_TRI && lb == 6) GLOME_LAUNCH(false, false, false, CLS_BIH_TRI, 6);
+    else if (cls == CLS_BIH_TRI && lb == 8) GLOME_LAUNCH(false, false, false, CLS_BIH_TRI, 8);
+    else GLOME_BY_CLS(false, false, false);
+#undef GLOME_BY_CLS
 #undef GLOME_LAUNCH
   } else {
     hipLaunchKernelGGL(k_render_generic, dim3(grid), dim3(64), 0, st, A);
@@ -506,8 +559,9 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
   HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(DCounters), ctx->stream));
   hipEvent_t ev_start = ctx->ev0, ev_stop = ctx->ev1;
   if (A.ntiles > 0) {
-    size_t lds = s->dev.tier == 0 ? (size_t)s->stack_cap * 64 * 12 : 0;
+    size_t lds = s->dev.tier == 0 ? flat_lds_bytes(s->stack_cap) : 0;
     int grid = persistent_grid(ctx, lds, A.total_waves);
+    if (s->dev.tier == 0 && s->ovf_cap && (rc = ensure_overflow(ctx, grid, 1, s->ovf_cap))) return rc;
     bool pooled = ctx->timing && ctx->pool_used + 2 <= (int)ctx->pool.size();
     hipEvent_t e0 = pooled ? ctx->pool[ctx->pool_used] : ctx->ev0, e1 = pooled ? ctx->pool[ctx->pool_used + 1] : ctx->ev1;
     if (pooled) ctx->pool_used += 2;
@@ -582,8 +636,10 @@ int glome_rayint_batch_dev(glome_scene* s, size_t n, const float* ox, const floa
   RayStream R{ox, oy, oz, dx, dy, dz, tmax};
   HitStream H{t, prim, nx, ny, nz, tex4};
   if (s->dev.tier == 0) {
-    size_t lds = (size_t)s->stack_cap * 64 * 12;
-    hipLaunchKernelGGL((k_rayint_batch_flat<false>), dim3(batch_grid(ctx, n, lds)), dim3(64), lds, ctx->stream, s->dev, n, R, H, s->stack_cap);
+    size_t lds = flat_lds_bytes(s->stack_cap);
+    int grid = batch_grid(ctx, n, lds), rc;
+    if (s->ovf_cap && (rc = ensure_overflow(ctx, grid, 1, s->ovf_cap))) return rc;
+    hipLaunchKernelGGL((k_rayint_batch_flat<false>), dim3(grid), dim3(64), lds, ctx->stream, s->dev, n, R, H, s->stack_cap, s->ovf_cap ? ctx->d_ovf : nullptr, s->ovf_cap);
   } else {
     HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(DCounters), ctx->stream));
     hipLaunchKernelGGL(k_rayint_batch_generic, dim3(batch_grid(ctx, n, 0)), dim3(64), 0, ctx->stream, s->dev, n, R, H, ctx->d_counters);
@@ -600,8 +656,10 @@ int glome_shadow_batch_dev(glome_scene* s, size_t n, const float* ox, const floa
   HIPCHK(ctx, hipSetDevice(ctx->device));
   RayStream R{ox, oy, oz, dx, dy, dz, tmax};
   if (s->dev.tier == 0) {
-    size_t lds = (size_t)s->stack_cap * 64 * 12;
-    hipLaunchKernelGGL(k_shadow_batch_flat, dim3(batch_grid(ctx, n, lds)), dim3(64), lds, ctx->stream, s->dev, n, R, occluded, s->stack_cap);
+    size_t lds = flat_lds_bytes(s->stack_cap);
+    int grid = batch_grid(ctx, n, lds), rc;
+    if (s->ovf_cap && (rc = ensure_overflow(ctx, grid, 1, s->ovf_cap))) return rc;
+    hipLaunchKernelGGL(k_shadow_batch_flat, dim3(grid), dim3(64), lds, ctx->stream, s->dev, n, R, occluded, s->stack_cap, s->ovf_cap ? ctx->d_ovf : nullptr, s->ovf_cap);
   } else {
     HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(DCounters), ctx->stream));
     hipLaunchKernelGGL(k_shadow_batch_generic, dim3(batch_grid(ctx, n, 0)), dim3(64), 0, ctx->stream, s->dev, n, R, occluded, ctx->d_counters);

@@ -331,23 +331,45 @@ GD bool prim_inside(const DScene& S, uint32_t kind, uint32_t a, V3 p) {
   }
 }
 
+// wave-wide vote: how many lanes of this wave hold `pred` (host build: one "lane", so all or nothing)
+GD int wave_count(bool pred) {
+#if defined(__HIPCC__)
+  return __popcll(__ballot(pred));
+#else
+  return pred ? 64 : 0;
+#endif
+}
+
 // ------------------------------------------------------------------ traversal stacks
 // Flat tier: one LDS column per lane -- entry e of lane l lives at base[e * 64 + l], so a wave's push or
 // pop touches 64 consecutive dwords: conflict-free for ds_read/write_b32 whatever the lanes' depths.
+// The LDS part holds `cap` entries (kept small: LDS per wave is what bounds occupancy); deeper pushes, which are
+// rare, spill to a per-lane column in global memory (`ovf`, same [entry][lane] layout), so any tree depth up to
+// kFlatStack is traversed correctly.
 struct LaneStack {
   uint32_t* node; float* nearv; float* farv;  // pointers to this lane's column (stride 64)
-  int cap;                                   // entries available (chosen from the scene's tree depth at commit)
+  int cap;                                   // entries held in LDS
+  uint32_t* ovf;                             // this lane's overflow column in global memory (3 words per entry), or null
+  int ovf_cap;                               // entries available there
 #if defined(__HIPCC__)
   static constexpr int STRIDE = 64;
 #else
   static constexpr int STRIDE = 1;
 #endif
-  GD void push(int sp, uint32_t n, float a, float b) { node[sp * STRIDE] = n; nearv[sp * STRIDE] = a; farv[sp * STRIDE] = b; }
-  GD void pop(int sp, uint32_t& n, float& a, float& b) const { n = node[sp * STRIDE]; a = nearv[sp * STRIDE]; b = farv[sp * STRIDE]; }
+  GD int total_cap() const { return cap + ovf_cap; }
+  GD void push(int sp, uint32_t n, float a, float b) {
+    if (sp < cap) { node[sp * STRIDE] = n; nearv[sp * STRIDE] = a; farv[sp * STRIDE] = b; }
+    else { uint32_t* o = ovf + (size_t)(sp - cap) * 3 * STRIDE; o[0] = n; o[STRIDE] = as_u(a); o[2 * STRIDE] = as_u(b); }
+  }
+  GD void pop(int sp, uint32_t& n, float& a, float& b) const {
+    if (sp < cap) { n = node[sp * STRIDE]; a = nearv[sp * STRIDE]; b = farv[sp * STRIDE]; }
+    else { const uint32_t* o = ovf + (size_t)(sp - cap) * 3 * STRIDE; n = o[0]; a = as_f(o[STRIDE]); b = as_f(o[2 * STRIDE]); }
+  }
 };
 // Generic tier: a fixed private array (scratch).
 struct PrivStack {
   uint32_t node[kGenericStack]; float nearv[kGenericStack]; float farv[kGenericStack];
+  GD int total_cap() const { return kGenericStack; }
   GD void push(int sp, uint32_t n, float a, float b) { node[sp] = n; nearv[sp] = a; farv[sp] = b; }
   GD void pop(int sp, uint32_t& n, float& a, float& b) const { n = node[sp]; a = nearv[sp]; b = farv[sp]; }
 };
@@ -361,46 +383,59 @@ struct PrivStack {
 //   MODE 2 (any hit, shadow_bih): stops at the first occluder.
 // leaf(first_rec, first_prim, count, tmax) tests a leaf's items; it returns true to stop the traversal.
 // best_t() is the running best distance (MODE 1).
+// Child references: bit 29 = leaf, then bits 28..26 = item count (7 = "read it from the leaf node at index
+// bits 25..0"), bits 25..0 = first record of the leaf.  A leaf with up to 6 items is therefore described entirely by
+// the reference held in its parent: reaching it costs no memory fetch, and an empty leaf (a quarter of the leaves the
+// reference builder makes) is never visited at all.  Branch references are plain node indices.
+constexpr uint32_t BREF_LEAF = 1u << 29, BREF_MASK = (1u << 30) - 1u, BREF_FIRST = (1u << 26) - 1u;
 template <int MODE, bool COUNT, class STK, class LEAF, class BEST>
 GD void bih_traverse(const DScene& S, uint32_t hdr, const Ray& r, float d, STK& stk, int stack_cap, Cnt& cnt, LEAF&& leaf, BEST&& best_t) {
-  F4 h0 = ld4(S.bihhdr, 2 * hdr), h1 = ld4(S.bihhdr, 2 * hdr + 1);
+  F4 h0 = ld4(S.bihhdr, 3 * hdr), h1 = ld4(S.bihhdr, 3 * hdr + 1);
+  const uint32_t delta = as_u(ld4(S.bihhdr, 3 * hdr + 2).x);  // first_prim - first_rec: constant per homogeneous BIH
   float nearv, farv;
   bbclip_ub(r, v3(h0), v3(h1), nearv, farv);
   farv = gminf(d, farv);  // `traverse root near (fmin d far)`, Bih.hs:368
   V3 rcp = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
-  uint32_t node = as_u(h0.w);
+  uint32_t ref = as_u(h0.w);
   int sp = 0;
   for (;;) {
     bool popit = true;
     if (MODE == 1) farv = gminf(farv, best_t());
-    F4 n = ld4(S.bihnodes, node);
-    uint32_t w0 = as_u(n.z), w1 = as_u(n.w);
-    uint32_t axis = w0 & 3u;
-    if (axis == 3u) {
+    if (ref & BREF_LEAF) {
       // BihLeaf: `rayint s r far` -- the reference tests a leaf it has reached without looking at near > far
       // (Bih.hs:339); with early-out an empty interval cannot hold the nearest hit, so it is skipped.
-      if (MODE == 0 || !(nearv > farv)) {
-        if (leaf(w1, as_u(n.x), w0 >> 2, farv)) return;
+      uint32_t count = (ref >> 26) & 7u, first = ref & BREF_FIRST;
+      if (count == 7u) { F4 n = ld4(S.bihnodes, first); count = as_u(n.z); first = as_u(n.w); }
+      if (count != 0 && (MODE == 0 || !(nearv > farv))) {
+        if (leaf(first, first + delta, count, farv)) return;
       }
-    } else if (COUNT && (cnt.bih++, false)) {  // rayint_debug_bih counts every branch entered, before the near > far test (Bih.hs:389-410)
-    } else if (!(nearv > farv)) {
-      float dirr = vcomp(rcp, axis), o = vcomp(r.o, axis);
-      float dl = (n.x - o) * dirr, dr = (n.y - o) * dirr;
-      uint32_t left = w0 >> 2, right = w1;
-      uint32_t c1, c2; float c1far, c2near; bool go1, go2;
-      if (dirr > 0) { c1 = left; go1 = nearv < dl; c1far = gminf(dl, farv); c2 = right; go2 = dr < farv; c2near = gmaxf(dr, nearv); }
-      else { c1 = right; go1 = nearv < dr; c1far = gminf(dr, farv); c2 = left; go2 = dl < farv; c2near = gmaxf(dl, nearv); }
-      if (go1) {
-        if (go2 && sp < stack_cap) { stk.push(sp, c2, c2near, farv); sp++; }
-        node = c1; farv = c1far; popit = false;
-      } else if (go2) {
-        node = c2; nearv = c2near; popit = false;
+    } else {
+      if (COUNT) cnt.bih++;  // rayint_debug_bih counts every branch entered, before the near > far test (Bih.hs:389-410)
+      if (!(nearv > farv)) {
+        F4 n = ld4(S.bihnodes, ref);
+        uint32_t w0 = as_u(n.z), w1 = as_u(n.w);
+        uint32_t axis = w0 & 3u;
+        float dirr = vcomp(rcp, axis), o = vcomp(r.o, axis);
+        float dl = (n.x - o) * dirr, dr = (n.y - o) * dirr;
+        uint32_t left = w0 >> 2, right = w1;
+        uint32_t c1, c2; float c1far, c2near; bool go1, go2;
+        if (dirr > 0) { c1 = left; go1 = nearv < dl; c1far = gminf(dl, farv); c2 = right; go2 = dr < farv; c2near = gmaxf(dr, nearv); }
+        else { c1 = right; go1 = nearv < dr; c1far = gminf(dr, farv); c2 = left; go2 = dl < farv; c2near = gmaxf(dl, nearv); }
+        // an empty leaf holds nothing to test: never visit it (no effect on results or on the branch-visit counts)
+        go1 = go1 && c1 != BREF_LEAF;
+        go2 = go2 && c2 != BREF_LEAF;
+        if (go1) {
+          if (go2 && sp < stack_cap) { stk.push(sp, c2, c2near, farv); sp++; }
+          ref = c1; farv = c1far; popit = false;
+        } else if (go2) {
+          ref = c2; nearv = c2near; popit = false;
+        }
       }
     }
     if (popit) {
       if (sp == 0) return;
       sp--;
-      stk.pop(sp, node, nearv, farv);
+      stk.pop(sp, ref, nearv, farv);
     }
   }
 }
@@ -484,7 +519,11 @@ GD HitG hit_miss() { HitG h; h.hit = false; h.t = kInf; h.p = v3(0, 0, 0); h.n =
 
 // closest hit over the flat root program = the list instance's `foldl' nearest RayMiss` (Solid.hs:327) over
 // simple primitives, homogeneous BIHs and meshes.  Every entry is tested with the same d (Q9).
-template <bool FAITHFUL, bool COUNT, class STK>
+// CLS is the set of entry classes the kernel instance is compiled for (the device analogue of the reference's
+// SPECIALIZE pragmas for Bih Triangle / Bih Sphere, Bih.hs:370-374): an all-triangle scene runs a kernel that contains
+// only the triangle loops, which keeps it small enough to stay in registers and in the instruction cache.
+constexpr int CLS_BIH_TRI = 1, CLS_BIH_SPHERE = 2, CLS_BIH_SIMPLE = 4, CLS_MESH = 8, CLS_PRIMS = 16, CLS_ALL = 31;
+template <bool FAITHFUL, bool COUNT, int CLS, class STK>
 GD Cand closest_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt) {
   Cand best; best.t = kInf; best.id = CAND_NONE; best.aux = 0;
   for (uint32_t e = 0; e < S.n_entries; e++) {
@@ -495,11 +534,11 @@ GD Cand closest_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt)
     // tmax for this entry; a hit replaces the running best when !(best.t < t)  (nearest: ties -> later)
     float dd = (FAITHFUL || best.id == CAND_NONE) ? d : gminf(d, best.t);
     if (kind == R_BIH) {
-      uint32_t cls = as_u(ld4(S.bihhdr, 2 * rec.y + 1).w);
+      uint32_t cls = as_u(ld4(S.bihhdr, 3 * rec.y + 1).w);
       auto bestt = [&]() { return best.id == CAND_NONE ? kInf * 4.0f : best.t; };
       auto accept = [&](float t, uint32_t id) { if (best.id == CAND_NONE || !(best.t < t)) { best.t = t; best.id = id; best.aux = e; } };
-      if (cls == BC_TRI) {
-        bih_traverse<FAITHFUL ? 0 : 1, COUNT>(S, rec.y, r, dd, stk, stk.cap, cnt,
+      if ((CLS & CLS_BIH_TRI) && (CLS == CLS_BIH_TRI || cls == BC_TRI)) {
+        bih_traverse<FAITHFUL ? 0 : 1, COUNT>(S, rec.y, r, dd, stk, stk.total_cap(), cnt,
           [&](uint32_t frec, uint32_t fprim, uint32_t count, float tmax) {
             for (uint32_t k = 0; k < count; k++) {
               uint32_t a = fprim + k;
@@ -510,8 +549,8 @@ GD Cand closest_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt)
             }
             return false;
           }, bestt);
-      } else if (cls == BC_SPHERE) {
-        bih_traverse<FAITHFUL ? 0 : 1, COUNT>(S, rec.y, r, dd, stk, stk.cap, cnt,
+      } else if ((CLS & CLS_BIH_SPHERE) && cls == BC_SPHERE) {
+        bih_traverse<FAITHFUL ? 0 : 1, COUNT>(S, rec.y, r, dd, stk, stk.total_cap(), cnt,
           [&](uint32_t frec, uint32_t fprim, uint32_t count, float tmax) {
             for (uint32_t k = 0; k < count; k++) {
               float t;
@@ -520,8 +559,8 @@ GD Cand closest_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt)
             }
             return false;
           }, bestt);
-      } else {  // BC_SIMPLE: mixed simple primitives, possibly with NoShadow / OnlyShadow flags
-        bih_traverse<FAITHFUL ? 0 : 1, COUNT>(S, rec.y, r, dd, stk, stk.cap, cnt,
+      } else if (CLS & CLS_BIH_SIMPLE) {  // BC_SIMPLE: mixed simple primitives, possibly with NoShadow / OnlyShadow flags
+        bih_traverse<FAITHFUL ? 0 : 1, COUNT>(S, rec.y, r, dd, stk, stk.total_cap(), cnt,
           [&](uint32_t frec, uint32_t, uint32_t count, float tmax) {
             for (uint32_t k = 0; k < count; k++) {
               U4 it = ldu4(S.recs, frec + k);
@@ -533,11 +572,11 @@ GD Cand closest_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt)
             return false;
           }, bestt);
       }
-    } else if (kind == R_MESH) {
+    } else if ((CLS & CLS_MESH) && kind == R_MESH) {
       float mt; uint32_t mtri;
-      mesh_closest<COUNT>(S, rec.y, r, d, stk, stk.cap, cnt, mt, mtri);  // depth = the list's d (Q12)
+      mesh_closest<COUNT>(S, rec.y, r, d, stk, stk.total_cap(), cnt, mt, mtri);  // depth = the list's d (Q12)
       if (mtri != 0xffffffffu && (best.id == CAND_NONE || !(best.t < mt))) { best.t = mt; best.id = mtri; best.aux = e | CAND_MESH; }
-    } else if (kind != R_VOID) {
+    } else if ((CLS & CLS_PRIMS) && kind != R_VOID && kind != R_MESH) {
       float t; V3 n;
       if (COUNT) cnt.prim++;
       if (prim_test<false>(S, kind, rec.y, r, dd, t, n) && (best.id == CAND_NONE || !(best.t < t))) { best.t = t; best.id = ent.x; best.aux = e; }
@@ -547,13 +586,14 @@ GD Cand closest_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt)
 }
 
 // Turn a candidate into a full hit: position (vscaleadd o dir t), normal, texture stack, primitive id.
+template <int CLS>
 GD HitG finalize_flat(const DScene& S, const Ray& r, const Cand& c) {
   HitG h = hit_miss();
   if (c.id == CAND_NONE) return h;
   h.hit = true; h.t = c.t;
   h.p = vscaleadd(r.o, r.d, c.t);
   U4 ent = ldu4(S.entries, c.aux & ~CAND_MESH);
-  if (c.aux & CAND_MESH) {
+  if ((CLS & CLS_MESH) && (c.aux & CAND_MESH)) {
     U4 rec = ldu4(S.recs, ent.x);
     uint32_t ti = c.id;
     U4 meta = ldu4(S.mtrimeta, ti);
@@ -573,15 +613,19 @@ GD HitG finalize_flat(const DScene& S, const Ray& r, const Cand& c) {
     return h;
   }
   U4 rec = ldu4(S.recs, c.id);
-  float t;
-  prim_test<true>(S, rec.x & RF_KINDMASK, rec.y, r, kInf * 8.0f, t, h.n);
+  if (CLS == CLS_BIH_TRI) {  // every primitive is a flat triangle: the normal is in the record
+    h.n = v3(ld4(S.tris, 3 * rec.y).w, ld4(S.tris, 3 * rec.y + 1).w, ld4(S.tris, 3 * rec.y + 2).w);
+  } else {
+    float t;
+    prim_test<true>(S, rec.x & RF_KINDMASK, rec.y, r, kInf * 8.0f, t, h.n);
+  }
   h.tex = tex_cat((TexStack)rec.z, (TexStack)ent.y);
   h.uid = rec.w;
   return h;
 }
 
 // shadow over the flat root program: `foldl' (||) False (map shadow xs)` (Solid.hs:330); Mesh casts none (Mesh.hs:210)
-template <bool COUNT, class STK>
+template <bool COUNT, int CLS, class STK>
 GD bool occluded_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt) {
   for (uint32_t e = 0; e < S.n_entries; e++) {
     U4 ent = ldu4(S.entries, e);
@@ -589,11 +633,11 @@ GD bool occluded_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt
     U4 rec = ldu4(S.recs, ent.x);
     uint32_t kind = rec.x & RF_KINDMASK;
     if (kind == R_BIH) {
-      uint32_t cls = as_u(ld4(S.bihhdr, 2 * rec.y + 1).w);
+      uint32_t cls = as_u(ld4(S.bihhdr, 3 * rec.y + 1).w);
       bool occ = false;
       auto nobest = [&]() { return 0.0f; };
-      if (cls == BC_TRI) {
-        bih_traverse<2, COUNT>(S, rec.y, r, d, stk, stk.cap, cnt,
+      if ((CLS & CLS_BIH_TRI) && (CLS == CLS_BIH_TRI || cls == BC_TRI)) {
+        bih_traverse<2, COUNT>(S, rec.y, r, d, stk, stk.total_cap(), cnt,
           [&](uint32_t, uint32_t fprim, uint32_t count, float tmax) {
             float dd = gminf(d, tmax);  // `shadow s r (fmin d far)`, Bih.hs:515
             for (uint32_t k = 0; k < count; k++) {
@@ -604,8 +648,8 @@ GD bool occluded_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt
             }
             return false;
           }, nobest);
-      } else if (cls == BC_SPHERE) {
-        bih_traverse<2, COUNT>(S, rec.y, r, d, stk, stk.cap, cnt,
+      } else if ((CLS & CLS_BIH_SPHERE) && cls == BC_SPHERE) {
+        bih_traverse<2, COUNT>(S, rec.y, r, d, stk, stk.total_cap(), cnt,
           [&](uint32_t, uint32_t fprim, uint32_t count, float tmax) {
             float dd = gminf(d, tmax);
             for (uint32_t k = 0; k < count; k++) {
@@ -614,8 +658,8 @@ GD bool occluded_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt
             }
             return false;
           }, nobest);
-      } else {
-        bih_traverse<2, COUNT>(S, rec.y, r, d, stk, stk.cap, cnt,
+      } else if (CLS & CLS_BIH_SIMPLE) {
+        bih_traverse<2, COUNT>(S, rec.y, r, d, stk, stk.total_cap(), cnt,
           [&](uint32_t frec, uint32_t, uint32_t count, float tmax) {
             float dd = gminf(d, tmax);
             for (uint32_t k = 0; k < count; k++) {
@@ -628,7 +672,7 @@ GD bool occluded_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt
           }, nobest);
       }
       if (occ) return true;
-    } else if (kind != R_MESH && kind != R_VOID) {
+    } else if ((CLS & CLS_PRIMS) && kind != R_MESH && kind != R_VOID) {
       if (COUNT) cnt.prim++;
       if (prim_shadow(S, kind, rec.y, r, d)) return true;
     }

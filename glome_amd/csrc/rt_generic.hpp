@@ -332,24 +332,26 @@ template <int D, bool C> struct G {
         case R_BOUND: return inside_g<D - 1>(g, ldu4(S.recs, rec.y), p) && inside_g<D - 1>(g, ldu4(S.recs, rec.z), p);  // Bound.hs:51-52
         case R_INNERBOUND: return inside_g<D - 1>(g, ldu4(S.recs, rec.y), p) || inside_g<D - 1>(g, ldu4(S.recs, rec.z), p);
         case R_BIH: {  // inside_bih, Bih.hs:550-565: strict box test, then both sides may be descended
-          F4 h0 = ld4(S.bihhdr, 2 * rec.y), h1 = ld4(S.bihhdr, 2 * rec.y + 1);
+          F4 h0 = ld4(S.bihhdr, 3 * rec.y), h1 = ld4(S.bihhdr, 3 * rec.y + 1);
           if (!(p.x > h0.x && p.x < h1.x && p.y > h0.y && p.y < h1.y && p.z > h0.z && p.z < h1.z)) return false;
           uint32_t st[kGenericStack];
           int sp = 0;
-          uint32_t node = as_u(h0.w);
+          uint32_t ref = as_u(h0.w);
           for (;;) {
-            F4 n = ld4(S.bihnodes, node);
-            uint32_t w0 = as_u(n.z), w1 = as_u(n.w), axis = w0 & 3u;
             bool popit = true;
-            if (axis == 3u) {
-              for (uint32_t k = 0; k < (w0 >> 2); k++) if (inside_g<D - 1>(g, ldu4(S.recs, w1 + k), p)) return true;
+            if (ref & BREF_LEAF) {
+              uint32_t count = (ref >> 26) & 7u, first = ref & BREF_FIRST;
+              if (count == 7u) { F4 n = ld4(S.bihnodes, first); count = as_u(n.z); first = as_u(n.w); }
+              for (uint32_t k = 0; k < count; k++) if (inside_g<D - 1>(g, ldu4(S.recs, first + k), p)) return true;
             } else {
+              F4 n = ld4(S.bihnodes, ref);
+              uint32_t w0 = as_u(n.z), w1 = as_u(n.w), axis = w0 & 3u;
               float o = vcomp(p, axis);
               bool gl = o < n.x, gr = o > n.y;
-              if (gl) { if (gr && sp < kGenericStack) st[sp++] = w1; node = w0 >> 2; popit = false; }
-              else if (gr) { node = w1; popit = false; }
+              if (gl) { if (gr && sp < kGenericStack) st[sp++] = w1; ref = w0 >> 2; popit = false; }
+              else if (gr) { ref = w1; popit = false; }
             }
-            if (popit) { if (sp == 0) return false; node = st[--sp]; }
+            if (popit) { if (sp == 0) return false; ref = st[--sp]; }
           }
         }
         default: return false;  // Mesh (Mesh.hs:211), Void
@@ -391,29 +393,31 @@ template <int D, bool C> struct G {
         case R_BOUND: if (inside_g<D - 1>(g, ldu4(S.recs, rec.y), p)) res = meta_g<D - 1>(g, ldu4(S.recs, rec.z), p); break;  // Bound.hs:54-58
         case R_INNERBOUND: res = meta_g<D - 1>(g, ldu4(S.recs, rec.z), p); break;
         case R_BIH: {  // get_metainfo_bih, Bih.hs:567-585: left result ++ right result, leaves like lists
-          F4 h0 = ld4(S.bihhdr, 2 * rec.y), h1 = ld4(S.bihhdr, 2 * rec.y + 1);
+          F4 h0 = ld4(S.bihhdr, 3 * rec.y), h1 = ld4(S.bihhdr, 3 * rec.y + 1);
           if (!(p.x > h0.x && p.x < h1.x && p.y > h0.y && p.y < h1.y && p.z > h0.z && p.z < h1.z)) break;
           uint32_t st[kGenericStack];
           int sp = 0;
-          uint32_t node = as_u(h0.w);
+          uint32_t ref = as_u(h0.w);
           for (;;) {
-            F4 n = ld4(S.bihnodes, node);
-            uint32_t w0 = as_u(n.z), w1 = as_u(n.w), axis = w0 & 3u;
             bool popit = true;
-            if (axis == 3u) {
+            if (ref & BREF_LEAF) {
+              uint32_t count = (ref >> 26) & 7u, first = ref & BREF_FIRST;
+              if (count == 7u) { F4 n = ld4(S.bihnodes, first); count = as_u(n.z); first = as_u(n.w); }
               TexStack leaf = 0;
-              for (uint32_t k = 0; k < (w0 >> 2); k++) {
-                U4 c = ldu4(S.recs, w1 + k);
+              for (uint32_t k = 0; k < count; k++) {
+                U4 c = ldu4(S.recs, first + k);
                 if (inside_g<D - 1>(g, c, p)) leaf = tex_cat(meta_g<D - 1>(g, c, p), leaf);
               }
               res = tex_cat(res, leaf);
             } else {
+              F4 n = ld4(S.bihnodes, ref);
+              uint32_t w0 = as_u(n.z), w1 = as_u(n.w), axis = w0 & 3u;
               float o = vcomp(p, axis);
               bool gl = o < n.x, gr = o > n.y;
-              if (gl) { if (gr && sp < kGenericStack) st[sp++] = w1; node = w0 >> 2; popit = false; }
-              else if (gr) { node = w1; popit = false; }
+              if (gl) { if (gr && sp < kGenericStack) st[sp++] = w1; ref = w0 >> 2; popit = false; }
+              else if (gr) { ref = w1; popit = false; }
             }
-            if (popit) { if (sp == 0) break; node = st[--sp]; }
+            if (popit) { if (sp == 0) break; ref = st[--sp]; }
           }
           break;
         }

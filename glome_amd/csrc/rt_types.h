@@ -13,8 +13,10 @@
 //   discs     float4  x2: (p.xyz, r^2) (n.xyz, -)
 //   quadrics  float4  cylinder (r, h1, h2, -) / cone (r, clip1, clip2, height)
 //   xfms      float4  x6: forward rows 0..2, inverse rows 0..2
-//   bihhdr    float4  x2: (bb.min, root node) (bb.max, leaf class)
-//   bihnodes  float4  branch (lsplit, rsplit, axis | left<<2, right); leaf (first prim, -, 3 | count<<2, first rec)
+//   bihhdr    float4  x3: (bb.min, root ref) (bb.max, leaf class) (first_prim - first_rec, -, -, -)
+//   bihnodes  float4  branch (lsplit, rsplit, axis | left_ref<<2, right_ref); child refs: bit 29 = leaf, bits 28..26 =
+//                     item count (7 = read the leaf slot), bits 25..0 = first record -- a leaf of <= 6 items costs no fetch;
+//                     leaf slot (-, -, count, first rec)
 //   meshhdr   float4  x2: (bb.min, root ref) (bb.max, root count)
 //   meshnodes float4  x4: (lbb.min, lref) (lbb.max, lcnt) (rbb.min, rref) (rbb.max, rcnt)
 //   mtris     float4  x3 per mesh triangle in leaf order, same layout as `tris`

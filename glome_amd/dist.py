@@ -105,4 +105,4 @@ class ShardedFrame:
                                                    C.c_void_p(self.frame.data_ptr()), None)
                 if rc != 0:
                     raise api.GlomeError("glome_tiles_blit_dev: " + self.ctx.err())
-        return {k: getattr(st, k) for k, _ in L.Stats._fields_} if stats else None
+        return api._stats_dict(st) if stats else None

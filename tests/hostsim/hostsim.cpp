@@ -24,8 +24,8 @@ template <bool FAITHFUL, bool COUNT, bool FULL_> struct HostFlatTier {
   int nlights;
   LaneStack stk;
   Cnt cnt;
-  HitG closest(const Ray& r, float tmax) { Cand c = closest_flat<FAITHFUL, COUNT>(S, r, tmax, stk, cnt); return finalize_flat(S, r, c); }
-  bool occluded(const Ray& r, float d) { return occluded_flat<COUNT>(S, r, d, stk, cnt); }
+  HitG closest(const Ray& r, float tmax) { Cand c = closest_flat<FAITHFUL, COUNT, CLS_ALL>(S, r, tmax, stk, cnt); return finalize_flat<CLS_ALL>(S, r, c); }
+  bool occluded(const Ray& r, float d) { return occluded_flat<COUNT, CLS_ALL>(S, r, d, stk, cnt); }
   HitG closest_ni(const Ray& r, float tmax) { return closest(r, tmax); }
   bool occluded_ni(const Ray& r, float d) { return occluded(r, d); }
 };
@@ -43,8 +43,15 @@ struct HostGenericTier {
 };
 
 struct HostStack {
+  // a deliberately small "LDS" part so the overflow columns are exercised by the CPU suite too
+  static constexpr int LDS_PART = 6;
   uint32_t node[kFlatStack]; float nearv[kFlatStack], farv[kFlatStack];
-  LaneStack lane(int cap) { LaneStack s; s.node = node; s.nearv = nearv; s.farv = farv; s.cap = cap; return s; }
+  uint32_t ovf[3 * kFlatStack];
+  LaneStack lane(int cap) {
+    LaneStack s; s.node = node; s.nearv = nearv; s.farv = farv; s.cap = LDS_PART < cap ? LDS_PART : cap;
+    s.ovf = ovf; s.ovf_cap = cap - s.cap;
+    return s;
+  }
 };
 
 extern "C" {
@@ -143,5 +150,35 @@ int hostsim_render(void* sv, int tier, const float* cam, const float* lights, in
     }
   if (counters) { counters[0] = (unsigned long long)width * height; counters[1] = total.shadow; counters[2] = total.secondary; }
   return err ? -2 : 0;
+}
+
+// Diagnostic: per-lane traversal work inside each 8x8 pixel block (what one wave executes), for primary rays and for
+// the shadow rays they spawn.  out[block][lane][k]: k = 0 nodes, 1 prim tests (primary); 2 nodes, 3 prims (shadow; -1 = no shadow ray)
+int hostsim_block_work(void* sv, const float* cam, const float* light_pos, int width, int height, int* out) {
+  SimScene* s = (SimScene*)sv;
+  if (s->D.tier != 0) return -1;
+  DCamera C; memcpy(&C, cam, sizeof(C));
+  HostStack hs;
+  int bw = width / 8, bh = height / 8;
+  for (int by = 0; by < bh; by++) for (int bx = 0; bx < bw; bx++) for (int lane = 0; lane < 64; lane++) {
+    int px = bx * 8 + (lane & 7), py = by * 8 + (lane >> 3);
+    float xc, yc; get_coordsf(width, height, (float)px, (float)py, xc, yc);
+    Ray ray = primary_ray(C, xc, yc);
+    HostFlatTier<false, true, false> T{s->D, nullptr, 0, hs.lane(kFlatStack), Cnt()};
+    HitG h = T.closest(ray, kInf);
+    int* o = out + ((size_t)(by * bw + bx) * 64 + lane) * 4;
+    o[0] = (int)T.cnt.bih; o[1] = (int)T.cnt.prim; o[2] = -1; o[3] = -1;
+    if (h.hit) {
+      V3 lvec = v3(light_pos[0], light_pos[1], light_pos[2]) - h.p;
+      if (!(vdot(lvec, h.n) < 0)) {
+        float llen = sqrtf(vdot(lvec, lvec));
+        Ray sr; sr.o = vscaleadd(h.p, h.n, kDel); sr.d = lvec * (1.0f / llen);
+        HostFlatTier<false, true, false> T2{s->D, nullptr, 0, hs.lane(kFlatStack), Cnt()};
+        T2.occluded(sr, llen - 2 * kDel);
+        o[2] = (int)T2.cnt.bih; o[3] = (int)T2.cnt.prim;
+      }
+    }
+  }
+  return 0;
 }
 }
