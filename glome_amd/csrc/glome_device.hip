@@ -176,6 +176,98 @@ __global__ void __launch_bounds__(64) k_render_generic(DRenderArgs A) {
   flush_counters(A.counters, T.cnt, T.err);
 }
 
+
+// ------------------------------------------------------------------------------------------------ adaptive sampler
+// renderTileSubsample (Glome.hs:226-323): one workgroup per reference tile, five passes separated by workgroup barriers.
+// Inside a pass every thread first takes the cheap `decide` test (Glome.hs:213-219) for its candidate pixels and
+// appends the ones that need a fresh sample to a list in LDS; after a barrier the workgroup traces the compacted list,
+// so the expensive lanes are dense.  The working buffer `v` lives in a dense per-tile scratch in global memory (written
+// and read by the same workgroup only); `v2` is the output.
+constexpr int kSSThreads = 256;
+template <class TIER>
+__device__ __forceinline__ TC ss_sample(const DRenderArgs& A, TIER& T, float xpix, float ypix) {
+  float xc, yc;
+  get_coordsf(A.width, A.height, xpix, ypix, xc, yc);
+  Ray ray = primary_ray(A.cam, xc, yc);
+  T.cnt.primary++;
+  HitG h;
+  CA c = trace_primary(T, ray, kInf, A.maxdepth, &h);
+  return tc(c.r, c.g, c.b, c.a, h.hit ? h.t : kInf);
+}
+__device__ __forceinline__ TC ss_load(const float* v, size_t i) { const float* p = v + i * 5; return tc(p[0], p[1], p[2], p[3], p[4]); }
+__device__ __forceinline__ void ss_store(float* v, size_t i, const TC& c) { float* p = v + i * 5; p[0] = c.r; p[1] = c.g; p[2] = c.b; p[3] = c.a; p[4] = c.d; }
+
+template <class TIER>
+__device__ __forceinline__ void subsample_tile(const DRenderArgs& A, TIER& T, const DTile& t, uint32_t* list, uint32_t* count) {
+  float* v = A.scratch + (size_t)t.pix_base * 5;  // dense tile buffer, tw * th entries
+  const int tw = t.w, th = t.h, np = tw * th, tid = threadIdx.x;
+  auto getc = [&](int dx, int dy) -> TC {  // getc, Glome.hs:233-235: neighbours outside the tile read as blank
+    if (dx >= 0 && dx < tw && dy >= 0 && dy < th) return ss_load(v, (size_t)dy * tw + dx);
+    return tc_blank();
+  };
+  for (int i = tid; i < np; i += kSSThreads) ss_store(v, i, tc_blank());  // MUV.replicate ... (0,0,0,0,infinity), :231
+  __syncthreads();
+  for (int pass = 1; pass <= 5; pass++) {
+    const float thr = pass >= 2 ? A.thresholds[pass - 2] : 0.0f;
+    int ox[4], oy[4];
+    ss_neighbours(pass, ox, oy);
+    if (tid == 0) *count = 0;
+    __syncthreads();
+    for (int i = tid; i < np; i += kSSThreads) {
+      int dx = i % tw, dy = i / tw;
+      if (!ss_candidate(pass, dx, dy)) continue;
+      bool need = true;
+      if (pass >= 2) {
+        TC a = getc(dx + ox[0], dy + oy[0]), b = getc(dx + ox[1], dy + oy[1]), c = getc(dx + ox[2], dy + oy[2]), d = getc(dx + ox[3], dy + oy[3]);
+        float variance = gmaxf(ccmp(a, c), ccmp(b, d));  // decide, Glome.hs:215
+        need = variance > thr;
+        if (!need) {
+          TC avg = cavg4(a, b, c, d);
+          if (pass < 5) ss_store(v, i, avg);
+          else ss_store(A.out5, A.dense ? (size_t)t.pix_base + i : (size_t)(t.y + dy) * A.width + (t.x + dx), ss_pass5_blend(avg, a, b, c, d, dx == tw - 1, dy == th - 1));
+        }
+      }
+      if (need) list[atomicAdd(count, 1u)] = (uint32_t)i;
+    }
+    __syncthreads();
+    const uint32_t n = *count;
+    for (uint32_t k = tid; k < n; k += kSSThreads) {
+      int i = (int)list[k], dx = i % tw, dy = i / tw;
+      float off = pass == 5 ? 0.5f : 0.0f;  // pass 5 samples the pixel's lower-right corner region (:307)
+      TC s = ss_sample(A, T, (float)(t.x + dx) + off, (float)(t.y + dy) + off);
+      if (pass < 5) ss_store(v, i, s);
+      else {
+        TC a = getc(dx + ox[0], dy + oy[0]), b = getc(dx + ox[1], dy + oy[1]), c = getc(dx + ox[2], dy + oy[2]), d = getc(dx + ox[3], dy + oy[3]);
+        ss_store(A.out5, A.dense ? (size_t)t.pix_base + i : (size_t)(t.y + dy) * A.width + (t.x + dx), ss_pass5_blend(s, a, b, c, d, dx == tw - 1, dy == th - 1));
+      }
+    }
+    __syncthreads();
+  }
+  if (A.packed && !A.dense) {
+    for (int i = tid; i < np; i += kSSThreads) {
+      size_t o = (size_t)(t.y + i / tw) * A.width + (t.x + i % tw);
+      const float* q = A.out5 + o * 5;
+      A.packed[o] = rgbf(q[0] * q[3], q[1] * q[3], q[2] * q[3]);
+    }
+  }
+}
+
+template <bool FULL, int CLS>
+__global__ void __launch_bounds__(kSSThreads) k_subsample_flat(DRenderArgs A, int stack_cap, uint32_t* ovf, int ovf_cap) {
+  extern __shared__ uint32_t lds[];
+  uint32_t* list = lds + (size_t)(kSSThreads / 64) * stack_cap * 64 * 3;
+  uint32_t* count = list + 65 * 65 + 3;
+  FlatTier<false, false, FULL, CLS> T{A.S, A.lights, A.nlights, lane_stack(lds, stack_cap, ovf, ovf_cap), Cnt()};
+  for (int ti = blockIdx.x; ti < A.ntiles; ti += gridDim.x) subsample_tile(A, T, A.tiles[ti], list, count);
+  flush_counters(A.counters, T.cnt, 0);
+}
+__global__ void __launch_bounds__(kSSThreads) k_subsample_generic(DRenderArgs A) {
+  __shared__ uint32_t list[65 * 65 + 4];
+  GenericTier T{A.S, A.lights, A.nlights, Cnt()};
+  for (int ti = blockIdx.x; ti < A.ntiles; ti += gridDim.x) subsample_tile(A, T, A.tiles[ti], list, list + 65 * 65 + 3);
+  flush_counters(A.counters, T.cnt, T.err);
+}
+
 // ------------------------------------------------------------------------------------------------ batch seams
 struct RayStream { const float *ox, *oy, *oz, *dx, *dy, *dz, *tmax; };
 struct HitStream { float* t; int32_t* prim; float *nx, *ny, *nz; int32_t* tex4; };
@@ -271,6 +363,8 @@ struct glome_ctx {
   DCounters* d_counters = nullptr;
   uint32_t* d_ovf = nullptr;  // traversal-stack overflow workspace (grown on demand)
   size_t ovf_bytes = 0;
+  float* d_scratch = nullptr;  // adaptive sampler working buffer
+  size_t scratch_bytes = 0;
   std::string err;
   // tile tables cached per (w, h, blocksize, first, stride)
   struct TileTable { std::vector<DTile> host; DTile* dev = nullptr; uint32_t total_waves = 0; int64_t pixels = 0; };
@@ -360,6 +454,7 @@ void glome_ctx_destroy(glome_ctx* c) {
   for (auto& kv : c->tile_cache) if (kv.second.dev) (void)hipFree(kv.second.dev);
   if (c->d_counters) (void)hipFree(c->d_counters);
   if (c->d_ovf) (void)hipFree(c->d_ovf);
+  if (c->d_scratch) (void)hipFree(c->d_scratch);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   for (hipEvent_t ev : c->pool) (void)hipEventDestroy(ev);
@@ -490,6 +585,13 @@ static int ensure_overflow(glome_ctx* ctx, int grid, int waves_per_block, int ov
   ctx->ovf_bytes = need;
   return 0;
 }
+static int ensure_scratch(glome_ctx* ctx, size_t need) {
+  if (need <= ctx->scratch_bytes) return 0;
+  if (ctx->d_scratch) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->d_scratch)); ctx->d_scratch = nullptr; ctx->scratch_bytes = 0; }
+  HIPCHK(ctx, hipMalloc((void**)&ctx->d_scratch, need));
+  ctx->scratch_bytes = need;
+  return 0;
+}
 static int check_device_error(glome_ctx* ctx) {
   DCounters c;
   HIPCHK(ctx, hipMemcpy(&c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
@@ -540,7 +642,8 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
   if (nlights > kMaxLights) { ctx->err = "too many lights"; return GLOME_E_LIMIT; }
   int rc = check_params(ctx, P);
   if (rc) return rc;
-  if (P->mode != GLOME_MODE_TILE) { ctx->err = "GLOME_MODE_SUBSAMPLE is not available in this build"; return GLOME_E_LIMIT; }
+  if (P->mode != GLOME_MODE_TILE && P->mode != GLOME_MODE_SUBSAMPLE) { ctx->err = "unknown render mode"; return GLOME_E_INVALID; }
+  if (P->mode == GLOME_MODE_SUBSAMPLE && P->blocksize > 65) { ctx->err = "GLOME_MODE_SUBSAMPLE supports tiles up to 65x65"; return GLOME_E_LIMIT; }
   HIPCHK(ctx, hipSetDevice(ctx->device));
   glome_ctx::TileTable* tt;
   if ((rc = get_tiles(ctx, P, P->tile_first, P->tile_stride, &tt))) return rc;
@@ -558,7 +661,33 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
   A.out5 = rgbad_dev; A.packed = dense ? nullptr : packed_dev; A.counters = ctx->d_counters; A.dense = dense;
   HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(DCounters), ctx->stream));
   hipEvent_t ev_start = ctx->ev0, ev_stop = ctx->ev1;
-  if (A.ntiles > 0) {
+  if (A.ntiles > 0 && P->mode == GLOME_MODE_SUBSAMPLE) {
+    if ((rc = ensure_scratch(ctx, (size_t)tt->pixels * 5 * sizeof(float)))) return rc;
+    A.scratch = ctx->d_scratch;
+    int grid = std::min(A.ntiles, ctx->prop.multiProcessorCount * 4);
+    bool pooled = ctx->timing && ctx->pool_used + 2 <= (int)ctx->pool.size();
+    hipEvent_t e0 = pooled ? ctx->pool[ctx->pool_used] : ctx->ev0, e1 = pooled ? ctx->pool[ctx->pool_used + 1] : ctx->ev1;
+    if (pooled) ctx->pool_used += 2;
+    ev_start = e0; ev_stop = e1;
+    HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
+    if (s->dev.tier == 0) {
+      size_t lds = flat_lds_bytes(s->stack_cap) * (kSSThreads / 64) + (65 * 65 + 4) * sizeof(uint32_t);
+      if (s->ovf_cap && (rc = ensure_overflow(ctx, grid, kSSThreads / 64, s->ovf_cap))) return rc;
+      bool full = s->has_nested_mats || (s->has_secondary_mats && P->maxdepth > 1);
+      uint32_t* ov = s->ovf_cap ? ctx->d_ovf : nullptr;
+      int m = s->cls_mask;
+      bool tri = (m & ~CLS_BIH_TRI) == 0;
+      dim3 g(grid), blk(kSSThreads);
+      if (tri && !full) hipLaunchKernelGGL((k_subsample_flat<false, CLS_BIH_TRI>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
+      else if (tri) hipLaunchKernelGGL((k_subsample_flat<true, CLS_BIH_TRI>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
+      else if (!full) hipLaunchKernelGGL((k_subsample_flat<false, CLS_ALL>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
+      else hipLaunchKernelGGL((k_subsample_flat<true, CLS_ALL>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
+    } else {
+      hipLaunchKernelGGL(k_subsample_generic, dim3(grid), dim3(kSSThreads), 0, ctx->stream, A);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
+  } else if (A.ntiles > 0) {
     size_t lds = s->dev.tier == 0 ? flat_lds_bytes(s->stack_cap) : 0;
     int grid = persistent_grid(ctx, lds, A.total_waves);
     if (s->dev.tier == 0 && s->ovf_cap && (rc = ensure_overflow(ctx, grid, 1, s->ovf_cap))) return rc;

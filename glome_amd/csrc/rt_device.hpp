@@ -877,4 +877,49 @@ GD uint32_t rgbf(float r, float g, float b) {            // Glome.hs:107-110 (wr
   return (uint32_t)ri * 65536u + (uint32_t)gi * 256u + (uint32_t)bi;
 }
 
+
+// ------------------------------------------------------------------ adaptive sampler (renderTileSubsample, Glome.hs:179-323; Q21)
+struct TC { float r, g, b, a, d; };  // TColor, Glome.hs:153
+GD TC tc(float r, float g, float b, float a, float d) { TC c; c.r = r; c.g = g; c.b = b; c.a = a; c.d = d; return c; }
+GD TC tc_blank() { return tc(0, 0, 0, 0, kInf); }  // out-of-tile neighbours and the initial buffer, Glome.hs:231-235
+GD float gabsf(float a) { return a < 0 ? -a : a; }  // fabs, Vec.hs:80-82
+GD float ccmp(const TC& p, const TC& q) {            // cCmp, Glome.hs:179-189
+  float md;
+  if (p.d == 0 && q.d == 0) md = 0;                  // muldiff 0 0 = 0
+  else md = (p.d > q.d) ? (p.d / q.d) - 1 : (q.d / p.d) - 1;
+  return gabsf(q.r - p.r) + gabsf(q.g - p.g) + gabsf(q.b - p.b) + gabsf(q.a - p.a) + md;
+}
+GD TC cavg4(const TC& a, const TC& b, const TC& c, const TC& d) {  // cAvg, Glome.hs:191-197
+  return tc((a.r + b.r + c.r + d.r) * 0.25f, (a.g + b.g + c.g + d.g) * 0.25f, (a.b + b.b + c.b + d.b) * 0.25f,
+            (a.a + b.a + c.a + d.a) * 0.25f, (a.d + b.d + c.d + d.d) * 0.25f);
+}
+GD TC cavg2(const TC& a, const TC& b) {  // cAvg2, Glome.hs:199-205
+  return tc((a.r + b.r) * 0.5f, (a.g + b.g) * 0.5f, (a.b + b.b) * 0.5f, (a.a + b.a) * 0.5f, (a.d + b.d) * 0.5f);
+}
+// Pass p (1..5) touches tile-local pixel (dx, dy)?  Passes 1-2: the even lattice, split by (dx+dy) mod 4; pass 3: the
+// odd-odd lattice; pass 4: the remaining pixels; pass 5: every pixel (Glome.hs:241-319).
+GD bool ss_candidate(int p, int dx, int dy) {
+  switch (p) {
+    case 1: return !(dx & 1) && !(dy & 1) && ((dx + dy) & 3) == 0;
+    case 2: return !(dx & 1) && !(dy & 1) && ((dx + dy) & 3) == 2;
+    case 3: return (dx & 1) && (dy & 1);
+    case 4: return ((dx + dy) & 1) == 1;
+    default: return true;
+  }
+}
+// neighbour offsets (a, b, c, d) of pass p, in the reference's order (decide compares a-c and b-d, Glome.hs:213-219)
+GD void ss_neighbours(int p, int* ox, int* oy) {
+  switch (p) {
+    case 2: ox[0] = -2; oy[0] = 0; ox[1] = 0; oy[1] = 2; ox[2] = 2; oy[2] = 0; ox[3] = 0; oy[3] = -2; break;    // :255-258
+    case 3: ox[0] = -1; oy[0] = -1; ox[1] = 1; oy[1] = -1; ox[2] = 1; oy[2] = 1; ox[3] = -1; oy[3] = 1; break;  // :274-277
+    case 4: ox[0] = -1; oy[0] = 0; ox[1] = 0; oy[1] = 1; ox[2] = 1; oy[2] = 0; ox[3] = 0; oy[3] = -1; break;    // :287-290
+    default: ox[0] = 0; oy[0] = 0; ox[1] = 0; oy[1] = 1; ox[2] = 1; oy[2] = 1; ox[3] = 1; oy[3] = 0; break;     // pass 5, :303-306
+  }
+}
+// pass 5's write: the new sample blended with the pixel's neighbourhood; edge pixels use two-sample averages (:309-316)
+GD TC ss_pass5_blend(const TC& color, const TC& a, const TC& b, const TC& c, const TC& d, bool last_col, bool last_row) {
+  if (last_col) return last_row ? color : cavg2(color, cavg2(a, b));
+  return last_row ? cavg2(color, cavg2(a, d)) : cavg2(color, cavg4(a, b, c, d));
+}
+
 }  // namespace glome

@@ -106,6 +106,7 @@ struct DRenderArgs {
   int32_t ntiles;
   uint32_t total_waves;
   int32_t dense;       // 1: out5 is a dense tile payload (tile order, row major inside a tile) instead of a frame
+  float* scratch;      // adaptive sampler: dense per-tile working buffer `v` (owned pixels * 5 floats)
   float* out5;         // width*height*5
   uint32_t* packed;    // width*height or null
   DCounters* counters;

@@ -88,6 +88,22 @@ class HostSim:
         return out, cnt
 
 
+def _hs_render_subsample(self, cam, lights, width, height, maxdepth, blocksize=65, thresholds=(0.14, 0.15, 0.16, 0.18), tier=-1):
+    camv = np.array(list(cam.pos) + list(cam.fwd) + list(cam.up) + list(cam.right), np.float32)
+    lv = np.array([list(l.pos) + list(l.color) + [l.rad, float(l.shadow)] for l in lights], np.float32).reshape(-1, 8)
+    th = np.array(thresholds, np.float32)
+    out = np.zeros((height, width, 5), np.float32)
+    cnt = np.zeros(3, np.uint64)
+    rc = self.lib.hostsim_render_subsample(self.h, tier, camv.ctypes.data_as(c_fp), lv.ctypes.data_as(c_fp), len(lights), width, height, maxdepth, blocksize,
+                                           th.ctypes.data_as(c_fp), out.ctypes.data_as(c_fp), cnt.ctypes.data_as(C.POINTER(C.c_ulonglong)))
+    if rc != 0:
+        raise RuntimeError(f"hostsim_render_subsample rc={rc}")
+    return out, cnt
+
+
+HostSim.render_subsample = _hs_render_subsample
+
+
 def product_camera_lights(sd):
     """The glome_camera / glome_light structs the product gets for a SceneDesc (fp32 fields)."""
     from glome_amd import api

@@ -181,4 +181,65 @@ int hostsim_block_work(void* sv, const float* cam, const float* light_pos, int w
   }
   return 0;
 }
+
+// renderTileSubsample through the device headers' pass helpers (ss_candidate / ss_neighbours / ccmp / cavg / blend),
+// executed sequentially tile by tile.  Mirrors subsample_tile() in glome_device.hip.
+int hostsim_render_subsample(void* sv, int tier, const float* cam, const float* lights, int nl, int width, int height, int maxdepth, int blocksize,
+                             const float* thresholds, float* out5, unsigned long long* counters) {
+  SimScene* s = (SimScene*)sv;
+  if (tier < 0) tier = (int)s->D.tier;
+  if (tier == 0 && s->D.tier != 0) return -1;
+  DCamera C; memcpy(&C, cam, sizeof(C));
+  DLight L[kMaxLights];
+  for (int i = 0; i < nl; i++) { memcpy(L[i].pos, lights + 8 * i, 12); memcpy(L[i].color, lights + 8 * i + 3, 12); L[i].rad = lights[8 * i + 6]; L[i].shadow = lights[8 * i + 7] != 0; }
+  HostStack hs;
+  unsigned long long nprim = 0, nshadow = 0, nsec = 0;
+  unsigned int err = 0;
+  auto sample = [&](float xp, float yp) {
+    float xc, yc; get_coordsf(width, height, xp, yp, xc, yc);
+    Ray ray = primary_ray(C, xc, yc);
+    HitG h; CA c;
+    nprim++;
+    if (tier == 0) { HostFlatTier<false, false, true> T{s->D, L, nl, hs.lane(kFlatStack), Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, &h); nshadow += T.cnt.shadow; nsec += T.cnt.secondary; }
+    else { HostGenericTier T{s->D, L, nl, Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, &h); err |= T.err; nshadow += T.cnt.shadow; nsec += T.cnt.secondary; }
+    return tc(c.r, c.g, c.b, c.a, h.hit ? h.t : kInf);
+  };
+  for (int xt = 0; xt < width;) {
+    int tw = (xt + blocksize >= width) ? width - xt : blocksize;
+    for (int yt = 0; yt < height;) {
+      int th = (yt + blocksize >= height) ? height - yt : blocksize;
+      std::vector<TC> v((size_t)tw * th, tc_blank());
+      auto getc = [&](int dx, int dy) { return (dx >= 0 && dx < tw && dy >= 0 && dy < th) ? v[(size_t)dy * tw + dx] : tc_blank(); };
+      for (int pass = 1; pass <= 5; pass++) {
+        float thr = pass >= 2 ? thresholds[pass - 2] : 0.0f;
+        int ox[4], oy[4];
+        ss_neighbours(pass, ox, oy);
+        std::vector<TC> nv = v;  // passes never read what they write, so a copy is equivalent and keeps this mirror simple
+        for (int i = 0; i < tw * th; i++) {
+          int dx = i % tw, dy = i / tw;
+          if (!ss_candidate(pass, dx, dy)) continue;
+          TC a = tc_blank(), b = a, c = a, d = a, col;
+          bool need = true;
+          if (pass >= 2) {
+            a = getc(dx + ox[0], dy + oy[0]); b = getc(dx + ox[1], dy + oy[1]); c = getc(dx + ox[2], dy + oy[2]); d = getc(dx + ox[3], dy + oy[3]);
+            need = gmaxf(ccmp(a, c), ccmp(b, d)) > thr;
+          }
+          float off = pass == 5 ? 0.5f : 0.0f;
+          col = need ? sample((float)(xt + dx) + off, (float)(yt + dy) + off) : cavg4(a, b, c, d);
+          if (pass < 5) nv[i] = col;
+          else {
+            TC o = ss_pass5_blend(col, a, b, c, d, dx == tw - 1, dy == th - 1);
+            float* q = out5 + ((size_t)(yt + dy) * width + (xt + dx)) * 5;
+            q[0] = o.r; q[1] = o.g; q[2] = o.b; q[3] = o.a; q[4] = o.d;
+          }
+        }
+        v.swap(nv);
+      }
+      yt += th;
+    }
+    xt += tw;
+  }
+  if (counters) { counters[0] = nprim; counters[1] = nshadow; counters[2] = nsec; }
+  return err ? -2 : 0;
+}
 }

@@ -62,3 +62,16 @@ def check_image(img, counts, sd, w, h, maxdepth):
     for got, want in ((counts[1], rc["rays_shadow"]), (counts[2], rc["rays_secondary"])):
         assert abs(int(got) - int(want)) <= max(8, int(want) // 200), (counts, rc)  # a flipped silhouette pixel adds / drops a few rays
     return c
+
+
+def check_subsample_image(img, counts, sd, w, h, maxdepth):
+    """Adaptive mode (renderTileSubsample): pixels are averages / blends of traced samples, and whether a pixel is traced is
+    a threshold test on neighbour contrast, so an fp32 contrast a hair from the threshold can flip one decision.  Bound
+    the outlier fraction and require the sample counts to agree closely."""
+    o, om, _ = oracle_for(sd)
+    ref, _, rc = o.render(w, h, mode=1, maxdepth=maxdepth, want_packed=False)
+    c = compare_images(img, ref)
+    assert c["frac_over"] <= 0.01, c
+    assert c["mean"] <= 5e-4, c
+    assert abs(int(counts[0]) - rc["rays_primary"]) <= max(8, rc["rays_primary"] // 500), (counts, rc)
+    return c, rc

@@ -151,6 +151,42 @@ def test_full_size_csg_generic_tier_vs_oracle_tile_sample(gpu_ctx):
     sc.release()
 
 
+@pytest.mark.parametrize("name,w,h", [("S1", 720, 480), ("S3small", 131, 66), ("materials", 200, 150), ("S4", 260, 195), ("mesh", 130, 65)])
+def test_adaptive_sampler_vs_oracle(gpu_ctx, name, w, h):
+    """GLOME_MODE_SUBSAMPLE = renderTileSubsample (Glome.hs:226-323), incl. S1 at BASELINE configs[0..1]'s 720x480."""
+    sd = SCENES[name]()
+    b, nm, sc = commit(gpu_ctx, sd)
+    cam, lights = product_camera_lights(sd)
+    img, packed, st = sc.render(cam, lights, api.render_params(width=w, height=h, mode=1, maxdepth=3))
+    c, rc = parity.check_subsample_image(img, (st["rays_primary"], st["rays_shadow"], st["rays_secondary"]), sd, w, h, 3)
+    assert w * h / 8 <= st["rays_primary"] <= 2 * w * h
+    img2, packed2, _ = sc.render(cam, lights, api.render_params(width=w, height=h, mode=1, maxdepth=3))
+    assert np.array_equal(img, img2) and np.array_equal(packed, packed2)  # deterministic
+    sc.release()
+
+
+def test_adaptive_sampler_tile_shards_reassemble_bit_exactly(gpu_ctx):
+    """The adaptive result depends on tile origin (Q21), so sharding must use whole reference tiles: 3 shards == whole."""
+    import torch
+    sd = scenes.s1(nlights=1)
+    b, nm, sc = commit(gpu_ctx, sd)
+    cam, lights = product_camera_lights(sd)
+    dev = torch.device("cuda:0")
+    P = api.render_params(width=720, height=480, mode=1, maxdepth=1)
+    whole = torch.zeros((480, 720, 5), dtype=torch.float32, device=dev)
+    sc.render_dev(cam, lights, P, whole.data_ptr())
+    frame = torch.full((480, 720, 5), float("nan"), dtype=torch.float32, device=dev)
+    la = (L.Light * len(lights))(*lights)
+    for r in range(3):
+        plan = dist.ShardPlan(P, r, 3)
+        payload = torch.zeros(plan.maxp, dtype=torch.float32, device=dev)
+        assert sc.lib.glome_render_tiles_dev(sc.h, C.byref(cam), la, len(lights), C.byref(plan.P_local), C.c_void_p(payload.data_ptr()), None) == 0
+        assert sc.lib.glome_tiles_blit_dev(gpu_ctx.h, C.byref(plan.P), r, 3, C.c_void_p(payload.data_ptr()), C.c_void_p(frame.data_ptr()), None) == 0
+        gpu_ctx.synchronize()  # the context runs on its own stream: finish before torch recycles `payload`
+    assert torch.equal(frame, whole)
+    sc.release()
+
+
 # ------------------------------------------------------------------ edge cases
 def test_edge_cases(gpu_ctx):
     b = api.Builder()
@@ -182,6 +218,9 @@ def test_edge_cases(gpu_ctx):
         sc.render(cam, [api.light((0, 1, 0), (1, 1, 1))] * 9, api.render_params(width=16, height=16))
     with pytest.raises(api.GlomeError):
         sc.render(cam, [], api.render_params(width=16, height=16, mode=7))
+    for (w, h) in [(1, 1), (7, 5), (65, 65), (66, 131)]:  # adaptive mode on tiny / ragged frames
+        img, _, st = sc.render(cam, [], api.render_params(width=w, height=h, mode=1, maxdepth=1), want_packed=False)
+        assert np.isfinite(img).all() and st["n_pixels"] == w * h
     sc.release()
     with pytest.raises(api.GlomeError, match="nests composites deeper"):
         n = b.sphere((0, 0, 0), 1)

@@ -104,3 +104,14 @@ def test_quirks_survive_flattening(built):
     me = b.mesh([[0, 0, 0], [1, 0, 0], [0, 1, 0]], [], [[0, 1, 2, -1, -1, -1, -1, -1]], [])
     hs = HostSim(b, me)
     assert hs.rayint([[.25, .25, -1]], [[0, 0, 1]])["t"][0] == pytest.approx(1) and not hs.shadow([[.25, .25, -1]], [[0, 0, 1]], 5.0)[0]
+
+
+@pytest.mark.parametrize("name,w,h", [("S1", 200, 150), ("S3small", 131, 66), ("materials", 160, 90), ("S4", 130, 130)])
+def test_adaptive_sampler(built, name, w, h):
+    """renderTileSubsample (Glome.hs:226-323): ragged tiles (200 = 3*65 + 5), 5 passes, sub-pixel pass-5 samples."""
+    sd, b, nm, hs = load(name)
+    cam, lights = product_camera_lights(sd)
+    img, cnt = hs.render_subsample(cam, lights, w, h, 3)
+    c, rc = parity.check_subsample_image(img, [int(x) for x in cnt], sd, w, h, 3)
+    # the sampler traces between 1/8 and 2 primary rays per pixel (README.md:20)
+    assert w * h / 8 <= int(cnt[0]) <= 2 * w * h
