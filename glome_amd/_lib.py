@@ -52,6 +52,7 @@ SYMBOLS = [
     ("glome_ctx_stream", vp, [vp]),
     ("glome_ctx_synchronize", C.c_int, [vp]),
     ("glome_ctx_use_stream", C.c_int, [vp, vp]),
+    ("glome_ctx_use_slot", C.c_int, [vp, vp, C.c_int]),
     ("glome_ctx_timing_begin", C.c_int, [vp, C.c_int]),
     ("glome_ctx_timing_end", C.c_int, [vp, c_fp, C.c_int]),
     ("glome_ctx_device_info", C.c_int, [vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -111,6 +112,7 @@ SYMBOLS = [
     ("glome_tiles_layout", C.c_int, [C.POINTER(RenderParams), C.c_int, C.c_int, c_ip, C.c_int]),
     ("glome_tiles_pack_dev", C.c_int, [vp, C.POINTER(RenderParams), vp, vp]),
     ("glome_tiles_blit_dev", C.c_int, [vp, C.POINTER(RenderParams), C.c_int, C.c_int, vp, vp, vp]),
+    ("glome_tiles_blit_all_dev", C.c_int, [vp, C.POINTER(RenderParams), C.c_int, vp, C.c_int64, vp, vp]),
 ]
 
 _lib = None

@@ -360,11 +360,19 @@ struct glome_ctx {
   bool timing = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipDeviceProp_t prop;
-  DCounters* d_counters = nullptr;
-  uint32_t* d_ovf = nullptr;  // traversal-stack overflow workspace (grown on demand)
-  size_t ovf_bytes = 0;
-  float* d_scratch = nullptr;  // adaptive sampler working buffer
-  size_t scratch_bytes = 0;
+  // Per-slot launch state, so several frames can be in flight on different streams (their work queues, counters and
+  // workspaces must not be shared): slot 0 is the default.
+  struct Slot {
+    DCounters* d_counters = nullptr;
+    uint32_t* d_ovf = nullptr;   // traversal-stack overflow workspace (grown on demand)
+    size_t ovf_bytes = 0;
+    float* d_scratch = nullptr;  // adaptive sampler working buffer
+    size_t scratch_bytes = 0;
+  };
+  static constexpr int kSlots = 4;
+  Slot slots[kSlots];
+  int cur = 0;
+  Slot& slot() { return slots[cur]; }
   std::string err;
   // tile tables cached per (w, h, blocksize, first, stride)
   struct TileTable { std::vector<DTile> host; DTile* dev = nullptr; uint32_t total_waves = 0; int64_t pixels = 0; };
@@ -445,16 +453,19 @@ glome_ctx* glome_ctx_create(int device_ordinal) {
   c->own_stream = c->stream;
   if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return fail("hipEventCreate", e);
   if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return fail("hipEventCreate", e);
-  if ((e = hipMalloc((void**)&c->d_counters, sizeof(DCounters))) != hipSuccess) return fail("hipMalloc", e);
+  for (int k = 0; k < glome_ctx::kSlots; k++)
+    if ((e = hipMalloc((void**)&c->slots[k].d_counters, sizeof(DCounters))) != hipSuccess) return fail("hipMalloc", e);
   return c;
 }
 void glome_ctx_destroy(glome_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   for (auto& kv : c->tile_cache) if (kv.second.dev) (void)hipFree(kv.second.dev);
-  if (c->d_counters) (void)hipFree(c->d_counters);
-  if (c->d_ovf) (void)hipFree(c->d_ovf);
-  if (c->d_scratch) (void)hipFree(c->d_scratch);
+  for (auto& sl : c->slots) {
+    if (sl.d_counters) (void)hipFree(sl.d_counters);
+    if (sl.d_ovf) (void)hipFree(sl.d_ovf);
+    if (sl.d_scratch) (void)hipFree(sl.d_scratch);
+  }
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   for (hipEvent_t ev : c->pool) (void)hipEventDestroy(ev);
@@ -466,6 +477,12 @@ void* glome_ctx_stream(glome_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int glome_ctx_use_stream(glome_ctx* c, void* stream) {
   if (!c) return GLOME_E_INVALID;
   c->stream = stream ? (hipStream_t)stream : c->own_stream;
+  return 0;
+}
+int glome_ctx_use_slot(glome_ctx* c, void* stream, int slot) {
+  if (!c || slot < 0 || slot >= glome_ctx::kSlots) return GLOME_E_INVALID;
+  c->stream = stream ? (hipStream_t)stream : c->own_stream;
+  c->cur = slot;
   return 0;
 }
 int glome_ctx_timing_begin(glome_ctx* c, int max_launches) {
@@ -579,22 +596,24 @@ static int persistent_grid(glome_ctx* ctx, size_t lds_per_block, uint32_t total_
 }
 static int ensure_overflow(glome_ctx* ctx, int grid, int waves_per_block, int ovf_cap) {
   size_t need = (size_t)grid * waves_per_block * ovf_cap * 3 * 64 * sizeof(uint32_t);
-  if (need <= ctx->ovf_bytes) return 0;
-  if (ctx->d_ovf) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->d_ovf)); ctx->d_ovf = nullptr; ctx->ovf_bytes = 0; }
-  HIPCHK(ctx, hipMalloc((void**)&ctx->d_ovf, need));
-  ctx->ovf_bytes = need;
+  glome_ctx::Slot& sl = ctx->slot();
+  if (need <= sl.ovf_bytes) return 0;
+  if (sl.d_ovf) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(sl.d_ovf)); sl.d_ovf = nullptr; sl.ovf_bytes = 0; }
+  HIPCHK(ctx, hipMalloc((void**)&sl.d_ovf, need));
+  sl.ovf_bytes = need;
   return 0;
 }
 static int ensure_scratch(glome_ctx* ctx, size_t need) {
-  if (need <= ctx->scratch_bytes) return 0;
-  if (ctx->d_scratch) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->d_scratch)); ctx->d_scratch = nullptr; ctx->scratch_bytes = 0; }
-  HIPCHK(ctx, hipMalloc((void**)&ctx->d_scratch, need));
-  ctx->scratch_bytes = need;
+  glome_ctx::Slot& sl = ctx->slot();
+  if (need <= sl.scratch_bytes) return 0;
+  if (sl.d_scratch) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(sl.d_scratch)); sl.d_scratch = nullptr; sl.scratch_bytes = 0; }
+  HIPCHK(ctx, hipMalloc((void**)&sl.d_scratch, need));
+  sl.scratch_bytes = need;
   return 0;
 }
 static int check_device_error(glome_ctx* ctx) {
   DCounters c;
-  HIPCHK(ctx, hipMemcpy(&c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipMemcpy(&c, ctx->slot().d_counters, sizeof(c), hipMemcpyDeviceToHost));
   if (c.error) { ctx->err = "device-side limit hit (traversal stack or CSG advance cap)"; return GLOME_E_LIMIT; }
   return 0;
 }
@@ -610,7 +629,7 @@ static void launch_render(glome_scene* s, const DRenderArgs& A, const glome_rend
     int m = s->cls_mask;
     int cls = (m & ~CLS_BIH_TRI) == 0 ? CLS_BIH_TRI : ((m & ~(CLS_BIH_SPHERE | CLS_PRIMS)) == 0 ? (CLS_BIH_SPHERE | CLS_PRIMS) : ((m & ~CLS_MESH) == 0 ? CLS_MESH : CLS_ALL));
     int lb = getenv("GLOME_DEBUG_LB") ? atoi(getenv("GLOME_DEBUG_LB")) : 0;
-#define GLOME_LAUNCH(F, C, U, K, B) hipLaunchKernelGGL((k_render_flat<F, C, U, K, B>), g, blk, lds, st, A, s->stack_cap, s->ovf_cap ? s->ctx->d_ovf : nullptr, s->ovf_cap)
+#define GLOME_LAUNCH(F, C, U, K, B) hipLaunchKernelGGL((k_render_flat<F, C, U, K, B>), g, blk, lds, st, A, s->stack_cap, s->ovf_cap ? s->ctx->slot().d_ovf : nullptr, s->ovf_cap)
 #define GLOME_BY_CLS(F, C, U)                                                   \
     do {                                                                          \
       if (cls == CLS_BIH_TRI) GLOME_LAUNCH(F, C, U, CLS_BIH_TRI, 1);              \
@@ -658,12 +677,12 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
   A.nlights = nlights; A.width = P->width; A.height = P->height; A.fog = P->fog; A.maxdepth = P->maxdepth;
   memcpy(A.thresholds, P->thresholds, 16);
   A.tiles = tt->dev; A.ntiles = (int)tt->host.size(); A.total_waves = tt->total_waves;
-  A.out5 = rgbad_dev; A.packed = dense ? nullptr : packed_dev; A.counters = ctx->d_counters; A.dense = dense;
-  HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(DCounters), ctx->stream));
+  A.out5 = rgbad_dev; A.packed = dense ? nullptr : packed_dev; A.counters = ctx->slot().d_counters; A.dense = dense;
+  HIPCHK(ctx, hipMemsetAsync(ctx->slot().d_counters, 0, sizeof(DCounters), ctx->stream));
   hipEvent_t ev_start = ctx->ev0, ev_stop = ctx->ev1;
   if (A.ntiles > 0 && P->mode == GLOME_MODE_SUBSAMPLE) {
     if ((rc = ensure_scratch(ctx, (size_t)tt->pixels * 5 * sizeof(float)))) return rc;
-    A.scratch = ctx->d_scratch;
+    A.scratch = ctx->slot().d_scratch;
     int grid = std::min(A.ntiles, ctx->prop.multiProcessorCount * 4);
     bool pooled = ctx->timing && ctx->pool_used + 2 <= (int)ctx->pool.size();
     hipEvent_t e0 = pooled ? ctx->pool[ctx->pool_used] : ctx->ev0, e1 = pooled ? ctx->pool[ctx->pool_used + 1] : ctx->ev1;
@@ -674,7 +693,7 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
       size_t lds = flat_lds_bytes(s->stack_cap) * (kSSThreads / 64) + (65 * 65 + 4) * sizeof(uint32_t);
       if (s->ovf_cap && (rc = ensure_overflow(ctx, grid, kSSThreads / 64, s->ovf_cap))) return rc;
       bool full = s->has_nested_mats || (s->has_secondary_mats && P->maxdepth > 1);
-      uint32_t* ov = s->ovf_cap ? ctx->d_ovf : nullptr;
+      uint32_t* ov = s->ovf_cap ? ctx->slot().d_ovf : nullptr;
       int m = s->cls_mask;
       bool tri = (m & ~CLS_BIH_TRI) == 0;
       dim3 g(grid), blk(kSSThreads);
@@ -704,7 +723,7 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
     memset(stats, 0, sizeof(*stats));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     DCounters c;
-    HIPCHK(ctx, hipMemcpy(&c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(&c, ctx->slot().d_counters, sizeof(c), hipMemcpyDeviceToHost));
     stats->rays_primary = c.rays_primary; stats->rays_shadow = c.rays_shadow; stats->rays_secondary = c.rays_secondary;
     stats->bih_nodes = c.bih_nodes; stats->mesh_nodes = c.mesh_nodes; stats->prim_tests = c.prim_tests;
     if (A.ntiles > 0) HIPCHK(ctx, hipEventElapsedTime(&stats->kernel_ms, ev_start, ev_stop));
@@ -768,10 +787,10 @@ int glome_rayint_batch_dev(glome_scene* s, size_t n, const float* ox, const floa
     size_t lds = flat_lds_bytes(s->stack_cap);
     int grid = batch_grid(ctx, n, lds), rc;
     if (s->ovf_cap && (rc = ensure_overflow(ctx, grid, 1, s->ovf_cap))) return rc;
-    hipLaunchKernelGGL((k_rayint_batch_flat<false>), dim3(grid), dim3(64), lds, ctx->stream, s->dev, n, R, H, s->stack_cap, s->ovf_cap ? ctx->d_ovf : nullptr, s->ovf_cap);
+    hipLaunchKernelGGL((k_rayint_batch_flat<false>), dim3(grid), dim3(64), lds, ctx->stream, s->dev, n, R, H, s->stack_cap, s->ovf_cap ? ctx->slot().d_ovf : nullptr, s->ovf_cap);
   } else {
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(DCounters), ctx->stream));
-    hipLaunchKernelGGL(k_rayint_batch_generic, dim3(batch_grid(ctx, n, 0)), dim3(64), 0, ctx->stream, s->dev, n, R, H, ctx->d_counters);
+    HIPCHK(ctx, hipMemsetAsync(ctx->slot().d_counters, 0, sizeof(DCounters), ctx->stream));
+    hipLaunchKernelGGL(k_rayint_batch_generic, dim3(batch_grid(ctx, n, 0)), dim3(64), 0, ctx->stream, s->dev, n, R, H, ctx->slot().d_counters);
   }
   HIPCHK(ctx, hipGetLastError());
   return 0;
@@ -788,10 +807,10 @@ int glome_shadow_batch_dev(glome_scene* s, size_t n, const float* ox, const floa
     size_t lds = flat_lds_bytes(s->stack_cap);
     int grid = batch_grid(ctx, n, lds), rc;
     if (s->ovf_cap && (rc = ensure_overflow(ctx, grid, 1, s->ovf_cap))) return rc;
-    hipLaunchKernelGGL(k_shadow_batch_flat, dim3(grid), dim3(64), lds, ctx->stream, s->dev, n, R, occluded, s->stack_cap, s->ovf_cap ? ctx->d_ovf : nullptr, s->ovf_cap);
+    hipLaunchKernelGGL(k_shadow_batch_flat, dim3(grid), dim3(64), lds, ctx->stream, s->dev, n, R, occluded, s->stack_cap, s->ovf_cap ? ctx->slot().d_ovf : nullptr, s->ovf_cap);
   } else {
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(DCounters), ctx->stream));
-    hipLaunchKernelGGL(k_shadow_batch_generic, dim3(batch_grid(ctx, n, 0)), dim3(64), 0, ctx->stream, s->dev, n, R, occluded, ctx->d_counters);
+    HIPCHK(ctx, hipMemsetAsync(ctx->slot().d_counters, 0, sizeof(DCounters), ctx->stream));
+    hipLaunchKernelGGL(k_shadow_batch_generic, dim3(batch_grid(ctx, n, 0)), dim3(64), 0, ctx->stream, s->dev, n, R, occluded, ctx->slot().d_counters);
   }
   HIPCHK(ctx, hipGetLastError());
   return 0;
@@ -868,8 +887,8 @@ int glome_inside_batch(glome_scene* s, size_t n, const float* px, const float* p
   float *dx = st.in(px, n), *dy = st.in(py, n), *dz = st.in(pz, n);
   uint8_t* din = st.in<uint8_t>(nullptr, n);
   if (!dx || !dy || !dz || !din) { ctx->err = "staging allocation failed"; return GLOME_E_HIP; }
-  HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(DCounters), ctx->stream));
-  hipLaunchKernelGGL(k_inside_batch, dim3(batch_grid(ctx, n, 0)), dim3(64), 0, ctx->stream, s->dev, n, dx, dy, dz, din, ctx->d_counters);
+  HIPCHK(ctx, hipMemsetAsync(ctx->slot().d_counters, 0, sizeof(DCounters), ctx->stream));
+  hipLaunchKernelGGL(k_inside_batch, dim3(batch_grid(ctx, n, 0)), dim3(64), 0, ctx->stream, s->dev, n, dx, dy, dz, din, ctx->slot().d_counters);
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   int rc = check_device_error(ctx);
@@ -894,6 +913,36 @@ int glome_tiles_pack_dev(glome_ctx* ctx, const glome_render_params* P, const flo
   if ((rc = get_tiles(ctx, P, P->tile_first, P->tile_stride, &tt))) return rc;
   if (tt->host.empty()) return 0;
   hipLaunchKernelGGL(k_tiles_pack, dim3(21, std::min<int>((int)tt->host.size(), 1024)), dim3(256), 0, ctx->stream, tt->dev, (int)tt->host.size(), P->width, rgbad_dev, payload_dev);
+  HIPCHK(ctx, hipGetLastError());
+  return 0;
+}
+int glome_tiles_blit_all_dev(glome_ctx* ctx, const glome_render_params* P, int world, const float* gathered_dev, int64_t stride_floats,
+                             float* rgbad_dev, uint32_t* packed_dev) {
+  if (!ctx) return GLOME_E_INVALID;
+  int rc = check_params(ctx, P);
+  if (rc) return rc;
+  if (world <= 0 || stride_floats < 0 || stride_floats % 5 != 0) { ctx->err = "bad world / stride"; return GLOME_E_INVALID; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  // one table over every tile of the frame; pix_base = owner rank's slab offset + the tile's offset inside that rank's payload
+  std::vector<int> key{P->width, P->height, P->blocksize, -world, (int)(stride_floats / 5)};
+  auto it = ctx->tile_cache.find(key);
+  if (it == ctx->tile_cache.end()) {
+    glome_ctx::TileTable tt;
+    for (int r = 0; r < world; r++) {
+      std::vector<DTile> t; uint32_t w; int64_t px;
+      owned_tiles(P->width, P->height, P->blocksize, r, world, t, w, px);
+      if ((int64_t)r * (stride_floats / 5) + px > 0xffffffffll) { ctx->err = "gathered payload too large"; return GLOME_E_LIMIT; }
+      for (DTile& d : t) { d.pix_base += (uint32_t)(r * (stride_floats / 5)); tt.host.push_back(d); }
+      tt.pixels += px;
+    }
+    size_t bytes = std::max<size_t>(1, tt.host.size()) * sizeof(DTile);
+    HIPCHK(ctx, hipMalloc((void**)&tt.dev, bytes));
+    if (!tt.host.empty()) HIPCHK(ctx, hipMemcpy(tt.dev, tt.host.data(), tt.host.size() * sizeof(DTile), hipMemcpyHostToDevice));
+    it = ctx->tile_cache.emplace(key, std::move(tt)).first;
+  }
+  glome_ctx::TileTable* tt = &it->second;
+  if (tt->host.empty()) return 0;
+  hipLaunchKernelGGL(k_tiles_blit, dim3(17, std::min<int>((int)tt->host.size(), 1024)), dim3(256), 0, ctx->stream, tt->dev, (int)tt->host.size(), P->width, gathered_dev, rgbad_dev, packed_dev);
   HIPCHK(ctx, hipGetLastError());
   return 0;
 }

@@ -64,45 +64,133 @@ class ShardPlan:
     def layout(self, r):
         return owned_layout(self.P, r, self.world)
 
-    def gather(self, payload, gathered):
-        """The path's only collective: every rank's (padded) tile payload -> rank 0."""
+    def gather(self, payload, gathered, async_op=False):
+        """The path's only collective: every rank's (padded) tile payload -> rank 0.  `gathered` (rank 0) is one
+        [world, maxp] tensor; returns the work handle when async_op."""
         import torch.distributed as dist
-        dist.gather(payload, gathered if self.rank == 0 else None, dst=0)
+        return dist.gather(payload, list(gathered.unbind(0)) if self.rank == 0 else None, dst=0, async_op=async_op)
+
+
+class FramePipeline:
+    """Frames are independent, so several are kept in flight:
+
+        step k:   on lane k % n:  render(k) -> payload[k % n] ; start gather(k) (asynchronous)
+                  then finish frame k-1 on its own lane (wait its gather, blit it)
+
+    Each lane is a (HIP stream, context slot) pair: the render kernel of frame k+1 starts filling the GPU while the tail
+    of frame k's persistent kernel drains, and the collective of frame k (on the backend's own stream) runs under the
+    render of frame k+1.  `flush()` completes the frames still in flight.  render(slot, payload) and blit(slot, gathered)
+    are callables and `lane(slot)` a context manager, so the same control flow is exercised on CPU tensors with gloo
+    (tests/test_dist_gloo.py)."""
+
+    def __init__(self, plan, payloads, gathereds, render, blit, lane=None):
+        import contextlib
+        self.plan, self.payloads, self.gathereds, self.render, self.blit = plan, payloads, gathereds, render, blit
+        self.lane = lane if lane is not None else (lambda slot: contextlib.nullcontext())
+        self.n = len(payloads)
+        self.k = 0
+        self.pending = []
+        self.done = 0
+
+    def step(self):
+        slot = self.k % self.n
+        with self.lane(slot):
+            self.render(slot, self.payloads[slot])
+            work = self.plan.gather(self.payloads[slot], self.gathereds[slot] if self.plan.rank == 0 else None, async_op=True)
+        self.pending.append((slot, work))
+        self.k += 1
+        while len(self.pending) > self.n - 1 or len(self.pending) > 1:
+            self._finish(self.pending.pop(0))
+
+    def _finish(self, pending):
+        slot, work = pending
+        with self.lane(slot):
+            work.wait()  # RCCL: this lane's stream waits for the collective; gloo: the host does
+            if self.plan.rank == 0:
+                self.blit(slot, self.gathereds[slot])
+        self.done += 1
+
+    def flush(self):
+        while self.pending:
+            self._finish(self.pending.pop(0))
 
 
 class ShardedFrame:
-    """Renders one frame per step() over all ranks of the default process group; the frame lands on rank 0."""
+    """Renders one frame per step() over all ranks of the default process group; frames land on rank 0.
+    Up to `lanes` frames are in flight (each on its own HIP stream and context slot): call flush() before reading
+    `frame` (the most recently completed one on rank 0)."""
 
-    def __init__(self, scene, params, rank, world, device):
+    def __init__(self, scene, params, rank, world, device, lanes=4):
         import torch
         self.torch = torch
         self.scene, self.ctx, self.lib = scene, scene.ctx, scene.lib
         self.plan = ShardPlan(params, rank, world)
-        self.rank, self.world = rank, world
+        self.rank, self.world, self.device = rank, world, device
         self.P, self.P_local = self.plan.P, self.plan.P_local
         h, w = params.height, params.width
-        self.frame = torch.zeros((h, w, 5), dtype=torch.float32, device=device) if rank == 0 else None
+        self.n = max(1, min(int(lanes), 4))
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(self.n)]
+        self.frames = [torch.zeros((h, w, 5), dtype=torch.float32, device=device) for _ in range(self.n)] if rank == 0 else None
+        self.last = 0
+        self.k = 0
+        self.cam = self.lights = self.la = None
         if world > 1:
-            self.payload = torch.zeros(self.plan.maxp, dtype=torch.float32, device=device)
-            self.gathered = [torch.zeros(self.plan.maxp, dtype=torch.float32, device=device) for _ in range(world)] if rank == 0 else None
-        # run on torch's current stream: kernels, the collective and the blit are ordered without host syncs
-        self.lib.glome_ctx_use_stream(self.ctx.h, C.c_void_p(torch.cuda.current_stream(device).cuda_stream))
+            payloads = [torch.zeros(self.plan.maxp, dtype=torch.float32, device=device) for _ in range(self.n)]
+            gathereds = [torch.zeros((world, self.plan.maxp), dtype=torch.float32, device=device) if rank == 0 else None for _ in range(self.n)]
+            self.pipe = FramePipeline(self.plan, payloads, gathereds, self._render, self._blit, self._lane)
+        torch.cuda.synchronize(device)
 
-    def step(self, cam, lights, stats=False):
-        """One frame.  Returns the per-rank stats dict when stats=True (that synchronises)."""
-        if self.world == 1:
-            return self.scene.render_dev(cam, lights, self.P, self.frame.data_ptr(), None, want_stats=stats)
-        la = (L.Light * max(1, len(lights)))(*lights)
-        st = L.Stats()
-        rc = self.lib.glome_render_tiles_dev(self.scene.h, C.byref(cam), la, len(lights), C.byref(self.P_local),
-                                             C.c_void_p(self.payload.data_ptr()), C.byref(st) if stats else None)
+    @property
+    def frame(self):
+        return self.frames[self.last] if self.frames is not None else None
+
+    def _lane(self, slot):
+        s = self.streams[slot]
+        self.lib.glome_ctx_use_slot(self.ctx.h, C.c_void_p(s.cuda_stream), slot)
+        return self.torch.cuda.stream(s)
+
+    def _render(self, slot, payload, stats=None):
+        rc = self.lib.glome_render_tiles_dev(self.scene.h, C.byref(self.cam), self.la, len(self.lights), C.byref(self.P_local),
+                                             C.c_void_p(payload.data_ptr()), C.byref(stats) if stats is not None else None)
         if rc != 0:
             raise api.GlomeError("glome_render_tiles_dev: " + self.ctx.err())
-        self.plan.gather(self.payload, self.gathered)  # tile payloads -> rank 0 (RCCL over xGMI)
-        if self.rank == 0:
-            for r in range(self.world):
-                rc = self.lib.glome_tiles_blit_dev(self.ctx.h, C.byref(self.P), r, self.world, C.c_void_p(self.gathered[r].data_ptr()),
-                                                   C.c_void_p(self.frame.data_ptr()), None)
-                if rc != 0:
-                    raise api.GlomeError("glome_tiles_blit_dev: " + self.ctx.err())
-        return api._stats_dict(st) if stats else None
+
+    def _blit(self, slot, gathered):
+        rc = self.lib.glome_tiles_blit_all_dev(self.ctx.h, C.byref(self.P), self.world, C.c_void_p(gathered.data_ptr()), self.plan.maxp,
+                                               C.c_void_p(self.frames[slot].data_ptr()), None)
+        if rc != 0:
+            raise api.GlomeError("glome_tiles_blit_all_dev: " + self.ctx.err())
+        self.last = slot
+
+    def set_view(self, cam, lights):
+        self.cam, self.lights = cam, lights
+        self.la = (L.Light * max(1, len(lights)))(*lights)
+
+    def step(self, cam, lights, stats=False):
+        """One frame.  stats=True renders it alone (no overlap) and returns this rank's stats dict (it synchronises)."""
+        if cam is not self.cam or lights is not self.lights:
+            self.set_view(cam, lights)
+        if stats:
+            self.flush()
+            self.torch.cuda.synchronize(self.device)
+        if self.world == 1:
+            slot = self.k % self.n
+            self.k += 1
+            with self._lane(slot):
+                st = self.scene.render_dev(cam, lights, self.P, self.frames[slot].data_ptr(), None, want_stats=stats)
+            self.last = slot
+            return st
+        if stats:
+            st = L.Stats()
+            with self._lane(0):
+                self._render(0, self.pipe.payloads[0], st)
+                self.plan.gather(self.pipe.payloads[0], self.pipe.gathereds[0] if self.rank == 0 else None)
+                if self.rank == 0:
+                    self._blit(0, self.pipe.gathereds[0])
+            return api._stats_dict(st)
+        self.pipe.step()
+        return None
+
+    def flush(self):
+        if self.world > 1:
+            self.pipe.flush()

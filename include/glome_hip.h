@@ -52,6 +52,9 @@ void* glome_ctx_stream(glome_ctx*);    /* the hipStream_t, for interop */
 int glome_ctx_synchronize(glome_ctx*);
 /* Run on an external HIP stream (e.g. torch's current stream) instead of the context's own; NULL restores it. */
 int glome_ctx_use_stream(glome_ctx*, void* hip_stream);
+/* Several frames in flight: a context has 4 launch slots, each with its own work queue, counters and workspaces.  Select
+ * (stream, slot) before a launch; launches that may overlap in time must use different slots (and streams). */
+int glome_ctx_use_slot(glome_ctx*, void* hip_stream, int slot);
 /* Per-launch kernel timing without extra synchronisation: between begin and end every render launch records its own
  * HIP-event pair on the context's stream; end synchronises once and returns the number of launches, writing their
  * durations (ms) to ms_out[0..cap). */
@@ -189,6 +192,10 @@ int glome_tiles_layout(const glome_render_params*, int tile_first, int tile_stri
 int glome_tiles_pack_dev(glome_ctx*, const glome_render_params*, const float* rgbad_dev, float* payload_dev);
 int glome_tiles_blit_dev(glome_ctx*, const glome_render_params*, int tile_first, int tile_stride,
                          const float* payload_dev, float* rgbad_dev, uint32_t* packed_dev);
+/* After the gather: `gathered_dev` holds `world` payload slabs of `stride_floats` floats each (rank r's payload at
+ * gathered_dev + r * stride_floats).  One launch blits every rank's tiles into the frame. */
+int glome_tiles_blit_all_dev(glome_ctx*, const glome_render_params*, int world, const float* gathered_dev, int64_t stride_floats,
+                             float* rgbad_dev, uint32_t* packed_dev);
 
 #ifdef __cplusplus
 }

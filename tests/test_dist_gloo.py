@@ -31,7 +31,7 @@ def _worker(rank, world, port, outdir):
     packed = dist.pack_numpy(mine, lay)
     assert packed.size == plan.sizes[rank]
     payload[:packed.size] = torch.from_numpy(packed)
-    gathered = [torch.zeros(plan.maxp, dtype=torch.float64) for _ in range(world)] if rank == 0 else None
+    gathered = torch.zeros((world, plan.maxp), dtype=torch.float64) if rank == 0 else None
     plan.gather(payload, gathered)
     rays = torch.tensor([cnt["rays_primary"], cnt["rays_shadow"]], dtype=torch.float64)
     tdist.all_reduce(rays)
@@ -41,6 +41,32 @@ def _worker(rank, world, port, outdir):
             dist.blit_numpy(frame, gathered[r].numpy(), plan.layout(r))
         np.save(os.path.join(outdir, "frame.npy"), frame)
         np.save(os.path.join(outdir, "rays.npy"), rays.numpy())
+    # the pipelined path (FramePipeline): 5 frames with different lights in flight two at a time
+    frames = []
+    state = {"k": 0}
+
+    def render(slot, payload_t):
+        k = state["k"]; state["k"] += 1
+        o.clear_lights()
+        o.add_light([-100 + 40 * k, 70, 140], [7000, 5600, 5600])
+        img, _, _ = o.render(W, H, maxdepth=1, tile_first=rank, tile_stride=world, want_packed=False)
+        pk = dist.pack_numpy(img, lay)
+        payload_t[:pk.size] = torch.from_numpy(pk)
+
+    def blit(slot, gathered_t):
+        f = np.full((H, W, 5), np.nan)
+        for r in range(world):
+            dist.blit_numpy(f, gathered_t[r].numpy(), plan.layout(r))
+        frames.append(f)
+
+    pipe = dist.FramePipeline(plan, [torch.zeros(plan.maxp, dtype=torch.float64) for _ in range(3)],
+                              [torch.zeros((world, plan.maxp), dtype=torch.float64) if rank == 0 else None for _ in range(3)], render, blit)
+    for _ in range(5):
+        pipe.step()
+    pipe.flush()
+    assert pipe.done == 5
+    if rank == 0:
+        np.save(os.path.join(outdir, "pipe_frames.npy"), np.stack(frames))
     tdist.barrier()
     tdist.destroy_process_group()
 
@@ -60,6 +86,13 @@ def test_two_rank_tile_sharding_reassembles_the_frame(built, tmp_path):
     assert not np.isnan(frame).any()          # every pixel is owned by exactly one rank
     assert np.array_equal(frame, whole)       # bit exact
     assert np.load(tmp_path / "rays.npy").tolist() == [cnt["rays_primary"], cnt["rays_shadow"]]
+    pf = np.load(tmp_path / "pipe_frames.npy")
+    assert pf.shape[0] == 5
+    for k in range(5):  # every pipelined frame equals its single-process render, in order
+        o.clear_lights()
+        o.add_light([-100 + 40 * k, 70, 140], [7000, 5600, 5600])
+        ref, _, _ = o.render(W, H, maxdepth=1, want_packed=False)
+        assert np.array_equal(pf[k], ref), k
 
 
 def test_shard_plan_partitions_tiles(built):

@@ -131,6 +131,15 @@ def test_full_size_tile_shards_reassemble_bit_exactly(gpu_ctx, s3_full, world):
         assert torch.equal(back[:plan.sizes[r]], payload[:plan.sizes[r]])
     gpu_ctx.synchronize()
     assert tot == 1920 * 1080 and torch.equal(frame, whole)
+    # the one-launch blit of all gathered slabs (what rank 0 runs after the gather)
+    plans = [dist.ShardPlan(P, r, world) for r in range(world)]
+    gathered = torch.zeros((world, plans[0].maxp), dtype=torch.float32, device=dev)
+    for r in range(world):
+        assert sc.lib.glome_render_tiles_dev(sc.h, C.byref(cam), la, len(lights), C.byref(plans[r].P_local), C.c_void_p(gathered[r].data_ptr()), None) == 0
+    frame2 = torch.full((1080, 1920, 5), float("nan"), dtype=torch.float32, device=dev)
+    assert sc.lib.glome_tiles_blit_all_dev(gpu_ctx.h, C.byref(P), world, C.c_void_p(gathered.data_ptr()), plans[0].maxp, C.c_void_p(frame2.data_ptr()), None) == 0
+    gpu_ctx.synchronize()
+    assert torch.equal(frame2, whole)
 
 
 def test_full_size_csg_generic_tier_vs_oracle_tile_sample(gpu_ctx):
