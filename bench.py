@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--scene", default="S3", help="S1 S2 S3 S3mesh S4 S5 (default: the headline workload S3)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--mode", type=int, default=0, help="0 = renderTile (1 ray/pixel), 1 = renderTileSubsample (adaptive)")
     ap.add_argument("--lanes", type=int, default=4, help="frames kept in flight per GPU (HIP streams / context slots)")
     args = ap.parse_args()
 
@@ -69,7 +70,7 @@ def main():
     info = scene.info()
     cam = api.camera(*sd.cam)
     lights = [api.light(p, c, r, s) for (p, c, r, s) in sd.lights]
-    P = api.render_params(width=W, height=H, maxdepth=maxdepth)
+    P = api.render_params(width=W, height=H, maxdepth=maxdepth, mode=args.mode)
 
     sf = dist.ShardedFrame(scene, P, rank, world, device, lanes=args.lanes)
 
@@ -174,7 +175,7 @@ def main():
         rates, cpu_rays, wall = [], 0, 0.0
         while len(rates) < 3 or wall < 3.0:
             tc = time.perf_counter()
-            _, _, oc = o.render(W, H, maxdepth=maxdepth, nthreads=cores, want_packed=False)
+            _, _, oc = o.render(W, H, mode=args.mode, maxdepth=maxdepth, nthreads=cores, want_packed=False)
             dt = time.perf_counter() - tc
             cpu_rays = oc["rays_primary"] + oc["rays_shadow"] + oc["rays_secondary"]
             rates.append(cpu_rays / dt / 1e6)
@@ -184,7 +185,7 @@ def main():
         rate = float(np.median(rates))
         # one thread (the reference's `+RTS -N1`) on every 8th tile
         tc = time.perf_counter()
-        _, _, o1 = o.render(W, H, maxdepth=maxdepth, tile_first=0, tile_stride=8, nthreads=1, want_packed=False)
+        _, _, o1 = o.render(W, H, mode=args.mode, maxdepth=maxdepth, tile_first=0, tile_stride=8, nthreads=1, want_packed=False)
         dt1 = time.perf_counter() - tc
         rate1 = (o1["rays_primary"] + o1["rays_shadow"] + o1["rays_secondary"]) / dt1 / 1e6
         cpu = {"value": round(rate, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
@@ -200,7 +201,7 @@ def main():
         "config": {"workload": f"{args.scene}: " + {"S3": "100,352-triangle heightfield under bih (BASELINE configs[2]), 1 light, primary + shadow rays, maxdepth 1",
                                                      "S3mesh": "100,352-triangle heightfield as mesh (2-box BVH)", "S5": "1,002,528-triangle heightfield under bih"}.get(args.scene, args.scene),
                    "width": W, "height": H, "rays_per_frame": {"primary": rays[0], "shadow": rays[1], "secondary": rays[2]},
-                   "sampling": "renderTile, 1 primary ray/pixel", "frames_in_flight": args.lanes, "tiles": "65x65 reference tiles, round-robin over ranks, one RCCL gather to rank 0 per frame, gather of frame k overlapped with render of frame k+1" if world > 1 else "65x65 reference tiles, one GPU",
+                   "sampling": "renderTile, 1 primary ray/pixel" if args.mode == 0 else "renderTileSubsample (adaptive, 1/8..2 primary rays/pixel)", "frames_in_flight": args.lanes, "tiles": "65x65 reference tiles, round-robin over ranks, one RCCL gather to rank 0 per frame, gather of frame k overlapped with render of frame k+1" if world > 1 else "65x65 reference tiles, one GPU",
                    "scene_setup_s": round(setup_s, 2), "device_bytes": info["device_bytes"]},
         "roofline": roofline, "cpu_baseline": cpu,
     }

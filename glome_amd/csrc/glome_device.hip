@@ -178,93 +178,120 @@ __global__ void __launch_bounds__(64) k_render_generic(DRenderArgs A) {
 
 
 // ------------------------------------------------------------------------------------------------ adaptive sampler
-// renderTileSubsample (Glome.hs:226-323): one workgroup per reference tile, five passes separated by workgroup barriers.
-// Inside a pass every thread first takes the cheap `decide` test (Glome.hs:213-219) for its candidate pixels and
-// appends the ones that need a fresh sample to a list in LDS; after a barrier the workgroup traces the compacted list,
-// so the expensive lanes are dense.  The working buffer `v` lives in a dense per-tile scratch in global memory (written
-// and read by the same workgroup only); `v2` is the output.
-constexpr int kSSThreads = 256;
-template <class TIER>
-__device__ __forceinline__ TC ss_sample(const DRenderArgs& A, TIER& T, float xpix, float ypix) {
-  float xc, yc;
-  get_coordsf(A.width, A.height, xpix, ypix, xc, yc);
-  Ray ray = primary_ray(A.cam, xc, yc);
-  T.cnt.primary++;
-  HitG h;
-  CA c = trace_primary(T, ray, kInf, A.maxdepth, &h);
-  return tc(c.r, c.g, c.b, c.a, h.hit ? h.t : kInf);
-}
+// renderTileSubsample (Glome.hs:226-323) as a wavefront.  The reference runs five passes over each 65x65 tile; a pass
+// looks at neighbour contrast (`decide`, Glome.hs:213-219) and either averages or traces a fresh sample.  Here every
+// pass is two launches over ALL owned tiles at once:
+//   k_ss_decide  one thread per owned pixel: candidates of the pass take the contrast test; the ones that settle for
+//                an average write it, the ones that need a sample are appended to a global list (wave-aggregated
+//                atomics, so neighbouring pixels stay neighbours in the list);
+//   k_ss_trace   persistent waves pull 64 list entries at a time and trace them: every lane has a ray.
+// The working buffer `v` is a dense per-tile array in global memory (tile order, row major inside a tile), so all
+// neighbour reads stay inside the tile like the reference's getc (Glome.hs:233-235); `v2` is the output.
 __device__ __forceinline__ TC ss_load(const float* v, size_t i) { const float* p = v + i * 5; return tc(p[0], p[1], p[2], p[3], p[4]); }
 __device__ __forceinline__ void ss_store(float* v, size_t i, const TC& c) { float* p = v + i * 5; p[0] = c.r; p[1] = c.g; p[2] = c.b; p[3] = c.a; p[4] = c.d; }
+__device__ __forceinline__ DTile ss_tile_of(const DRenderArgs& A, uint32_t dense) {  // owned tile holding dense pixel index
+  int lo = 0, hi = A.ntiles - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (A.tiles[mid].pix_base <= dense) lo = mid; else hi = mid - 1;
+  }
+  return A.tiles[lo];
+}
+__device__ __forceinline__ TC ss_getc(const float* v, const DTile& t, int dx, int dy) {  // getc: outside the tile reads blank
+  if (dx >= 0 && dx < t.w && dy >= 0 && dy < t.h) return ss_load(v, (size_t)t.pix_base + (size_t)dy * t.w + dx);
+  return tc_blank();
+}
+__device__ __forceinline__ size_t ss_out_index(const DRenderArgs& A, const DTile& t, int dx, int dy) {
+  return A.dense ? (size_t)t.pix_base + (size_t)dy * t.w + dx : (size_t)(t.y + dy) * A.width + (t.x + dx);
+}
+__device__ __forceinline__ void ss_write_out(const DRenderArgs& A, const DTile& t, int dx, int dy, const TC& c) {
+  size_t o = ss_out_index(A, t, dx, dy);
+  ss_store(A.out5, o, c);
+  if (A.packed && !A.dense) A.packed[o] = rgbf(c.r * c.a, c.g * c.a, c.b * c.a);
+}
 
-template <class TIER>
-__device__ __forceinline__ void subsample_tile(const DRenderArgs& A, TIER& T, const DTile& t, uint32_t* list, uint32_t* count) {
-  float* v = A.scratch + (size_t)t.pix_base * 5;  // dense tile buffer, tw * th entries
-  const int tw = t.w, th = t.h, np = tw * th, tid = threadIdx.x;
-  auto getc = [&](int dx, int dy) -> TC {  // getc, Glome.hs:233-235: neighbours outside the tile read as blank
-    if (dx >= 0 && dx < tw && dy >= 0 && dy < th) return ss_load(v, (size_t)dy * tw + dx);
-    return tc_blank();
-  };
-  for (int i = tid; i < np; i += kSSThreads) ss_store(v, i, tc_blank());  // MUV.replicate ... (0,0,0,0,infinity), :231
-  __syncthreads();
-  for (int pass = 1; pass <= 5; pass++) {
-    const float thr = pass >= 2 ? A.thresholds[pass - 2] : 0.0f;
-    int ox[4], oy[4];
-    ss_neighbours(pass, ox, oy);
-    if (tid == 0) *count = 0;
-    __syncthreads();
-    for (int i = tid; i < np; i += kSSThreads) {
-      int dx = i % tw, dy = i / tw;
-      if (!ss_candidate(pass, dx, dy)) continue;
-      bool need = true;
-      if (pass >= 2) {
-        TC a = getc(dx + ox[0], dy + oy[0]), b = getc(dx + ox[1], dy + oy[1]), c = getc(dx + ox[2], dy + oy[2]), d = getc(dx + ox[3], dy + oy[3]);
-        float variance = gmaxf(ccmp(a, c), ccmp(b, d));  // decide, Glome.hs:215
-        need = variance > thr;
-        if (!need) {
-          TC avg = cavg4(a, b, c, d);
-          if (pass < 5) ss_store(v, i, avg);
-          else ss_store(A.out5, A.dense ? (size_t)t.pix_base + i : (size_t)(t.y + dy) * A.width + (t.x + dx), ss_pass5_blend(avg, a, b, c, d, dx == tw - 1, dy == th - 1));
+__global__ void __launch_bounds__(256) k_ss_decide(DRenderArgs A, int pass) {
+  float* v = A.scratch;
+  const int lane = threadIdx.x & 63;
+  const float thr = pass >= 2 ? A.thresholds[pass - 2] : 0.0f;
+  int ox[4], oy[4];
+  ss_neighbours(pass, ox, oy);
+  // whole waves iterate together so the ballot below always sees 64 lanes
+  const uint32_t total = A.total_pixels, step = gridDim.x * blockDim.x;
+  for (uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) - lane; base < total; base += step) {
+    uint32_t idx = base + lane;
+    bool need = false;
+    if (idx < total) {
+      DTile t = ss_tile_of(A, idx);
+      int i = (int)(idx - t.pix_base), dx = i % t.w, dy = i / t.w;
+      if (pass == 1) ss_store(v, idx, tc_blank());  // MUV.replicate ... (0,0,0,0,infinity), Glome.hs:231
+      if (ss_candidate(pass, dx, dy)) {
+        need = true;
+        if (pass >= 2) {
+          TC a = ss_getc(v, t, dx + ox[0], dy + oy[0]), b = ss_getc(v, t, dx + ox[1], dy + oy[1]);
+          TC c = ss_getc(v, t, dx + ox[2], dy + oy[2]), d = ss_getc(v, t, dx + ox[3], dy + oy[3]);
+          need = gmaxf(ccmp(a, c), ccmp(b, d)) > thr;  // decide, Glome.hs:215-216
+          if (!need) {
+            TC avg = cavg4(a, b, c, d);
+            if (pass < 5) ss_store(v, idx, avg);
+            else ss_write_out(A, t, dx, dy, ss_pass5_blend(avg, a, b, c, d, dx == t.w - 1, dy == t.h - 1));
+          }
         }
       }
-      if (need) list[atomicAdd(count, 1u)] = (uint32_t)i;
     }
-    __syncthreads();
-    const uint32_t n = *count;
-    for (uint32_t k = tid; k < n; k += kSSThreads) {
-      int i = (int)list[k], dx = i % tw, dy = i / tw;
-      float off = pass == 5 ? 0.5f : 0.0f;  // pass 5 samples the pixel's lower-right corner region (:307)
-      TC s = ss_sample(A, T, (float)(t.x + dx) + off, (float)(t.y + dy) + off);
-      if (pass < 5) ss_store(v, i, s);
-      else {
-        TC a = getc(dx + ox[0], dy + oy[0]), b = getc(dx + ox[1], dy + oy[1]), c = getc(dx + ox[2], dy + oy[2]), d = getc(dx + ox[3], dy + oy[3]);
-        ss_store(A.out5, A.dense ? (size_t)t.pix_base + i : (size_t)(t.y + dy) * A.width + (t.x + dx), ss_pass5_blend(s, a, b, c, d, dx == tw - 1, dy == th - 1));
-      }
-    }
-    __syncthreads();
-  }
-  if (A.packed && !A.dense) {
-    for (int i = tid; i < np; i += kSSThreads) {
-      size_t o = (size_t)(t.y + i / tw) * A.width + (t.x + i % tw);
-      const float* q = A.out5 + o * 5;
-      A.packed[o] = rgbf(q[0] * q[3], q[1] * q[3], q[2] * q[3]);
+    unsigned long long m = __ballot(need);
+    if (m) {
+      uint32_t start = 0;
+      if (lane == 0) start = atomicAdd(&A.ss_cnt[pass], (unsigned int)__popcll(m));
+      start = __shfl(start, 0, 64);
+      if (need) A.ss_list[start + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = idx;
     }
   }
 }
 
+template <class TIER>
+__device__ __forceinline__ void ss_trace_loop(const DRenderArgs& A, TIER& T, int pass) {
+  float* v = A.scratch;
+  const int lane = threadIdx.x & 63;
+  const uint32_t n = A.ss_cnt[pass];
+  int ox[4], oy[4];
+  ss_neighbours(pass, ox, oy);
+  for (;;) {
+    uint32_t w = 0;
+    if (lane == 0) w = atomicAdd(&A.ss_cnt[8 + pass], 1u);  // queue head of this pass
+    w = __shfl(w, 0, 64);
+    if ((unsigned long long)w * 64 >= n) break;
+    uint32_t k = w * 64 + lane;
+    if (k >= n) continue;
+    uint32_t idx = A.ss_list[k];
+    DTile t = ss_tile_of(A, idx);
+    int i = (int)(idx - t.pix_base), dx = i % t.w, dy = i / t.w;
+    float off = pass == 5 ? 0.5f : 0.0f;  // pass 5 samples between pixels (getCoordsf (x+.5) (y+.5), Glome.hs:307)
+    float xc, yc;
+    get_coordsf(A.width, A.height, (float)(t.x + dx) + off, (float)(t.y + dy) + off, xc, yc);
+    Ray ray = primary_ray(A.cam, xc, yc);
+    T.cnt.primary++;
+    HitG h;
+    CA c = trace_primary(T, ray, kInf, A.maxdepth, &h);
+    TC s = tc(c.r, c.g, c.b, c.a, h.hit ? h.t : kInf);
+    if (pass < 5) ss_store(v, idx, s);
+    else {
+      TC a = ss_getc(v, t, dx + ox[0], dy + oy[0]), b = ss_getc(v, t, dx + ox[1], dy + oy[1]);
+      TC cc = ss_getc(v, t, dx + ox[2], dy + oy[2]), d = ss_getc(v, t, dx + ox[3], dy + oy[3]);
+      ss_write_out(A, t, dx, dy, ss_pass5_blend(s, a, b, cc, d, dx == t.w - 1, dy == t.h - 1));
+    }
+  }
+}
 template <bool FULL, int CLS>
-__global__ void __launch_bounds__(kSSThreads) k_subsample_flat(DRenderArgs A, int stack_cap, uint32_t* ovf, int ovf_cap) {
+__global__ void __launch_bounds__(64) k_ss_trace_flat(DRenderArgs A, int pass, int stack_cap, uint32_t* ovf, int ovf_cap) {
   extern __shared__ uint32_t lds[];
-  uint32_t* list = lds + (size_t)(kSSThreads / 64) * stack_cap * 64 * 3;
-  uint32_t* count = list + 65 * 65 + 3;
   FlatTier<false, false, FULL, CLS> T{A.S, A.lights, A.nlights, lane_stack(lds, stack_cap, ovf, ovf_cap), Cnt()};
-  for (int ti = blockIdx.x; ti < A.ntiles; ti += gridDim.x) subsample_tile(A, T, A.tiles[ti], list, count);
+  ss_trace_loop(A, T, pass);
   flush_counters(A.counters, T.cnt, 0);
 }
-__global__ void __launch_bounds__(kSSThreads) k_subsample_generic(DRenderArgs A) {
-  __shared__ uint32_t list[65 * 65 + 4];
+__global__ void __launch_bounds__(64) k_ss_trace_generic(DRenderArgs A, int pass) {
   GenericTier T{A.S, A.lights, A.nlights, Cnt()};
-  for (int ti = blockIdx.x; ti < A.ntiles; ti += gridDim.x) subsample_tile(A, T, A.tiles[ti], list, list + 65 * 65 + 3);
+  ss_trace_loop(A, T, pass);
   flush_counters(A.counters, T.cnt, T.err);
 }
 
@@ -681,28 +708,34 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
   HIPCHK(ctx, hipMemsetAsync(ctx->slot().d_counters, 0, sizeof(DCounters), ctx->stream));
   hipEvent_t ev_start = ctx->ev0, ev_stop = ctx->ev1;
   if (A.ntiles > 0 && P->mode == GLOME_MODE_SUBSAMPLE) {
-    if ((rc = ensure_scratch(ctx, (size_t)tt->pixels * 5 * sizeof(float)))) return rc;
+    // scratch: v (5 floats per owned pixel) | list (one u32 per owned pixel) | 16 counters (list lengths, queue heads)
+    size_t npx = (size_t)tt->pixels;
+    if ((rc = ensure_scratch(ctx, npx * 5 * sizeof(float) + npx * sizeof(uint32_t) + 16 * sizeof(unsigned int)))) return rc;
     A.scratch = ctx->slot().d_scratch;
-    int grid = std::min(A.ntiles, ctx->prop.multiProcessorCount * 4);
+    A.ss_list = (uint32_t*)(A.scratch + npx * 5);
+    A.ss_cnt = (unsigned int*)(A.ss_list + npx);
+    A.total_pixels = (uint32_t)npx;
+    HIPCHK(ctx, hipMemsetAsync(A.ss_cnt, 0, 16 * sizeof(unsigned int), ctx->stream));
     bool pooled = ctx->timing && ctx->pool_used + 2 <= (int)ctx->pool.size();
     hipEvent_t e0 = pooled ? ctx->pool[ctx->pool_used] : ctx->ev0, e1 = pooled ? ctx->pool[ctx->pool_used + 1] : ctx->ev1;
     if (pooled) ctx->pool_used += 2;
     ev_start = e0; ev_stop = e1;
     HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
-    if (s->dev.tier == 0) {
-      size_t lds = flat_lds_bytes(s->stack_cap) * (kSSThreads / 64) + (65 * 65 + 4) * sizeof(uint32_t);
-      if (s->ovf_cap && (rc = ensure_overflow(ctx, grid, kSSThreads / 64, s->ovf_cap))) return rc;
-      bool full = s->has_nested_mats || (s->has_secondary_mats && P->maxdepth > 1);
-      uint32_t* ov = s->ovf_cap ? ctx->slot().d_ovf : nullptr;
-      int m = s->cls_mask;
-      bool tri = (m & ~CLS_BIH_TRI) == 0;
-      dim3 g(grid), blk(kSSThreads);
-      if (tri && !full) hipLaunchKernelGGL((k_subsample_flat<false, CLS_BIH_TRI>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
-      else if (tri) hipLaunchKernelGGL((k_subsample_flat<true, CLS_BIH_TRI>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
-      else if (!full) hipLaunchKernelGGL((k_subsample_flat<false, CLS_ALL>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
-      else hipLaunchKernelGGL((k_subsample_flat<true, CLS_ALL>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
-    } else {
-      hipLaunchKernelGGL(k_subsample_generic, dim3(grid), dim3(kSSThreads), 0, ctx->stream, A);
+    size_t lds = s->dev.tier == 0 ? flat_lds_bytes(s->stack_cap) : 0;
+    int tgrid = persistent_grid(ctx, lds, (uint32_t)((npx + 63) / 64));
+    if (s->dev.tier == 0 && s->ovf_cap && (rc = ensure_overflow(ctx, tgrid, 1, s->ovf_cap))) return rc;
+    bool full = s->has_nested_mats || (s->has_secondary_mats && P->maxdepth > 1);
+    bool tri = s->dev.tier == 0 && (s->cls_mask & ~CLS_BIH_TRI) == 0;
+    uint32_t* ov = s->ovf_cap ? ctx->slot().d_ovf : nullptr;
+    int dgrid = (int)std::min<size_t>((npx + 255) / 256, (size_t)ctx->prop.multiProcessorCount * 16);
+    for (int pass = 1; pass <= 5; pass++) {
+      hipLaunchKernelGGL(k_ss_decide, dim3(dgrid), dim3(256), 0, ctx->stream, A, pass);
+      dim3 g(tgrid), blk(64);
+      if (s->dev.tier != 0) hipLaunchKernelGGL(k_ss_trace_generic, g, blk, 0, ctx->stream, A, pass);
+      else if (tri && !full) hipLaunchKernelGGL((k_ss_trace_flat<false, CLS_BIH_TRI>), g, blk, lds, ctx->stream, A, pass, s->stack_cap, ov, s->ovf_cap);
+      else if (tri) hipLaunchKernelGGL((k_ss_trace_flat<true, CLS_BIH_TRI>), g, blk, lds, ctx->stream, A, pass, s->stack_cap, ov, s->ovf_cap);
+      else if (!full) hipLaunchKernelGGL((k_ss_trace_flat<false, CLS_ALL>), g, blk, lds, ctx->stream, A, pass, s->stack_cap, ov, s->ovf_cap);
+      else hipLaunchKernelGGL((k_ss_trace_flat<true, CLS_ALL>), g, blk, lds, ctx->stream, A, pass, s->stack_cap, ov, s->ovf_cap);
     }
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(e1, ctx->stream));

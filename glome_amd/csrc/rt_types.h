@@ -107,6 +107,9 @@ struct DRenderArgs {
   uint32_t total_waves;
   int32_t dense;       // 1: out5 is a dense tile payload (tile order, row major inside a tile) instead of a frame
   float* scratch;      // adaptive sampler: dense per-tile working buffer `v` (owned pixels * 5 floats)
+  uint32_t* ss_list;   // adaptive sampler: pixels (dense index) that need a traced sample in the current pass
+  unsigned int* ss_cnt;  // [pass] list length, [8 + pass] queue head
+  uint32_t total_pixels;  // owned pixels
   float* out5;         // width*height*5
   uint32_t* packed;    // width*height or null
   DCounters* counters;
