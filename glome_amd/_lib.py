@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libglome_hip.so")
+# GLOME_DEBUG_LIB: load another build of the same library (kernel experiments, tools/variant_bench.py); never a fallback
+LIB_PATH = os.environ.get("GLOME_DEBUG_LIB") or os.path.join(HERE, "libglome_hip.so")
 
 c_dp = C.POINTER(C.c_double)
 c_fp = C.POINTER(C.c_float)

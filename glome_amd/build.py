@@ -10,7 +10,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=on: contraction decided per source expression, so every kernel instance rounds identically (the tests
 # require bit-identical frames across instances); denormals flushed so 1/x is a bare v_rcp_f32
 HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-ffp-contract=on",
-            "-fgpu-flush-denormals-to-zero"]
+            "-fgpu-flush-denormals-to-zero"] + os.environ.get("GLOME_EXTRA_HIPFLAGS", "").split()
 
 
 def _stale(target, sources):

@@ -44,6 +44,12 @@ struct FlatTier {
     return finalize_flat<CLS>(S, r, c);
   }
   __device__ __forceinline__ bool occluded(const Ray& r, float d) { return occluded_flat<COUNT, CLS>(S, r, d, stk, cnt); }
+  // wave-wide calls (every lane of the wave makes them together; `valid` = the lane holds a ray)
+  __device__ __forceinline__ HitG closest_wave(const Ray& r, float tmax, bool valid) {
+    Cand c = closest_flat<FAITHFUL, COUNT, CLS, true>(S, r, tmax, stk, cnt, valid);
+    return valid ? finalize_flat<CLS>(S, r, c) : hit_miss();
+  }
+  __device__ __forceinline__ bool occluded_wave(const Ray& r, float d, bool valid) { return occluded_flat<COUNT, CLS, true>(S, r, d, stk, cnt, valid); }
   __device__ __noinline__ HitG closest_ni(const Ray& r, float tmax) { return closest(r, tmax); }
   __device__ __noinline__ bool occluded_ni(const Ray& r, float d) { return occluded(r, d); }
 };
@@ -68,6 +74,8 @@ struct GenericTier {
   }
   __device__ __forceinline__ HitG closest_ni(const Ray& r, float tmax) { return closest(r, tmax); }  // rayint_g is out of line already
   __device__ __forceinline__ bool occluded_ni(const Ray& r, float d) { return occluded(r, d); }
+  __device__ __forceinline__ HitG closest_wave(const Ray& r, float tmax, bool valid) { return valid ? closest(r, tmax) : hit_miss(); }
+  __device__ __forceinline__ bool occluded_wave(const Ray& r, float d, bool valid) { return valid && occluded(r, d); }
 };
 
 // LDS carve per wave: three stack columns of cap * 64 words
@@ -144,15 +152,16 @@ __device__ __forceinline__ void render_loop(const DRenderArgs& A, TIER& T) {
     if (lane == 0) w = atomicAdd(&A.counters->next_work, 1u);
     w = __shfl(w, 0, 64);
     if (w >= A.total_waves) break;
-    int px, py;
-    size_t dense_off;
-    if (!work_to_pixel(A, w, lane, px, py, dense_off)) continue;
+    int px = 0, py = 0;
+    size_t dense_off = 0;
+    const bool valid = work_to_pixel(A, w, lane, px, py, dense_off);  // lanes past the end of a leftover strip idle along
     float xc, yc;
     get_coordsf(A.width, A.height, (float)px, (float)py, xc, yc);
     Ray ray = primary_ray(A.cam, xc, yc);
-    T.cnt.primary++;
+    if (valid) T.cnt.primary++;
     HitG h;
-    CA c = trace_primary(T, ray, kInf, A.maxdepth, &h);  // Trace.trace lights shader sld ray infinity maxdepth (Glome.hs:33)
+    CA c = trace_primary(T, ray, kInf, A.maxdepth, valid, &h);  // Trace.trace lights shader sld ray infinity maxdepth (Glome.hs:33)
+    if (!valid) continue;
     float depth = h.hit ? h.t : kInf;      // ridepth
     float r = c.r;
     if (A.fog) r = r + (depth / 400);      // renderTile's debug fog (Glome.hs:174, Q20)
@@ -262,17 +271,18 @@ __device__ __forceinline__ void ss_trace_loop(const DRenderArgs& A, TIER& T, int
     w = __shfl(w, 0, 64);
     if ((unsigned long long)w * 64 >= n) break;
     uint32_t k = w * 64 + lane;
-    if (k >= n) continue;
-    uint32_t idx = A.ss_list[k];
+    const bool valid = k < n;
+    uint32_t idx = A.ss_list[valid ? k : n - 1];
     DTile t = ss_tile_of(A, idx);
     int i = (int)(idx - t.pix_base), dx = i % t.w, dy = i / t.w;
     float off = pass == 5 ? 0.5f : 0.0f;  // pass 5 samples between pixels (getCoordsf (x+.5) (y+.5), Glome.hs:307)
     float xc, yc;
     get_coordsf(A.width, A.height, (float)(t.x + dx) + off, (float)(t.y + dy) + off, xc, yc);
     Ray ray = primary_ray(A.cam, xc, yc);
-    T.cnt.primary++;
+    if (valid) T.cnt.primary++;
     HitG h;
-    CA c = trace_primary(T, ray, kInf, A.maxdepth, &h);
+    CA c = trace_primary(T, ray, kInf, A.maxdepth, valid, &h);
+    if (!valid) continue;
     TC s = tc(c.r, c.g, c.b, c.a, h.hit ? h.t : kInf);
     if (pass < 5) ss_store(v, idx, s);
     else {

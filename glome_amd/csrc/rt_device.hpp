@@ -71,6 +71,28 @@ struct Ray { V3 o, d; };
 GD F4 ld4(const F4* p, uint32_t i) { return p[i]; }
 GD U4 ldu4(const U4* p, uint32_t i) { return p[i]; }
 
+// ------------------------------------------------------------------ wave-level helpers
+// The packet traversal below keeps its control flow uniform across the 64 lanes of a wave: votes decide where the wave
+// goes, every lane follows.  Compiled for the host (tests/hostsim) a "wave" is one lane, and the same code is a
+// single-ray traversal.
+#if defined(__HIPCC__)
+GD unsigned long long wave_ballot(bool p) { return __ballot(p); }
+GD bool wave_any(bool p) { return __ballot(p) != 0ull; }
+GD uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }  // a value every lane agrees on -> SGPR
+// loads at a wave-uniform index through the constant address space, so they can be scalar loads (s_load_dwordx4)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+GD F4 ld4u(const F4* p, uint32_t i) {
+  const f32x4 __attribute__((address_space(4)))* q = (const f32x4 __attribute__((address_space(4)))*)(uintptr_t)p;
+  f32x4 v = q[uni(i)];
+  F4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r;
+}
+#else
+GD unsigned long long wave_ballot(bool p) { return p ? 1ull : 0ull; }
+GD bool wave_any(bool p) { return p; }
+GD uint32_t uni(uint32_t v) { return v; }
+GD F4 ld4u(const F4* p, uint32_t i) { return p[i]; }
+#endif
+
 // texture stacks: 4 x 16 bit, innermost first, id+1 (rt_types.h)
 GD TexStack tex_push(TexStack s, uint32_t mat) { return (s << 16) | (TexStack)(mat + 1); }  // tex:texs, Tex.hs:66
 GD int tex_len(TexStack s) { return (s >> 48) ? 4 : ((s >> 32) ? 3 : ((s >> 16) ? 2 : (s ? 1 : 0))); }
@@ -151,8 +173,10 @@ GD bool tri_test(const F4& q0, const F4& q1, const F4& q2, const Ray& ray, float
   V3 s2 = vcross(d, e1);
   b2 = vdot(ray.d, s2) * invdivisor;
   t = vdot(e2, s2) * invdivisor;
-  bool miss = (divisor == 0) | (b1 < 0) | (b1 > 1) | (b2 < 0) | (b1 + b2 > 1) | (t < 0) | (t > dist);
-  return !miss;
+  // the reference's chain `divisor == 0 || b1 < 0 || b1 > 1 || b2 < 0 || b1 + b2 > 1 || t < 0 || t > dist`, folded with
+  // IEEE min/max (which return the other operand for a NaN, so every NaN case decides as the chain does)
+  float lo = fminf(fminf(b1, b2), t), hi = fmaxf(b1, b1 + b2);
+  return (divisor != 0) & !(lo < 0) & !(hi > 1) & !(t > dist);
 }
 // Box.hs:18-54 (Q1, Q6)
 GD bool box_test(const F4& lo, const F4& hi, const Ray& r, float d, float& t, V3& n) {
@@ -357,6 +381,26 @@ struct LaneStack {
   static constexpr int STRIDE = 1;
 #endif
   GD int total_cap() const { return cap + ovf_cap; }
+#if defined(__HIPCC__)
+  // The overflow column is spill traffic (non-temporal).  The empty asm pins the overflow loads inside their branch:
+  // without it the compiler sinks both branches' loads into one access through a generic (flat) pointer, and every
+  // pop becomes three flat loads that wait on the LDS and the vector-memory counters.
+  GD void push(int sp, uint32_t n, float a, float b) {
+    if (__builtin_expect(sp < cap, 1)) { node[sp * STRIDE] = n; nearv[sp * STRIDE] = a; farv[sp * STRIDE] = b; }
+    else {
+      uint32_t* o = ovf + (size_t)(sp - cap) * 3 * STRIDE;
+      __builtin_nontemporal_store(n, o); __builtin_nontemporal_store(as_u(a), o + STRIDE); __builtin_nontemporal_store(as_u(b), o + 2 * STRIDE);
+    }
+  }
+  GD void pop(int sp, uint32_t& n, float& a, float& b) const {
+    if (__builtin_expect(sp < cap, 1)) { n = node[sp * STRIDE]; a = nearv[sp * STRIDE]; b = farv[sp * STRIDE]; }
+    else {
+      const uint32_t* o = ovf + (size_t)(sp - cap) * 3 * STRIDE;
+      n = __builtin_nontemporal_load(o); a = as_f(__builtin_nontemporal_load(o + STRIDE)); b = as_f(__builtin_nontemporal_load(o + 2 * STRIDE));
+      asm volatile("" : "+v"(n), "+v"(a), "+v"(b));
+    }
+  }
+#else
   GD void push(int sp, uint32_t n, float a, float b) {
     if (sp < cap) { node[sp * STRIDE] = n; nearv[sp * STRIDE] = a; farv[sp * STRIDE] = b; }
     else { uint32_t* o = ovf + (size_t)(sp - cap) * 3 * STRIDE; o[0] = n; o[STRIDE] = as_u(a); o[2 * STRIDE] = as_u(b); }
@@ -365,6 +409,7 @@ struct LaneStack {
     if (sp < cap) { n = node[sp * STRIDE]; a = nearv[sp * STRIDE]; b = farv[sp * STRIDE]; }
     else { const uint32_t* o = ovf + (size_t)(sp - cap) * 3 * STRIDE; n = o[0]; a = as_f(o[STRIDE]); b = as_f(o[2 * STRIDE]); }
   }
+#endif
 };
 // Generic tier: a fixed private array (scratch).
 struct PrivStack {
@@ -387,7 +432,7 @@ struct PrivStack {
 // bits 25..0"), bits 25..0 = first record of the leaf.  A leaf with up to 6 items is therefore described entirely by
 // the reference held in its parent: reaching it costs no memory fetch, and an empty leaf (a quarter of the leaves the
 // reference builder makes) is never visited at all.  Branch references are plain node indices.
-constexpr uint32_t BREF_LEAF = 1u << 29, BREF_MASK = (1u << 30) - 1u, BREF_FIRST = (1u << 26) - 1u;
+constexpr uint32_t BREF_LEAF = 1u << 29, BREF_MASK = (1u << 30) - 1u, BREF_FIRST = (1u << 26) - 1u, BREF_CONT = 1u << 30;
 template <int MODE, bool COUNT, class STK, class LEAF, class BEST>
 GD void bih_traverse(const DScene& S, uint32_t hdr, const Ray& r, float d, STK& stk, int stack_cap, Cnt& cnt, LEAF&& leaf, BEST&& best_t) {
   F4 h0 = ld4(S.bihhdr, 3 * hdr), h1 = ld4(S.bihhdr, 3 * hdr + 1);
@@ -438,6 +483,187 @@ GD void bih_traverse(const DScene& S, uint32_t hdr, const Ray& r, float d, STK& 
       stk.pop(sp, ref, nearv, farv);
     }
   }
+}
+
+// ------------------------------------------------------------------ BIH of triangles (the `Bih Triangle` SPECIALIZE, Bih.hs:370-374)
+// Same traversal as bih_traverse, shaped for a 64-lane wave: every loop iteration a lane takes ONE step -- a branch
+// step or one triangle of the leaf it stands on (the leaf reference itself is the cursor: first record + remaining
+// count) -- so lanes walking the tree are not held up while a neighbour works through a leaf.  An interval is known to be
+// non-empty when a child is chosen; only an entry popped after `far` has shrunk (MODE 1) can be stale, and that is checked
+// at the pop.  best_t / best_rec: running nearest hit (best_t = kNoBest when none); MODE 2 returns true at the first occluder.
+constexpr float kNoBest = 3.0e38f;
+#if defined(GLOME_HOSTSIM_TRACE)
+#include <vector>
+static thread_local std::vector<uint32_t>* g_trace_nodes = nullptr; static thread_local std::vector<uint32_t>* g_trace_tris = nullptr;
+#endif
+template <int MODE, bool COUNT, class STK>
+GD bool bih_tri(const DScene& S, uint32_t hdr, const Ray& r, float d, STK& stk, Cnt& cnt, float& best_t, uint32_t& best_rec) {
+  F4 h0 = ld4(S.bihhdr, 3 * hdr), h1 = ld4(S.bihhdr, 3 * hdr + 1);
+  const uint32_t delta = as_u(ld4(S.bihhdr, 3 * hdr + 2).x);
+  float nearv, farv;
+  bbclip_ub(r, v3(h0), v3(h1), nearv, farv);
+  farv = gminf(d, farv);  // `traverse root near (fmin d far)`, Bih.hs:368
+  const V3 rcp = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+  uint32_t ref = as_u(h0.w);
+  const int cap = stk.total_cap();
+  int sp = 0;
+  bool occ = false;
+  if (nearv > farv) {  // the root interval is empty
+    if (!(ref & BREF_LEAF)) { if (COUNT) cnt.bih++; return false; }  // a branch is entered, counted and left (Bih.hs:343)
+    if (MODE != 0) return false;                                       // a root leaf is tested regardless (Bih.hs:339)
+  }
+  for (;;) {
+    bool popit;
+    if (!(ref & BREF_LEAF)) {
+      if (COUNT) cnt.bih++;
+#if defined(GLOME_HOSTSIM_TRACE)
+      if (g_trace_nodes) g_trace_nodes->push_back(ref);
+#endif
+      F4 n = ld4(S.bihnodes, ref);
+      uint32_t w0 = as_u(n.z), right = as_u(n.w);
+      uint32_t axis = w0 & 3u, left = w0 >> 2;
+      float dirr = vcomp(rcp, axis), o = vcomp(r.o, axis);
+      float dl = (n.x - o) * dirr, dr = (n.y - o) * dirr;
+      bool fwd = dirr > 0;
+      uint32_t c1 = fwd ? left : right, c2 = fwd ? right : left;
+      float t1 = fwd ? dl : dr, t2 = fwd ? dr : dl;        // near child ends at t1, far child starts at t2
+      // an empty leaf holds nothing to test: it is never visited (no effect on results or on the branch counts)
+      bool go1 = (nearv < t1) && (c1 != BREF_LEAF), go2 = (t2 < farv) && (c2 != BREF_LEAF);
+      float c1far = gminf(t1, farv), c2near = gmaxf(t2, nearv);
+      if (go1 && go2 && sp < cap) { stk.push(sp, c2, c2near, farv); sp++; }
+      ref = go1 ? c1 : c2;
+      nearv = go1 ? nearv : c2near;
+      farv = go1 ? c1far : farv;
+      popit = !(go1 || go2);
+    } else {
+      uint32_t count = (ref >> 26) & 7u, first = ref & BREF_FIRST;
+      if (__builtin_expect(count == 7u, 0)) {
+        // a leaf of more than 6 triangles: its extent is in the leaf node.  It is worked through six at a time; the
+        // rest waits on the stack as a continuation (bit 30; the `near` slot carries the offset reached).
+        F4 ln = ld4(S.bihnodes, first);
+        uint32_t k0 = (ref & BREF_CONT) ? as_u(nearv) : 0u, left_over = as_u(ln.z) - k0;
+        if (left_over > 6u && sp < cap) { stk.push(sp, ref | BREF_CONT, as_f(k0 + 6u), farv); sp++; }
+        ref = BREF_LEAF | ((left_over < 6u ? left_over : 6u) << 26) | (as_u(ln.w) + k0);
+        popit = false;
+      } else if (count == 0u) {
+        popit = true;  // an empty root leaf, or a stale entry retired at the pop below
+      } else {
+        uint32_t a = first + delta;
+#if defined(GLOME_HOSTSIM_TRACE)
+        if (g_trace_tris) g_trace_tris->push_back(a);
+#endif
+        F4 q0 = ld4(S.tris, 3 * a), q1 = ld4(S.tris, 3 * a + 1), q2 = ld4(S.tris, 3 * a + 2);
+        float t, b1, b2;
+        if (COUNT) cnt.prim++;
+        // tmax = far (Bih.hs:339; shadow: `fmin d far`, Bih.hs:515 -- far <= d already); MODE 1: far <= best_t
+        bool hit = tri_test(q0, q1, q2, r, farv, t, b1, b2);
+        ref += 1u - (1u << 26);  // the next triangle of this leaf
+        popit = count == 1u;
+        if (MODE == 2) { if (hit) { occ = true; sp = 0; popit = true; } }  // first occluder: leave through the one exit
+        else if (hit && !(best_t < t)) { best_t = t; best_rec = first; if (MODE == 1) farv = gminf(farv, t); }
+      }
+    }
+    if (popit) {
+      if (sp == 0) break;
+      sp--;
+      stk.pop(sp, ref, nearv, farv);
+      if (MODE == 1 && !(ref & BREF_CONT)) {
+        farv = gminf(farv, best_t);
+        if (nearv > farv) ref = BREF_LEAF;  // nothing nearer can be in there: retire it (one idle step, as before)
+      }
+    }
+  }
+  return occ;
+}
+
+// ------------------------------------------------------------------ BIH of triangles, one wave = one packet
+// The 64 rays of a work item (an 8x8 pixel block, or the shadow rays leaving it) visit almost the same nodes: on the
+// 100k-triangle scene the union over a wave is 1.2x one ray's own list.  So the wave walks the tree ONCE: the node
+// reference is wave-uniform (scalar loads, scalar branches, no per-lane stack pointer), each lane carries only its own
+// [near, far] interval and is simply inactive (near = +inf, far = -inf) where its ray would not go; a child is entered
+// when any lane's interval reaches it.  Per lane the sequence of nodes entered and triangles tested is exactly the one
+// bih_tri walks -- children are taken near-first by the direction signs, which must therefore agree across the wave;
+// when they do not (a block straddling an axis plane through the eye), or the root is a leaf, the lanes fall back to
+// bih_tri.  Results, tie order and work counters are identical to the per-lane traversal.
+// `valid`: the lane holds a ray.  All lanes of the wave must make this call together.
+template <int MODE, bool COUNT, class STK>
+GD bool bih_tri_wave(const DScene& S, uint32_t hdr, const Ray& r, float d, bool valid, STK& stk, Cnt& cnt, float& best_t, uint32_t& best_rec) {
+  const float kOut = __builtin_huge_valf();
+  hdr = uni(hdr);
+  F4 h0 = ld4u(S.bihhdr, 3 * hdr), h1 = ld4u(S.bihhdr, 3 * hdr + 1);
+  const uint32_t delta = uni(as_u(ld4u(S.bihhdr, 3 * hdr + 2).x));
+  uint32_t ref = uni(as_u(h0.w));
+  const V3 rcp = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+  const unsigned long long vm = wave_ballot(valid);
+  const unsigned long long sx = wave_ballot(valid && rcp.x > 0), sy = wave_ballot(valid && rcp.y > 0), sz = wave_ballot(valid && rcp.z > 0);
+  const bool packet = !(ref & BREF_LEAF) && (sx == 0 || sx == vm) && (sy == 0 || sy == vm) && (sz == 0 || sz == vm);
+  if (!packet) return valid ? bih_tri<MODE, COUNT>(S, hdr, r, d, stk, cnt, best_t, best_rec) : false;
+  const bool fx = sx != 0, fy = sy != 0, fz = sz != 0;
+  float nearv, farv;
+  bbclip_ub(r, v3(h0), v3(h1), nearv, farv);
+  farv = gminf(d, farv);  // `traverse root near (fmin d far)`, Bih.hs:368
+  if (!valid || nearv > farv) {
+    if (COUNT && valid) cnt.bih++;  // the root branch is entered, counted and left (Bih.hs:343)
+    nearv = kOut; farv = -kOut;
+  }
+  const int cap = stk.total_cap();
+  int sp = 0;
+  bool occ = false;
+  for (;;) {
+    bool popit;
+    if (!(ref & BREF_LEAF)) {
+      F4 n = ld4u(S.bihnodes, ref);
+      const uint32_t w0 = uni(as_u(n.z)), right = uni(as_u(n.w));
+      const uint32_t axis = w0 & 3u, left = w0 >> 2;
+      const float dirr = axis == 0 ? rcp.x : (axis == 1 ? rcp.y : rcp.z), o = axis == 0 ? r.o.x : (axis == 1 ? r.o.y : r.o.z);
+      const bool fwd = axis == 0 ? fx : (axis == 1 ? fy : fz);
+      const float dl = (n.x - o) * dirr, dr = (n.y - o) * dirr;
+      const uint32_t c1 = fwd ? left : right, c2 = fwd ? right : left;
+      const float t1 = fwd ? dl : dr, t2 = fwd ? dr : dl;  // near child ends at t1, far child starts at t2
+      if (COUNT) { if (!(nearv > farv)) cnt.bih++; }
+      const bool a1 = nearv < t1, a2 = t2 < farv;           // an inactive lane fails both
+      const bool go1 = (c1 != BREF_LEAF) && wave_any(a1), go2 = (c2 != BREF_LEAF) && wave_any(a2);
+      const float n1 = a1 ? nearv : kOut, f1 = a1 ? gminf(t1, farv) : -kOut;
+      const float n2 = a2 ? gmaxf(t2, nearv) : kOut, f2 = a2 ? farv : -kOut;
+      if (go1) {
+        if (go2 && sp < cap) { stk.push(sp, c2, n2, f2); sp++; }
+        ref = c1; nearv = n1; farv = f1;
+      } else {
+        ref = c2; nearv = n2; farv = f2;
+      }
+      popit = !(go1 || go2);
+    } else {
+      uint32_t count = (ref >> 26) & 7u, first = ref & BREF_FIRST;
+      if (count == 7u) { F4 ln = ld4u(S.bihnodes, first); count = uni(as_u(ln.z)); first = uni(as_u(ln.w)); }
+      for (uint32_t k = 0; k < count; k++) {
+        const uint32_t a = first + k + delta;
+        F4 q0 = ld4u(S.tris, 3 * a), q1 = ld4u(S.tris, 3 * a + 1), q2 = ld4u(S.tris, 3 * a + 2);
+        float t, b1, b2;
+        const bool act = !(nearv > farv);
+        if (COUNT) { if (act) cnt.prim++; }
+        // tmax = far (Bih.hs:339; shadow: `fmin d far`, Bih.hs:515 -- far <= d already); MODE 1: far <= best_t
+        const bool hit = tri_test(q0, q1, q2, r, farv, t, b1, b2) && act;
+        if (MODE == 2) { if (hit) { occ = true; nearv = kOut; farv = -kOut; } }
+        else if (hit && !(best_t < t)) { best_t = t; best_rec = first + k; if (MODE == 1) farv = gminf(farv, t); }
+      }
+      popit = true;
+    }
+    if (popit) {
+      // pop until an entry some lane still wants (MODE 1: `far` may have shrunk since the push; MODE 2: lanes retire)
+      bool found = false;
+      while (sp > 0 && !found) {
+        sp--;
+        uint32_t pr;
+        stk.pop(sp, pr, nearv, farv);
+        ref = uni(pr);
+        if (MODE == 1) { farv = gminf(farv, best_t); if (nearv > farv) { nearv = kOut; farv = -kOut; } }
+        if (MODE == 2) { if (occ) { nearv = kOut; farv = -kOut; } }
+        found = wave_any(!(nearv > farv));
+      }
+      if (!found) break;
+    }
+  }
+  return occ;
 }
 
 // ------------------------------------------------------------------ Mesh 2-box BVH (Mesh.hs:136-198; Q12)
@@ -523,32 +749,33 @@ GD HitG hit_miss() { HitG h; h.hit = false; h.t = kInf; h.p = v3(0, 0, 0); h.n =
 // SPECIALIZE pragmas for Bih Triangle / Bih Sphere, Bih.hs:370-374): an all-triangle scene runs a kernel that contains
 // only the triangle loops, which keeps it small enough to stay in registers and in the instruction cache.
 constexpr int CLS_BIH_TRI = 1, CLS_BIH_SPHERE = 2, CLS_BIH_SIMPLE = 4, CLS_MESH = 8, CLS_PRIMS = 16, CLS_ALL = 31;
-template <bool FAITHFUL, bool COUNT, int CLS, class STK>
-GD Cand closest_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt) {
+// WAVE: the call is made by all lanes of a wave together (`valid` = this lane holds a ray); triangle BIHs are then
+// walked as one packet (bih_tri_wave), everything else per lane as before.
+template <bool FAITHFUL, bool COUNT, int CLS, bool WAVE = false, class STK>
+GD Cand closest_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt, bool valid = true) {
   Cand best; best.t = kInf; best.id = CAND_NONE; best.aux = 0;
   for (uint32_t e = 0; e < S.n_entries; e++) {
     U4 ent = ldu4(S.entries, e);
+    if (WAVE) { ent.x = uni(ent.x); ent.z = uni(ent.z); }
     if (ent.z & RF_NOVIS) continue;
     U4 rec = ldu4(S.recs, ent.x);
+    if (WAVE) { rec.x = uni(rec.x); rec.y = uni(rec.y); }
     uint32_t kind = rec.x & RF_KINDMASK;
+    uint32_t cls = 0;
+    if (kind == R_BIH) { cls = as_u(ld4(S.bihhdr, 3 * rec.y + 1).w); if (WAVE) cls = uni(cls); }
+    const bool tri_bih = kind == R_BIH && (CLS & CLS_BIH_TRI) && (CLS == CLS_BIH_TRI || cls == BC_TRI);
+    if (WAVE && !valid && !tri_bih) continue;  // only the packet walk needs the lanes without a ray
     // tmax for this entry; a hit replaces the running best when !(best.t < t)  (nearest: ties -> later)
     float dd = (FAITHFUL || best.id == CAND_NONE) ? d : gminf(d, best.t);
     if (kind == R_BIH) {
-      uint32_t cls = as_u(ld4(S.bihhdr, 3 * rec.y + 1).w);
       auto bestt = [&]() { return best.id == CAND_NONE ? kInf * 4.0f : best.t; };
       auto accept = [&](float t, uint32_t id) { if (best.id == CAND_NONE || !(best.t < t)) { best.t = t; best.id = id; best.aux = e; } };
-      if ((CLS & CLS_BIH_TRI) && (CLS == CLS_BIH_TRI || cls == BC_TRI)) {
-        bih_traverse<FAITHFUL ? 0 : 1, COUNT>(S, rec.y, r, dd, stk, stk.total_cap(), cnt,
-          [&](uint32_t frec, uint32_t fprim, uint32_t count, float tmax) {
-            for (uint32_t k = 0; k < count; k++) {
-              uint32_t a = fprim + k;
-              F4 q0 = ld4(S.tris, 3 * a), q1 = ld4(S.tris, 3 * a + 1), q2 = ld4(S.tris, 3 * a + 2);
-              float t, b1, b2;
-              if (COUNT) cnt.prim++;
-              if (tri_test(q0, q1, q2, r, tmax, t, b1, b2)) { accept(t, frec + k); if (!FAITHFUL) tmax = gminf(tmax, best.t); }
-            }
-            return false;
-          }, bestt);
+      if (tri_bih) {
+        float bt = best.id == CAND_NONE ? kNoBest : best.t;
+        uint32_t brec = CAND_NONE;
+        if (WAVE) bih_tri_wave<FAITHFUL ? 0 : 1, COUNT>(S, rec.y, r, dd, valid, stk, cnt, bt, brec);
+        else bih_tri<FAITHFUL ? 0 : 1, COUNT>(S, rec.y, r, dd, stk, cnt, bt, brec);
+        if (brec != CAND_NONE) { best.t = bt; best.id = brec; best.aux = e; }
       } else if ((CLS & CLS_BIH_SPHERE) && cls == BC_SPHERE) {
         bih_traverse<FAITHFUL ? 0 : 1, COUNT>(S, rec.y, r, dd, stk, stk.total_cap(), cnt,
           [&](uint32_t frec, uint32_t fprim, uint32_t count, float tmax) {
@@ -625,29 +852,27 @@ GD HitG finalize_flat(const DScene& S, const Ray& r, const Cand& c) {
 }
 
 // shadow over the flat root program: `foldl' (||) False (map shadow xs)` (Solid.hs:330); Mesh casts none (Mesh.hs:210)
-template <bool COUNT, int CLS, class STK>
-GD bool occluded_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt) {
+template <bool COUNT, int CLS, bool WAVE = false, class STK>
+GD bool occluded_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt, bool valid = true) {
+  bool result = false;  // WAVE: an occluded lane stays in the entry loop without a ray until the wave is through
   for (uint32_t e = 0; e < S.n_entries; e++) {
     U4 ent = ldu4(S.entries, e);
+    if (WAVE) { ent.x = uni(ent.x); ent.z = uni(ent.z); }
     if (ent.z & RF_NOSHADOW) continue;
     U4 rec = ldu4(S.recs, ent.x);
+    if (WAVE) { rec.x = uni(rec.x); rec.y = uni(rec.y); }
     uint32_t kind = rec.x & RF_KINDMASK;
+    uint32_t cls = 0;
+    if (kind == R_BIH) { cls = as_u(ld4(S.bihhdr, 3 * rec.y + 1).w); if (WAVE) cls = uni(cls); }
+    const bool tri_bih = kind == R_BIH && (CLS & CLS_BIH_TRI) && (CLS == CLS_BIH_TRI || cls == BC_TRI);
+    if (WAVE) { if (!wave_any(valid)) break; if (!valid && !tri_bih) continue; }
     if (kind == R_BIH) {
-      uint32_t cls = as_u(ld4(S.bihhdr, 3 * rec.y + 1).w);
       bool occ = false;
       auto nobest = [&]() { return 0.0f; };
-      if ((CLS & CLS_BIH_TRI) && (CLS == CLS_BIH_TRI || cls == BC_TRI)) {
-        bih_traverse<2, COUNT>(S, rec.y, r, d, stk, stk.total_cap(), cnt,
-          [&](uint32_t, uint32_t fprim, uint32_t count, float tmax) {
-            float dd = gminf(d, tmax);  // `shadow s r (fmin d far)`, Bih.hs:515
-            for (uint32_t k = 0; k < count; k++) {
-              uint32_t a = fprim + k;
-              float t, b1, b2;
-              if (COUNT) cnt.prim++;
-              if (tri_test(ld4(S.tris, 3 * a), ld4(S.tris, 3 * a + 1), ld4(S.tris, 3 * a + 2), r, dd, t, b1, b2)) { occ = true; return true; }
-            }
-            return false;
-          }, nobest);
+      if (tri_bih) {
+        float bt = kNoBest; uint32_t brec = CAND_NONE;
+        if (WAVE) occ = bih_tri_wave<2, COUNT>(S, rec.y, r, d, valid, stk, cnt, bt, brec);
+        else occ = bih_tri<2, COUNT>(S, rec.y, r, d, stk, cnt, bt, brec);
       } else if ((CLS & CLS_BIH_SPHERE) && cls == BC_SPHERE) {
         bih_traverse<2, COUNT>(S, rec.y, r, d, stk, stk.total_cap(), cnt,
           [&](uint32_t, uint32_t fprim, uint32_t count, float tmax) {
@@ -671,13 +896,13 @@ GD bool occluded_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt
             return false;
           }, nobest);
       }
-      if (occ) return true;
+      if (occ) { if (!WAVE) return true; result = true; valid = false; }
     } else if ((CLS & CLS_PRIMS) && kind != R_MESH && kind != R_VOID) {
       if (COUNT) cnt.prim++;
-      if (prim_shadow(S, kind, rec.y, r, d)) return true;
+      if (prim_shadow(S, kind, rec.y, r, d)) { if (!WAVE) return true; result = true; valid = false; }
     }
   }
-  return false;
+  return result;
 }
 
 // ------------------------------------------------------------------ colour algebra (Clr.hs)
@@ -719,6 +944,28 @@ GD uint32_t preshade(TIER& T, const HitG& h) {  // mpreshade, Shader.hs:65-80 (Q
       if (occ) continue;
     }
     mask |= 1u << i;
+  }
+  return mask;
+}
+
+// mpreshade for the lanes of a wave at once (`want` = this lane's hit needs its light list): the light loop is uniform,
+// so the shadow rays of one light leave together and can be walked as a packet (TIER::occluded_wave).
+template <class TIER>
+GD uint32_t preshade_wave(TIER& T, const HitG& h, bool want) {
+  uint32_t mask = 0;
+  for (int i = 0; i < T.nlights; i++) {
+    const DLight& L = T.lights[i];
+    V3 lvec = v3(L.pos[0], L.pos[1], L.pos[2]) - h.p;
+    float llen = sqrtf(vdot(lvec, lvec));
+    V3 ldir = lvec * (1.0f / llen);
+    bool lit = want && !(vdot(lvec, h.n) < 0) && !(llen > L.rad);
+    if (L.shadow) {
+      if (lit) T.cnt.shadow++;
+      Ray sr; sr.o = vscaleadd(h.p, h.n, kDel); sr.d = ldir;
+      bool occ = T.occluded_wave(sr, llen - (2 * kDel), lit);
+      lit = lit && !occ;
+    }
+    if (lit) mask |= 1u << i;
   }
   return mask;
 }
@@ -823,13 +1070,9 @@ template <int R, int MD, class TIER> struct PostFn {
   }
 };
 
-// trace, Trace.hs:59-82 (Q16)
+// trace, Trace.hs:59-82 (Q16): fold the hit's texture stack until opaque
 template <int R, bool INL, class TIER>
-GD CA trace_body(TIER& T, const Ray& ray, float tmax, int recurs, HitG* hout) {
-  HitG h = INL ? T.closest(ray, tmax) : T.closest_ni(ray, tmax);
-  if (hout) *hout = h;
-  if (!h.hit) return ca(0, 0, 0, 0);  // mmissshade: transparent (Shader.hs:186-187)
-  LightCache lc; lc.done = false; lc.mask = 0;
+GD CA shade_hit(TIER& T, const Ray& ray, const HitG& h, LightCache& lc, int recurs) {
   CA acc = ca(0, 0, 0, 0);
   TexStack ts = h.tex;
   for (int k = 0; k < kMaxTexDepth; k++) {
@@ -841,6 +1084,14 @@ GD CA trace_body(TIER& T, const Ray& ray, float tmax, int recurs, HitG* hout) {
   }
   return acc;
 }
+template <int R, bool INL, class TIER>
+GD CA trace_body(TIER& T, const Ray& ray, float tmax, int recurs, HitG* hout) {
+  HitG h = INL ? T.closest(ray, tmax) : T.closest_ni(ray, tmax);
+  if (hout) *hout = h;
+  if (!h.hit) return ca(0, 0, 0, 0);  // mmissshade: transparent (Shader.hs:186-187)
+  LightCache lc; lc.done = false; lc.mask = 0;
+  return shade_hit<R, INL>(T, ray, h, lc, recurs);
+}
 template <int R, class TIER> struct TraceFn {
   static GDN CA run(TIER& T, const Ray& ray, float tmax, int recurs) {
     if (recurs <= 0) return ca(0, 0, 0, 0);  // `trace _ _ _ _ _ 0 = traceMiss`
@@ -851,10 +1102,26 @@ template <int R, class TIER> struct TraceFn {
 template <class TIER> struct TraceFn<0, TIER> {
   static GD CA run(TIER&, const Ray&, float, int) { return ca(0, 0, 0, 0); }
 };
-// the pixel loop's entry: `Trace.trace lights shader sld ray infinity maxdepth` (Glome.hs:33), maxdepth <= kMaxTraceDepth
-template <class TIER> GD CA trace_primary(TIER& T, const Ray& ray, float tmax, int maxdepth, HitG* hout) {
+// the pixel loop's entry: `Trace.trace lights shader sld ray infinity maxdepth` (Glome.hs:33), maxdepth <= kMaxTraceDepth.
+// Called by all lanes of a wave together (`valid` = the lane has a pixel): the primary rays and, where the first
+// material of the hit is a Surface -- which always forces the light list (Trace.hs:63, Shader.hs:96) -- the shadow rays
+// are traced wave-wide; every other case (lazy light lists under Reflect / Blend, secondary rays) stays per lane.
+template <class TIER> GD CA trace_primary(TIER& T, const Ray& ray, float tmax, int maxdepth, bool valid, HitG* hout) {
   if (maxdepth <= 0) { *hout = hit_miss(); return ca(0, 0, 0, 0); }
-  return trace_body<kMaxTraceDepth, true>(T, ray, tmax, maxdepth, hout);
+  HitG h = T.closest_wave(ray, tmax, valid);
+  *hout = h;
+  LightCache lc; lc.done = false; lc.mask = 0;
+  bool eager = false;
+  if (valid && h.hit) {
+    uint32_t id = (uint32_t)(h.tex & 0xffffu);
+    if (id != 0) eager = as_u(ld4(T.S.mats, 3 * (id - 1)).x) == DM_SURFACE;
+  }
+  if (wave_any(eager)) {
+    uint32_t m = preshade_wave(T, h, eager);
+    if (eager) { lc.mask = m; lc.done = true; }
+  }
+  if (!(valid && h.hit)) return ca(0, 0, 0, 0);  // mmissshade: transparent (Shader.hs:186-187)
+  return shade_hit<kMaxTraceDepth, true>(T, ray, h, lc, maxdepth);
 }
 
 // ------------------------------------------------------------------ pixel mapping (Glome.hs:27-33, 119-140; Q19)

@@ -3,6 +3,8 @@
 // machine without a GPU, before a kernel is ever launched.  It is not part of libglome_hip.so, nothing in glome_amd
 // imports it, and bench.py never times it.  GPU parity tests (-m gpu) go through the real C ABI.
 #include <cstring>
+#include <set>
+#define GLOME_HOSTSIM_TRACE 1
 
 #include "../../glome_amd/csrc/capi_shared.hpp"
 #include "../../glome_amd/csrc/flatten.hpp"
@@ -26,6 +28,9 @@ template <bool FAITHFUL, bool COUNT, bool FULL_> struct HostFlatTier {
   Cnt cnt;
   HitG closest(const Ray& r, float tmax) { Cand c = closest_flat<FAITHFUL, COUNT, CLS_ALL>(S, r, tmax, stk, cnt); return finalize_flat<CLS_ALL>(S, r, c); }
   bool occluded(const Ray& r, float d) { return occluded_flat<COUNT, CLS_ALL>(S, r, d, stk, cnt); }
+  // on the host a wave is one lane: the packet code runs as a single-ray traversal
+  HitG closest_wave(const Ray& r, float tmax, bool valid) { Cand c = closest_flat<FAITHFUL, COUNT, CLS_ALL, true>(S, r, tmax, stk, cnt, valid); return valid ? finalize_flat<CLS_ALL>(S, r, c) : hit_miss(); }
+  bool occluded_wave(const Ray& r, float d, bool valid) { return occluded_flat<COUNT, CLS_ALL, true>(S, r, d, stk, cnt, valid); }
   HitG closest_ni(const Ray& r, float tmax) { return closest(r, tmax); }
   bool occluded_ni(const Ray& r, float d) { return occluded(r, d); }
 };
@@ -40,6 +45,8 @@ struct HostGenericTier {
   bool occluded(const Ray& r, float d) { GCtx<true> g{S, cnt, err}; bool o = shadow_g<kGenericDepth>(g, S.recs[S.root_rec], r, d); err = g.err; return o; }
   HitG closest_ni(const Ray& r, float tmax) { return closest(r, tmax); }
   bool occluded_ni(const Ray& r, float d) { return occluded(r, d); }
+  HitG closest_wave(const Ray& r, float tmax, bool valid) { return valid ? closest(r, tmax) : hit_miss(); }
+  bool occluded_wave(const Ray& r, float d, bool valid) { return valid && occluded(r, d); }
 };
 
 struct HostStack {
@@ -90,8 +97,8 @@ int hostsim_rayint(void* sv, int tier, int analysis, size_t n, const float* ox, 
     Ray r; r.o = v3(ox[i], oy[i], oz[i]); r.d = v3(dx[i], dy[i], dz[i]);
     HitG h;
     if (tier == 0) {
-      if (analysis) { HostFlatTier<true, true, false> T{s->D, nullptr, 0, hs.lane(kFlatStack), Cnt()}; h = T.closest(r, tmax[i]); total.bih += T.cnt.bih; total.prim += T.cnt.prim; total.mesh += T.cnt.mesh; }
-      else { HostFlatTier<false, false, false> T{s->D, nullptr, 0, hs.lane(kFlatStack), Cnt()}; h = T.closest(r, tmax[i]); }
+      if (analysis & 1) { HostFlatTier<true, true, false> T{s->D, nullptr, 0, hs.lane(kFlatStack), Cnt()}; h = (analysis & 2) ? T.closest_wave(r, tmax[i], true) : T.closest(r, tmax[i]); total.bih += T.cnt.bih; total.prim += T.cnt.prim; total.mesh += T.cnt.mesh; }
+      else { HostFlatTier<false, false, false> T{s->D, nullptr, 0, hs.lane(kFlatStack), Cnt()}; h = (analysis & 2) ? T.closest_wave(r, tmax[i], true) : T.closest(r, tmax[i]); }
     } else {
       HostGenericTier T{s->D, nullptr, 0, Cnt()};
       h = T.closest(r, tmax[i]);
@@ -143,8 +150,8 @@ int hostsim_render(void* sv, int tier, const float* cam, const float* lights, in
       get_coordsf(width, height, (float)px, (float)py, xc, yc);
       Ray ray = primary_ray(C, xc, yc);
       HitG h; CA c;
-      if (tier == 0) { HostFlatTier<false, false, true> T{s->D, L, nl, hs.lane(kFlatStack), Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, &h); total.shadow += T.cnt.shadow; total.secondary += T.cnt.secondary; }
-      else { HostGenericTier T{s->D, L, nl, Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, &h); err |= T.err; total.shadow += T.cnt.shadow; total.secondary += T.cnt.secondary; }
+      if (tier == 0) { HostFlatTier<false, false, true> T{s->D, L, nl, hs.lane(kFlatStack), Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, true, &h); total.shadow += T.cnt.shadow; total.secondary += T.cnt.secondary; }
+      else { HostGenericTier T{s->D, L, nl, Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, true, &h); err |= T.err; total.shadow += T.cnt.shadow; total.secondary += T.cnt.secondary; }
       float* o = out5 + ((size_t)py * width + px) * 5;
       o[0] = c.r; o[1] = c.g; o[2] = c.b; o[3] = c.a; o[4] = h.hit ? h.t : kInf;
     }
@@ -182,6 +189,43 @@ int hostsim_block_work(void* sv, const float* cam, const float* light_pos, int w
   return 0;
 }
 
+// EXPERIMENT: what a wave-wide packet would visit = the union of its lanes' visited nodes / tested triangles.
+// out[block][8]: primary: max_lane(nodes+tris), union nodes, union tris, sum nodes, sum tris ; shadow the same in a second row
+int hostsim_packet_union(void* sv, const float* cam, const float* light_pos, int width, int height, int bx0, int by0, int nbx, int nby, int* out) {
+  SimScene* s = (SimScene*)sv;
+  DCamera C; memcpy(&C, cam, sizeof(C));
+  HostStack hs;
+  for (int by = 0; by < nby; by++) for (int bx = 0; bx < nbx; bx++) {
+    std::set<uint32_t> un[2], ut[2]; long sn[2] = {0, 0}, st[2] = {0, 0}; int mx[2] = {0, 0}; int nsh = 0;
+    for (int lane = 0; lane < 64; lane++) {
+      int px = (bx0 + bx) * 8 + (lane & 7), py = (by0 + by) * 8 + (lane >> 3);
+      float xc, yc; get_coordsf(width, height, (float)px, (float)py, xc, yc);
+      Ray ray = primary_ray(C, xc, yc);
+      std::vector<uint32_t> vn, vt; g_trace_nodes = &vn; g_trace_tris = &vt;
+      HostFlatTier<false, false, false> T{s->D, nullptr, 0, hs.lane(kFlatStack), Cnt()};
+      HitG h = T.closest(ray, kInf);
+      un[0].insert(vn.begin(), vn.end()); ut[0].insert(vt.begin(), vt.end()); sn[0] += vn.size(); st[0] += vt.size();
+      mx[0] = std::max(mx[0], (int)(vn.size() + vt.size()));
+      if (h.hit) {
+        V3 lvec = v3(light_pos[0], light_pos[1], light_pos[2]) - h.p;
+        if (!(vdot(lvec, h.n) < 0)) {
+          float llen = sqrtf(vdot(lvec, lvec));
+          Ray sr; sr.o = vscaleadd(h.p, h.n, kDel); sr.d = lvec * (1.0f / llen);
+          vn.clear(); vt.clear();
+          HostFlatTier<false, false, false> T2{s->D, nullptr, 0, hs.lane(kFlatStack), Cnt()};
+          T2.occluded(sr, llen - 2 * kDel);
+          un[1].insert(vn.begin(), vn.end()); ut[1].insert(vt.begin(), vt.end()); sn[1] += vn.size(); st[1] += vt.size();
+          mx[1] = std::max(mx[1], (int)(vn.size() + vt.size())); nsh++;
+        }
+      }
+      g_trace_nodes = nullptr; g_trace_tris = nullptr;
+    }
+    int* o = out + (size_t)(by * nbx + bx) * 12;
+    for (int k = 0; k < 2; k++) { o[k * 6 + 0] = mx[k]; o[k * 6 + 1] = (int)un[k].size(); o[k * 6 + 2] = (int)ut[k].size(); o[k * 6 + 3] = (int)sn[k]; o[k * 6 + 4] = (int)st[k]; o[k * 6 + 5] = k ? nsh : 64; }
+  }
+  return 0;
+}
+
 // renderTileSubsample through the device headers' pass helpers (ss_candidate / ss_neighbours / ccmp / cavg / blend),
 // executed sequentially tile by tile.  Mirrors subsample_tile() in glome_device.hip.
 int hostsim_render_subsample(void* sv, int tier, const float* cam, const float* lights, int nl, int width, int height, int maxdepth, int blocksize,
@@ -200,8 +244,8 @@ int hostsim_render_subsample(void* sv, int tier, const float* cam, const float* 
     Ray ray = primary_ray(C, xc, yc);
     HitG h; CA c;
     nprim++;
-    if (tier == 0) { HostFlatTier<false, false, true> T{s->D, L, nl, hs.lane(kFlatStack), Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, &h); nshadow += T.cnt.shadow; nsec += T.cnt.secondary; }
-    else { HostGenericTier T{s->D, L, nl, Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, &h); err |= T.err; nshadow += T.cnt.shadow; nsec += T.cnt.secondary; }
+    if (tier == 0) { HostFlatTier<false, false, true> T{s->D, L, nl, hs.lane(kFlatStack), Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, true, &h); nshadow += T.cnt.shadow; nsec += T.cnt.secondary; }
+    else { HostGenericTier T{s->D, L, nl, Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, true, &h); err |= T.err; nshadow += T.cnt.shadow; nsec += T.cnt.secondary; }
     return tc(c.r, c.g, c.b, c.a, h.hit ? h.t : kInf);
   };
   for (int xt = 0; xt < width;) {
