@@ -44,12 +44,21 @@ struct FlatTier {
     return finalize_flat<CLS>(S, r, c);
   }
   __device__ __forceinline__ bool occluded(const Ray& r, float d) { return occluded_flat<COUNT, CLS>(S, r, d, stk, cnt); }
-  // wave-wide calls (every lane of the wave makes them together; `valid` = the lane holds a ray)
+  // wave-wide calls (every lane of the wave makes them together; `valid` = the lane holds a ray).  Triangle BIHs are
+  // walked as packets in the lean kernels; kernels with out-of-line shader calls (FULL) keep the per-lane walk.
+  static constexpr bool PACKETS = !FULL_ && (CLS & CLS_BIH_TRI) != 0;
   __device__ __forceinline__ HitG closest_wave(const Ray& r, float tmax, bool valid) {
-    Cand c = closest_flat<FAITHFUL, COUNT, CLS, true>(S, r, tmax, stk, cnt, valid);
-    return valid ? finalize_flat<CLS>(S, r, c) : hit_miss();
+    if constexpr (PACKETS) {
+      Cand c = closest_flat<FAITHFUL, COUNT, CLS, true>(S, r, tmax, stk, cnt, valid);
+      return valid ? finalize_flat<CLS>(S, r, c) : hit_miss();
+    } else {
+      return valid ? closest(r, tmax) : hit_miss();
+    }
   }
-  __device__ __forceinline__ bool occluded_wave(const Ray& r, float d, bool valid) { return occluded_flat<COUNT, CLS, true>(S, r, d, stk, cnt, valid); }
+  __device__ __forceinline__ bool occluded_wave(const Ray& r, float d, bool valid) {
+    if constexpr (PACKETS) return occluded_flat<COUNT, CLS, true>(S, r, d, stk, cnt, valid);
+    else return valid && occluded(r, d);
+  }
   __device__ __noinline__ HitG closest_ni(const Ray& r, float tmax) { return closest(r, tmax); }
   __device__ __noinline__ bool occluded_ni(const Ray& r, float d) { return occluded(r, d); }
 };

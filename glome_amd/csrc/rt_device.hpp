@@ -75,22 +75,37 @@ GD U4 ldu4(const U4* p, uint32_t i) { return p[i]; }
 // The packet traversal below keeps its control flow uniform across the 64 lanes of a wave: votes decide where the wave
 // goes, every lane follows.  Compiled for the host (tests/hostsim) a "wave" is one lane, and the same code is a
 // single-ray traversal.
+typedef unsigned long long LaneMask;  // one bit per lane of the wave
 #if defined(__HIPCC__)
-GD unsigned long long wave_ballot(bool p) { return __ballot(p); }
+GD LaneMask wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 GD bool wave_any(bool p) { return __ballot(p) != 0ull; }
+GD bool lane_of(LaneMask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }  // this lane's bit (m is wave-uniform)
 GD uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }  // a value every lane agrees on -> SGPR
-// loads at a wave-uniform index through the constant address space, so they can be scalar loads (s_load_dwordx4)
+GD LaneMask uni(LaneMask m) { return (LaneMask)uni((uint32_t)m) | ((LaneMask)uni((uint32_t)(m >> 32)) << 32); }
+// loads at a wave-uniform index through the constant address space with a 32-bit byte offset, so they become scalar
+// loads (s_load_dwordx4 sdst, sbase, soffset); `i` counts 16-byte words and the pools are far below 4 GiB
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const f32x4 __attribute__((address_space(4))) cf32x4;
 GD F4 ld4u(const F4* p, uint32_t i) {
-  const f32x4 __attribute__((address_space(4)))* q = (const f32x4 __attribute__((address_space(4)))*)(uintptr_t)p;
-  f32x4 v = q[uni(i)];
+  const char __attribute__((address_space(4)))* b = (const char __attribute__((address_space(4)))*)(uintptr_t)p;
+  f32x4 v = *(cf32x4*)(b + (uint32_t)(uni(i) << 4));
   F4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r;
 }
+// the 48-byte triangle record at a uniform index: one address, three loads at immediate offsets
+GD void ld_tri_u(const F4* p, uint32_t tri, F4& q0, F4& q1, F4& q2) {
+  const char __attribute__((address_space(4)))* b = (const char __attribute__((address_space(4)))*)(uintptr_t)p;
+  cf32x4* q = (cf32x4*)(b + (uint32_t)(uni(tri) * 48u));
+  f32x4 a = q[0], c = q[1], e = q[2];
+  q0.x = a.x; q0.y = a.y; q0.z = a.z; q0.w = a.w; q1.x = c.x; q1.y = c.y; q1.z = c.z; q1.w = c.w; q2.x = e.x; q2.y = e.y; q2.z = e.z; q2.w = e.w;
+}
 #else
-GD unsigned long long wave_ballot(bool p) { return p ? 1ull : 0ull; }
+GD LaneMask wave_ballot(bool p) { return p ? 1ull : 0ull; }
 GD bool wave_any(bool p) { return p; }
+GD bool lane_of(LaneMask m) { return (m & 1ull) != 0; }
 GD uint32_t uni(uint32_t v) { return v; }
+GD LaneMask uni(LaneMask m) { return m; }
 GD F4 ld4u(const F4* p, uint32_t i) { return p[i]; }
+GD void ld_tri_u(const F4* p, uint32_t tri, F4& q0, F4& q1, F4& q2) { q0 = p[3 * tri]; q1 = p[3 * tri + 1]; q2 = p[3 * tri + 2]; }
 #endif
 
 // texture stacks: 4 x 16 bit, innermost first, id+1 (rt_types.h)
@@ -381,6 +396,26 @@ struct LaneStack {
   static constexpr int STRIDE = 1;
 #endif
   GD int total_cap() const { return cap + ovf_cap; }
+  // Packet entries (bih_tri_wave): the node reference and the mask of lanes that want the entry are wave-uniform; they
+  // ride in the `node` row -- lane 0's word is the reference, lanes 1 and 2 hold the mask -- next to every lane's own
+  // (near, far).  On the host a wave is one lane and the mask is one bit, kept in bit 31 of the reference.
+#if defined(__HIPCC__)
+  GD void push_wave(int sp, uint32_t ref, LaneMask m, float a, float b) {
+    uint32_t w = ref;
+    asm("v_writelane_b32 %0, %1, 1" : "+v"(w) : "s"((uint32_t)m));
+    asm("v_writelane_b32 %0, %1, 2" : "+v"(w) : "s"((uint32_t)(m >> 32)));
+    push(sp, w, a, b);
+  }
+  GD void pop_wave(int sp, uint32_t& ref, LaneMask& m, float& a, float& b) const {
+    uint32_t w;
+    pop(sp, w, a, b);
+    ref = (uint32_t)__builtin_amdgcn_readlane((int)w, 0);
+    m = (LaneMask)(uint32_t)__builtin_amdgcn_readlane((int)w, 1) | ((LaneMask)(uint32_t)__builtin_amdgcn_readlane((int)w, 2) << 32);
+  }
+#else
+  GD void push_wave(int sp, uint32_t ref, LaneMask m, float a, float b) { push(sp, ref | ((uint32_t)(m & 1ull) << 31), a, b); }
+  GD void pop_wave(int sp, uint32_t& ref, LaneMask& m, float& a, float& b) const { uint32_t w; pop(sp, w, a, b); ref = w & 0x7fffffffu; m = w >> 31; }
+#endif
 #if defined(__HIPCC__)
   // The overflow column is spill traffic (non-temporal).  The empty asm pins the overflow loads inside their branch:
   // without it the compiler sinks both branches' loads into one access through a generic (flat) pointer, and every
@@ -588,82 +623,76 @@ GD bool bih_tri(const DScene& S, uint32_t hdr, const Ray& r, float d, STK& stk, 
 // `valid`: the lane holds a ray.  All lanes of the wave must make this call together.
 template <int MODE, bool COUNT, class STK>
 GD bool bih_tri_wave(const DScene& S, uint32_t hdr, const Ray& r, float d, bool valid, STK& stk, Cnt& cnt, float& best_t, uint32_t& best_rec) {
-  const float kOut = __builtin_huge_valf();
   hdr = uni(hdr);
   F4 h0 = ld4u(S.bihhdr, 3 * hdr), h1 = ld4u(S.bihhdr, 3 * hdr + 1);
   const uint32_t delta = uni(as_u(ld4u(S.bihhdr, 3 * hdr + 2).x));
   uint32_t ref = uni(as_u(h0.w));
   const V3 rcp = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
-  const unsigned long long vm = wave_ballot(valid);
-  const unsigned long long sx = wave_ballot(valid && rcp.x > 0), sy = wave_ballot(valid && rcp.y > 0), sz = wave_ballot(valid && rcp.z > 0);
+  const LaneMask vm = wave_ballot(valid);
+  const LaneMask sx = wave_ballot(valid && rcp.x > 0), sy = wave_ballot(valid && rcp.y > 0), sz = wave_ballot(valid && rcp.z > 0);
   const bool packet = !(ref & BREF_LEAF) && (sx == 0 || sx == vm) && (sy == 0 || sy == vm) && (sz == 0 || sz == vm);
   if (!packet) return valid ? bih_tri<MODE, COUNT>(S, hdr, r, d, stk, cnt, best_t, best_rec) : false;
-  const bool fx = sx != 0, fy = sy != 0, fz = sz != 0;
+  const uint32_t fwdbits = uni((sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u));  // per axis: do the rays run towards +axis
   float nearv, farv;
   bbclip_ub(r, v3(h0), v3(h1), nearv, farv);
   farv = gminf(d, farv);  // `traverse root near (fmin d far)`, Bih.hs:368
-  if (!valid || nearv > farv) {
-    if (COUNT && valid) cnt.bih++;  // the root branch is entered, counted and left (Bih.hs:343)
-    nearv = kOut; farv = -kOut;
-  }
+  // `am`: the lanes whose ray has a non-empty interval in the current node.  Their (near, far) are live; the other
+  // lanes' are don't-cares, so no sentinel values are needed and plain min / max serve (a NaN plane distance only
+  // arises on a lane that fails the activity test of that child).
+  LaneMask am = wave_ballot(valid && !(nearv > farv));
+  if (COUNT) { if (valid && nearv > farv) cnt.bih++; }  // a root branch entered with an empty interval is counted and left (Bih.hs:343)
   const int cap = stk.total_cap();
   int sp = 0;
-  bool occ = false;
-  for (;;) {
-    bool popit;
+  LaneMask occm = 0;  // MODE 2: lanes that found an occluder
+  if (am != 0) for (;;) {
+    ref = uni(ref); am = uni(am); sp = (int)uni((uint32_t)sp);  // wave-uniform by construction: keep them in SGPRs
     if (!(ref & BREF_LEAF)) {
       F4 n = ld4u(S.bihnodes, ref);
       const uint32_t w0 = uni(as_u(n.z)), right = uni(as_u(n.w));
       const uint32_t axis = w0 & 3u, left = w0 >> 2;
       const float dirr = axis == 0 ? rcp.x : (axis == 1 ? rcp.y : rcp.z), o = axis == 0 ? r.o.x : (axis == 1 ? r.o.y : r.o.z);
-      const bool fwd = axis == 0 ? fx : (axis == 1 ? fy : fz);
+      const bool fwd = (fwdbits >> axis) & 1u;
       const float dl = (n.x - o) * dirr, dr = (n.y - o) * dirr;
       const uint32_t c1 = fwd ? left : right, c2 = fwd ? right : left;
       const float t1 = fwd ? dl : dr, t2 = fwd ? dr : dl;  // near child ends at t1, far child starts at t2
-      if (COUNT) { if (!(nearv > farv)) cnt.bih++; }
-      const bool a1 = nearv < t1, a2 = t2 < farv;           // an inactive lane fails both
-      const bool go1 = (c1 != BREF_LEAF) && wave_any(a1), go2 = (c2 != BREF_LEAF) && wave_any(a2);
-      const float n1 = a1 ? nearv : kOut, f1 = a1 ? gminf(t1, farv) : -kOut;
-      const float n2 = a2 ? gmaxf(t2, nearv) : kOut, f2 = a2 ? farv : -kOut;
-      if (go1) {
-        if (go2 && sp < cap) { stk.push(sp, c2, n2, f2); sp++; }
-        ref = c1; nearv = n1; farv = f1;
-      } else {
-        ref = c2; nearv = n2; farv = f2;
+      if (COUNT) { if (lane_of(am)) cnt.bih++; }
+      // an empty leaf holds nothing to test: it is never visited (no effect on results or on the branch counts)
+      const LaneMask m1 = c1 != BREF_LEAF ? (wave_ballot(nearv < t1) & am) : 0ull;
+      const LaneMask m2 = c2 != BREF_LEAF ? (wave_ballot(t2 < farv) & am) : 0ull;
+      const float f1 = fminf(t1, farv), n2 = fmaxf(t2, nearv);
+      if (m1 != 0) {
+        if (m2 != 0 && sp < cap) { stk.push_wave(sp, c2, m2, n2, farv); sp++; }
+        ref = c1; farv = f1; am = m1;
+        continue;
       }
-      popit = !(go1 || go2);
+      if (m2 != 0) { ref = c2; nearv = n2; am = m2; continue; }
     } else {
       uint32_t count = (ref >> 26) & 7u, first = ref & BREF_FIRST;
       if (count == 7u) { F4 ln = ld4u(S.bihnodes, first); count = uni(as_u(ln.z)); first = uni(as_u(ln.w)); }
+      F4 q0, q1, q2;
+      if (count != 0u) ld_tri_u(S.tris, first + delta, q0, q1, q2);
       for (uint32_t k = 0; k < count; k++) {
-        const uint32_t a = first + k + delta;
-        F4 q0 = ld4u(S.tris, 3 * a), q1 = ld4u(S.tris, 3 * a + 1), q2 = ld4u(S.tris, 3 * a + 2);
+        F4 p0 = q0, p1 = q1, p2 = q2;
+        if (k + 1 < count) ld_tri_u(S.tris, first + delta + k + 1, q0, q1, q2);  // the next record is on its way while this one is tested
         float t, b1, b2;
-        const bool act = !(nearv > farv);
-        if (COUNT) { if (act) cnt.prim++; }
+        if (COUNT) { if (lane_of(am)) cnt.prim++; }
         // tmax = far (Bih.hs:339; shadow: `fmin d far`, Bih.hs:515 -- far <= d already); MODE 1: far <= best_t
-        const bool hit = tri_test(q0, q1, q2, r, farv, t, b1, b2) && act;
-        if (MODE == 2) { if (hit) { occ = true; nearv = kOut; farv = -kOut; } }
+        const bool hit = tri_test(p0, p1, p2, r, farv, t, b1, b2) && lane_of(am);
+        if (MODE == 2) { const LaneMask hm = wave_ballot(hit); occm |= hm; am &= ~hm; }
         else if (hit && !(best_t < t)) { best_t = t; best_rec = first + k; if (MODE == 1) farv = gminf(farv, t); }
       }
-      popit = true;
     }
-    if (popit) {
-      // pop until an entry some lane still wants (MODE 1: `far` may have shrunk since the push; MODE 2: lanes retire)
-      bool found = false;
-      while (sp > 0 && !found) {
-        sp--;
-        uint32_t pr;
-        stk.pop(sp, pr, nearv, farv);
-        ref = uni(pr);
-        if (MODE == 1) { farv = gminf(farv, best_t); if (nearv > farv) { nearv = kOut; farv = -kOut; } }
-        if (MODE == 2) { if (occ) { nearv = kOut; farv = -kOut; } }
-        found = wave_any(!(nearv > farv));
-      }
-      if (!found) break;
+    // pop until an entry some lane still wants (MODE 1: `far` may have shrunk since the push; MODE 2: lanes retire)
+    am = 0;
+    while (sp > 0 && am == 0) {
+      sp--;
+      stk.pop_wave(sp, ref, am, nearv, farv);
+      if (MODE == 1) { farv = gminf(farv, best_t); am &= wave_ballot(!(nearv > farv)); }
+      if (MODE == 2) am &= ~occm;
     }
+    if (am == 0) break;
   }
-  return occ;
+  return MODE == 2 ? lane_of(occm) : false;
 }
 
 // ------------------------------------------------------------------ Mesh 2-box BVH (Mesh.hs:136-198; Q12)
