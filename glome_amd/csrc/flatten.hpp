@@ -2,6 +2,7 @@
 // This is the "Haskell host flattens the scene graph to packed SoA device buffers" step; it is pure host
 // code (no HIP) so the layout can be inspected and tested without a GPU.
 #pragma once
+#include <limits>
 #include <cstring>
 #include <map>
 #include <unordered_map>
@@ -283,7 +284,12 @@ class Flattener {
     for (size_t k = 0; k < T.nodes.size(); k++) {
       const BihTree::Node& bn = T.nodes[k];
       if (bn.leaf) continue;
-      F.bihnodes[base + k] = F4{round_up(bn.lsplit), round_down(bn.rsplit), as_float_bits((uint32_t)bn.axis | (ref[bn.left] << 2)), as_float_bits(ref[bn.right])};
+      // A child that is an empty leaf (a quarter of the leaves the reference builder makes) gets a plane at -inf / +inf:
+      // the interval tests of the traversal (`near < t1`, `t2 < far`) then fail for it whatever the ray, so the device
+      // never enters it and needs no test for it.  The other child's interval does not depend on this plane.
+      const float inf = std::numeric_limits<float>::infinity();
+      float ls = ref[bn.left] == BREF_LEAF_BIT ? -inf : round_up(bn.lsplit), rs = ref[bn.right] == BREF_LEAF_BIT ? inf : round_down(bn.rsplit);
+      F.bihnodes[base + k] = F4{ls, rs, as_float_bits((uint32_t)bn.axis | (ref[bn.left] << 2)), as_float_bits(ref[bn.right])};
     }
     F.bihhdr[3 * hdr] = mk4u(round_down(T.bb.lo.x), round_down(T.bb.lo.y), round_down(T.bb.lo.z), ref[0]);
     F.bihhdr[3 * hdr + 1] = mk4u(round_up(T.bb.hi.x), round_up(T.bb.hi.y), round_up(T.bb.hi.z), cls);

@@ -48,6 +48,14 @@ struct FlatTier {
   // walked as packets in the lean kernels; kernels with out-of-line shader calls (FULL) keep the per-lane walk.
   static constexpr bool PACKETS = !FULL_ && (CLS & CLS_BIH_TRI) != 0;
   __device__ __forceinline__ HitG closest_wave(const Ray& r, float tmax, bool valid) {
+#if defined(GLOME_EXP_TIMING)
+    unsigned long long t0 = __builtin_readcyclecounter();
+    Cand c0 = closest_flat<FAITHFUL, COUNT, CLS, true>(S, r, tmax, stk, cnt, valid);
+    unsigned long long t1 = __builtin_readcyclecounter();
+    HitG hh = valid ? finalize_flat<CLS>(S, r, c0) : hit_miss();
+    if ((threadIdx.x & 63) == 0) cnt.bih += (uint32_t)(t1 - t0);
+    return hh;
+#endif
     if constexpr (PACKETS) {
       Cand c = closest_flat<FAITHFUL, COUNT, CLS, true>(S, r, tmax, stk, cnt, valid);
       return valid ? finalize_flat<CLS>(S, r, c) : hit_miss();
@@ -56,6 +64,13 @@ struct FlatTier {
     }
   }
   __device__ __forceinline__ bool occluded_wave(const Ray& r, float d, bool valid) {
+#if defined(GLOME_EXP_TIMING)
+    unsigned long long t0 = __builtin_readcyclecounter();
+    bool oo = occluded_flat<COUNT, CLS, true>(S, r, d, stk, cnt, valid);
+    unsigned long long t1 = __builtin_readcyclecounter();
+    if ((threadIdx.x & 63) == 0) cnt.prim += (uint32_t)(t1 - t0);
+    return oo;
+#endif
     if constexpr (PACKETS) return occluded_flat<COUNT, CLS, true>(S, r, d, stk, cnt, valid);
     else return valid && occluded(r, d);
   }
@@ -161,6 +176,9 @@ __device__ __forceinline__ void render_loop(const DRenderArgs& A, TIER& T) {
     if (lane == 0) w = atomicAdd(&A.counters->next_work, 1u);
     w = __shfl(w, 0, 64);
     if (w >= A.total_waves) break;
+#if defined(GLOME_EXP_TIMING)
+    unsigned long long tw0 = __builtin_readcyclecounter();
+#endif
     int px = 0, py = 0;
     size_t dense_off = 0;
     const bool valid = work_to_pixel(A, w, lane, px, py, dense_off);  // lanes past the end of a leftover strip idle along
@@ -178,6 +196,9 @@ __device__ __forceinline__ void render_loop(const DRenderArgs& A, TIER& T) {
     float* out = A.out5 + o * 5;
     out[0] = r; out[1] = c.g; out[2] = c.b; out[3] = c.a; out[4] = depth;
     if (A.packed) A.packed[o] = rgbf(r * c.a, c.g * c.a, c.b * c.a);  // blitTile (Glome.hs:353-358)
+#if defined(GLOME_EXP_TIMING)
+    if (lane == 0) T.cnt.mesh += (uint32_t)(__builtin_readcyclecounter() - tw0);
+#endif
   }
 }
 

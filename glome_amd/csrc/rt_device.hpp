@@ -76,6 +76,15 @@ GD U4 ldu4(const U4* p, uint32_t i) { return p[i]; }
 // goes, every lane follows.  Compiled for the host (tests/hostsim) a "wave" is one lane, and the same code is a
 // single-ray traversal.
 typedef unsigned long long LaneMask;  // one bit per lane of the wave
+// min / max of values that are known not to be NaN where it matters: one instruction, without the quieting moves the
+// compiler puts in front of fminf / fmaxf on values it cannot see the origin of
+#if defined(__HIPCC__)
+GD float min_nn(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+GD float max_nn(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+#else
+GD float min_nn(float a, float b) { return fminf(a, b); }
+GD float max_nn(float a, float b) { return fmaxf(a, b); }
+#endif
 #if defined(__HIPCC__)
 GD LaneMask wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 GD bool wave_any(bool p) { return __ballot(p) != 0ull; }
@@ -91,8 +100,20 @@ GD F4 ld4u(const F4* p, uint32_t i) {
   f32x4 v = *(cf32x4*)(b + (uint32_t)(uni(i) << 4));
   F4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r;
 }
+// the same uniform fetch through the vector memory path (every lane reads the same 16 bytes: one request)
+GD F4 ld4v(const F4* p, uint32_t i) { return p[uni(i)]; }
+#if defined(GLOME_EXP_NODE_VMEM)
+#define LD_NODE ld4v
+#else
+#define LD_NODE ld4u
+#endif
 // the 48-byte triangle record at a uniform index: one address, three loads at immediate offsets
 GD void ld_tri_u(const F4* p, uint32_t tri, F4& q0, F4& q1, F4& q2) {
+#if defined(GLOME_EXP_TRI_VMEM)
+  const F4* t = p + 3 * (size_t)uni(tri);
+  q0 = t[0]; q1 = t[1]; q2 = t[2];
+  return;
+#endif
   const char __attribute__((address_space(4)))* b = (const char __attribute__((address_space(4)))*)(uintptr_t)p;
   cf32x4* q = (cf32x4*)(b + (uint32_t)(uni(tri) * 48u));
   f32x4 a = q[0], c = q[1], e = q[2];
@@ -105,6 +126,7 @@ GD bool lane_of(LaneMask m) { return (m & 1ull) != 0; }
 GD uint32_t uni(uint32_t v) { return v; }
 GD LaneMask uni(LaneMask m) { return m; }
 GD F4 ld4u(const F4* p, uint32_t i) { return p[i]; }
+#define LD_NODE ld4u
 GD void ld_tri_u(const F4* p, uint32_t tri, F4& q0, F4& q1, F4& q2) { q0 = p[3 * tri]; q1 = p[3 * tri + 1]; q2 = p[3 * tri + 2]; }
 #endif
 
@@ -527,6 +549,7 @@ GD void bih_traverse(const DScene& S, uint32_t hdr, const Ray& r, float d, STK& 
 // non-empty when a child is chosen; only an entry popped after `far` has shrunk (MODE 1) can be stale, and that is checked
 // at the pop.  best_t / best_rec: running nearest hit (best_t = kNoBest when none); MODE 2 returns true at the first occluder.
 constexpr float kNoBest = 3.0e38f;
+constexpr uint32_t kNoRec = 0xffffffffu;  // == CAND_NONE below
 #if defined(GLOME_HOSTSIM_TRACE)
 #include <vector>
 static thread_local std::vector<uint32_t>* g_trace_nodes = nullptr; static thread_local std::vector<uint32_t>* g_trace_tris = nullptr;
@@ -621,12 +644,91 @@ GD bool bih_tri(const DScene& S, uint32_t hdr, const Ray& r, float d, STK& stk, 
 // when they do not (a block straddling an axis plane through the eye), or the root is a leaf, the lanes fall back to
 // bih_tri.  Results, tie order and work counters are identical to the per-lane traversal.
 // `valid`: the lane holds a ray.  All lanes of the wave must make this call together.
+// The packet loop proper.  Every branch in it is wave-uniform (the per-lane decisions are selects), and it takes and
+// returns everything by value, so it can be compiled as a function of its own with plain scalar control flow.
+struct PacketResult { float best_t; uint32_t best_rec; uint32_t occ_lo, occ_hi, n_bih, n_prim; };
+#if defined(GLOME_EXP_PACKET_NOINLINE)
+#define GPK GDN
+#else
+#define GPK GD
+#endif
+template <int MODE, bool COUNT, class STK>
+GPK PacketResult bih_tri_packet(const F4* nodes, const F4* tris, uint32_t ref, uint32_t delta, uint32_t fwdbits, uint32_t am_lo, uint32_t am_hi,
+                                float nearv, float farv, V3 ro, V3 rd, V3 rcp, float best_t, STK stk) {
+  ref = uni(ref); delta = uni(delta); fwdbits = uni(fwdbits);
+  LaneMask am = uni((LaneMask)am_lo | ((LaneMask)am_hi << 32));
+  Ray r; r.o = ro; r.d = rd;
+  PacketResult R; R.best_t = best_t; R.best_rec = kNoRec; R.n_bih = 0; R.n_prim = 0;
+  int sp = 0;
+  LaneMask occm = 0;  // MODE 2: lanes that found an occluder
+  for (;;) {
+    // ---- branch steps: walk down while the reference is a branch
+    while (!(ref & BREF_LEAF)) {
+      ref = uni(ref); am = uni(am); sp = (int)uni((uint32_t)sp);  // wave-uniform by construction: keep them in SGPRs
+      F4 n = LD_NODE(nodes, ref);
+      const uint32_t w0 = uni(as_u(n.z)), right = uni(as_u(n.w));
+      const uint32_t axis = w0 & 3u, left = w0 >> 2;
+      float dl, dr;  // distances to the two planes along the ray; the axis is wave-uniform: a scalar branch, no selects
+      if (axis == 0) { dl = (n.x - r.o.x) * rcp.x; dr = (n.y - r.o.x) * rcp.x; }
+      else if (axis == 1) { dl = (n.x - r.o.y) * rcp.y; dr = (n.y - r.o.y) * rcp.y; }
+      else { dl = (n.x - r.o.z) * rcp.z; dr = (n.y - r.o.z) * rcp.z; }
+      const bool fwd = (fwdbits >> axis) & 1u;
+      const uint32_t c1 = fwd ? left : right, c2 = fwd ? right : left;
+      const float t1 = fwd ? dl : dr, t2 = fwd ? dr : dl;  // near child ends at t1, far child starts at t2
+      if (COUNT) R.n_bih += lane_of(am) ? 1u : 0u;
+      // (an empty leaf child has its plane at -+inf, flatten.hpp: both tests fail for it, it is never entered)
+      const LaneMask m1 = wave_ballot(nearv < t1) & am;
+      const LaneMask m2 = wave_ballot(t2 < farv) & am;
+      const float f1 = min_nn(t1, farv), n2 = max_nn(t2, nearv);
+      if ((m1 != 0) & (m2 != 0)) { stk.push_wave(sp, c2, m2, n2, farv); sp++; }  // depth <= capacity (validated at commit)
+      const bool g1 = m1 != 0;
+      ref = g1 ? c1 : c2;
+      am = g1 ? m1 : m2;
+      farv = g1 ? f1 : farv;
+      nearv = g1 ? nearv : n2;
+      if (am == 0) break;
+    }
+    // ---- a leaf (entered with am != 0), or nothing left below the last branch (am == 0)
+    if (am != 0) {
+      ref = uni(ref);
+      uint32_t count = (ref >> 26) & 7u, first = ref & BREF_FIRST;
+      if (count == 7u) { F4 ln = ld4u(nodes, first); count = uni(as_u(ln.z)); first = uni(as_u(ln.w)); }
+      for (uint32_t k = 0; k < count; k++) {
+        F4 p0, p1, p2;
+        ld_tri_u(tris, first + delta + k, p0, p1, p2);
+        float t, b1, b2;
+        if (COUNT) R.n_prim += lane_of(am) ? 1u : 0u;
+        // tmax = far (Bih.hs:339; shadow: `fmin d far`, Bih.hs:515 -- far <= d already); MODE 1: far <= best_t
+        const bool hit = tri_test(p0, p1, p2, r, farv, t, b1, b2) && lane_of(am);
+        if (MODE == 2) { const LaneMask hm = wave_ballot(hit); occm |= hm; am &= ~hm; }
+        else {
+          const bool acc = hit && !(R.best_t < t);  // selects, not a branch
+          R.best_t = acc ? t : R.best_t;
+          R.best_rec = acc ? first + k : R.best_rec;
+          if (MODE == 1) farv = acc ? gminf(farv, t) : farv;
+        }
+      }
+    }
+    // ---- pop until an entry some lane still wants (MODE 1: `far` may have shrunk since the push; MODE 2: lanes retire)
+    am = 0;
+    while (sp > 0 && am == 0) {
+      sp--;
+      stk.pop_wave(sp, ref, am, nearv, farv);
+      if (MODE == 1) { farv = gminf(farv, R.best_t); am &= wave_ballot(!(nearv > farv)); }
+      if (MODE == 2) am &= ~occm;
+    }
+    if (am == 0) break;
+  }
+  R.occ_lo = (uint32_t)occm; R.occ_hi = (uint32_t)(occm >> 32);
+  return R;
+}
+
 template <int MODE, bool COUNT, class STK>
 GD bool bih_tri_wave(const DScene& S, uint32_t hdr, const Ray& r, float d, bool valid, STK& stk, Cnt& cnt, float& best_t, uint32_t& best_rec) {
   hdr = uni(hdr);
   F4 h0 = ld4u(S.bihhdr, 3 * hdr), h1 = ld4u(S.bihhdr, 3 * hdr + 1);
   const uint32_t delta = uni(as_u(ld4u(S.bihhdr, 3 * hdr + 2).x));
-  uint32_t ref = uni(as_u(h0.w));
+  const uint32_t ref = uni(as_u(h0.w));
   const V3 rcp = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
   const LaneMask vm = wave_ballot(valid);
   const LaneMask sx = wave_ballot(valid && rcp.x > 0), sy = wave_ballot(valid && rcp.y > 0), sz = wave_ballot(valid && rcp.z > 0);
@@ -639,60 +741,13 @@ GD bool bih_tri_wave(const DScene& S, uint32_t hdr, const Ray& r, float d, bool 
   // `am`: the lanes whose ray has a non-empty interval in the current node.  Their (near, far) are live; the other
   // lanes' are don't-cares, so no sentinel values are needed and plain min / max serve (a NaN plane distance only
   // arises on a lane that fails the activity test of that child).
-  LaneMask am = wave_ballot(valid && !(nearv > farv));
+  const LaneMask am = wave_ballot(valid && !(nearv > farv));
   if (COUNT) { if (valid && nearv > farv) cnt.bih++; }  // a root branch entered with an empty interval is counted and left (Bih.hs:343)
-  const int cap = stk.total_cap();
-  int sp = 0;
-  LaneMask occm = 0;  // MODE 2: lanes that found an occluder
-  if (am != 0) for (;;) {
-    ref = uni(ref); am = uni(am); sp = (int)uni((uint32_t)sp);  // wave-uniform by construction: keep them in SGPRs
-    if (!(ref & BREF_LEAF)) {
-      F4 n = ld4u(S.bihnodes, ref);
-      const uint32_t w0 = uni(as_u(n.z)), right = uni(as_u(n.w));
-      const uint32_t axis = w0 & 3u, left = w0 >> 2;
-      const float dirr = axis == 0 ? rcp.x : (axis == 1 ? rcp.y : rcp.z), o = axis == 0 ? r.o.x : (axis == 1 ? r.o.y : r.o.z);
-      const bool fwd = (fwdbits >> axis) & 1u;
-      const float dl = (n.x - o) * dirr, dr = (n.y - o) * dirr;
-      const uint32_t c1 = fwd ? left : right, c2 = fwd ? right : left;
-      const float t1 = fwd ? dl : dr, t2 = fwd ? dr : dl;  // near child ends at t1, far child starts at t2
-      if (COUNT) { if (lane_of(am)) cnt.bih++; }
-      // an empty leaf holds nothing to test: it is never visited (no effect on results or on the branch counts)
-      const LaneMask m1 = c1 != BREF_LEAF ? (wave_ballot(nearv < t1) & am) : 0ull;
-      const LaneMask m2 = c2 != BREF_LEAF ? (wave_ballot(t2 < farv) & am) : 0ull;
-      const float f1 = fminf(t1, farv), n2 = fmaxf(t2, nearv);
-      if (m1 != 0) {
-        if (m2 != 0 && sp < cap) { stk.push_wave(sp, c2, m2, n2, farv); sp++; }
-        ref = c1; farv = f1; am = m1;
-        continue;
-      }
-      if (m2 != 0) { ref = c2; nearv = n2; am = m2; continue; }
-    } else {
-      uint32_t count = (ref >> 26) & 7u, first = ref & BREF_FIRST;
-      if (count == 7u) { F4 ln = ld4u(S.bihnodes, first); count = uni(as_u(ln.z)); first = uni(as_u(ln.w)); }
-      F4 q0, q1, q2;
-      if (count != 0u) ld_tri_u(S.tris, first + delta, q0, q1, q2);
-      for (uint32_t k = 0; k < count; k++) {
-        F4 p0 = q0, p1 = q1, p2 = q2;
-        if (k + 1 < count) ld_tri_u(S.tris, first + delta + k + 1, q0, q1, q2);  // the next record is on its way while this one is tested
-        float t, b1, b2;
-        if (COUNT) { if (lane_of(am)) cnt.prim++; }
-        // tmax = far (Bih.hs:339; shadow: `fmin d far`, Bih.hs:515 -- far <= d already); MODE 1: far <= best_t
-        const bool hit = tri_test(p0, p1, p2, r, farv, t, b1, b2) && lane_of(am);
-        if (MODE == 2) { const LaneMask hm = wave_ballot(hit); occm |= hm; am &= ~hm; }
-        else if (hit && !(best_t < t)) { best_t = t; best_rec = first + k; if (MODE == 1) farv = gminf(farv, t); }
-      }
-    }
-    // pop until an entry some lane still wants (MODE 1: `far` may have shrunk since the push; MODE 2: lanes retire)
-    am = 0;
-    while (sp > 0 && am == 0) {
-      sp--;
-      stk.pop_wave(sp, ref, am, nearv, farv);
-      if (MODE == 1) { farv = gminf(farv, best_t); am &= wave_ballot(!(nearv > farv)); }
-      if (MODE == 2) am &= ~occm;
-    }
-    if (am == 0) break;
-  }
-  return MODE == 2 ? lane_of(occm) : false;
+  if (am == 0) return false;
+  PacketResult R = bih_tri_packet<MODE, COUNT, STK>(S.bihnodes, S.tris, ref, delta, fwdbits, (uint32_t)am, (uint32_t)(am >> 32), nearv, farv, r.o, r.d, rcp, best_t, stk);
+  if (COUNT) { cnt.bih += R.n_bih; cnt.prim += R.n_prim; }
+  if (MODE != 2 && R.best_rec != kNoRec) { best_t = R.best_t; best_rec = R.best_rec; }
+  return MODE == 2 ? lane_of((LaneMask)R.occ_lo | ((LaneMask)R.occ_hi << 32)) : false;
 }
 
 // ------------------------------------------------------------------ Mesh 2-box BVH (Mesh.hs:136-198; Q12)
