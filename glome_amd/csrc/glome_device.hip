@@ -44,9 +44,9 @@ struct FlatTier {
     return finalize_flat<CLS>(S, r, c);
   }
   __device__ __forceinline__ bool occluded(const Ray& r, float d) { return occluded_flat<COUNT, CLS>(S, r, d, stk, cnt); }
-  // wave-wide calls (every lane of the wave makes them together; `valid` = the lane holds a ray).  Triangle BIHs are
-  // walked as packets in the lean kernels; kernels with out-of-line shader calls (FULL) keep the per-lane walk.
-  static constexpr bool PACKETS = !FULL_ && (CLS & CLS_BIH_TRI) != 0;
+  // wave-wide calls (every lane of the wave makes them together; `valid` = the lane holds a ray).  Triangle and sphere
+  // BIHs are walked as packets in the lean kernels; kernels with out-of-line shader calls (FULL) keep the per-lane walk.
+  static constexpr bool PACKETS = !FULL_ && (CLS & (CLS_BIH_TRI | CLS_BIH_SPHERE)) != 0;
   __device__ __forceinline__ HitG closest_wave(const Ray& r, float tmax, bool valid) {
 #if defined(GLOME_EXP_TIMING)
     unsigned long long t0 = __builtin_readcyclecounter();
@@ -311,7 +311,7 @@ __device__ __forceinline__ void ss_trace_loop(const DRenderArgs& A, TIER& T, int
     Ray ray = primary_ray(A.cam, xc, yc);
     if (valid) T.cnt.primary++;
     HitG h;
-    CA c = trace_primary(T, ray, kInf, A.maxdepth, valid, &h);
+    CA c = trace_primary(T, ray, kInf, A.maxdepth, valid, &h, false);  // a compacted sample list: per-lane traversal
     if (!valid) continue;
     TC s = tc(c.r, c.g, c.b, c.a, h.hit ? h.t : kInf);
     if (pass < 5) ss_store(v, idx, s);

@@ -554,7 +554,15 @@ constexpr uint32_t kNoRec = 0xffffffffu;  // == CAND_NONE below
 #include <vector>
 static thread_local std::vector<uint32_t>* g_trace_nodes = nullptr; static thread_local std::vector<uint32_t>* g_trace_tris = nullptr;
 #endif
-template <int MODE, bool COUNT, class STK>
+// LEAFK: what the leaves hold -- 0 triangles (48-byte records), 1 spheres (16-byte records).
+GD bool leaf_item_test(const DScene& S, int leafk, bool shadow, uint32_t prim, const Ray& r, float tmax, float& t) {
+  if (leafk == 0) {
+    float b1, b2;
+    return tri_test(ld4(S.tris, 3 * prim), ld4(S.tris, 3 * prim + 1), ld4(S.tris, 3 * prim + 2), r, tmax, t, b1, b2);
+  }
+  return shadow ? sphere_shadow(ld4(S.spheres, prim), r, tmax) : sphere_test(ld4(S.spheres, prim), r, tmax, t);
+}
+template <int MODE, bool COUNT, int LEAFK = 0, class STK>
 GD bool bih_tri(const DScene& S, uint32_t hdr, const Ray& r, float d, STK& stk, Cnt& cnt, float& best_t, uint32_t& best_rec) {
   F4 h0 = ld4(S.bihhdr, 3 * hdr), h1 = ld4(S.bihhdr, 3 * hdr + 1);
   const uint32_t delta = as_u(ld4(S.bihhdr, 3 * hdr + 2).x);
@@ -610,11 +618,10 @@ GD bool bih_tri(const DScene& S, uint32_t hdr, const Ray& r, float d, STK& stk, 
 #if defined(GLOME_HOSTSIM_TRACE)
         if (g_trace_tris) g_trace_tris->push_back(a);
 #endif
-        F4 q0 = ld4(S.tris, 3 * a), q1 = ld4(S.tris, 3 * a + 1), q2 = ld4(S.tris, 3 * a + 2);
-        float t, b1, b2;
+        float t;
         if (COUNT) cnt.prim++;
         // tmax = far (Bih.hs:339; shadow: `fmin d far`, Bih.hs:515 -- far <= d already); MODE 1: far <= best_t
-        bool hit = tri_test(q0, q1, q2, r, farv, t, b1, b2);
+        bool hit = leaf_item_test(S, LEAFK, MODE == 2, a, r, farv, t);
         ref += 1u - (1u << 26);  // the next triangle of this leaf
         popit = count == 1u;
         if (MODE == 2) { if (hit) { occ = true; sp = 0; popit = true; } }  // first occluder: leave through the one exit
@@ -652,7 +659,7 @@ struct PacketResult { float best_t; uint32_t best_rec; uint32_t occ_lo, occ_hi, 
 #else
 #define GPK GD
 #endif
-template <int MODE, bool COUNT, class STK>
+template <int MODE, bool COUNT, int LEAFK, class STK>
 GPK PacketResult bih_tri_packet(const F4* nodes, const F4* tris, uint32_t ref, uint32_t delta, uint32_t fwdbits, uint32_t am_lo, uint32_t am_hi,
                                 float nearv, float farv, V3 ro, V3 rd, V3 rcp, float best_t, STK stk) {
   ref = uni(ref); delta = uni(delta); fwdbits = uni(fwdbits);
@@ -694,12 +701,20 @@ GPK PacketResult bih_tri_packet(const F4* nodes, const F4* tris, uint32_t ref, u
       uint32_t count = (ref >> 26) & 7u, first = ref & BREF_FIRST;
       if (count == 7u) { F4 ln = ld4u(nodes, first); count = uni(as_u(ln.z)); first = uni(as_u(ln.w)); }
       for (uint32_t k = 0; k < count; k++) {
-        F4 p0, p1, p2;
-        ld_tri_u(tris, first + delta + k, p0, p1, p2);
-        float t, b1, b2;
+        float t;
+        bool hit;
         if (COUNT) R.n_prim += lane_of(am) ? 1u : 0u;
         // tmax = far (Bih.hs:339; shadow: `fmin d far`, Bih.hs:515 -- far <= d already); MODE 1: far <= best_t
-        const bool hit = tri_test(p0, p1, p2, r, farv, t, b1, b2) && lane_of(am);
+        if (LEAFK == 0) {
+          F4 p0, p1, p2;
+          float b1, b2;
+          ld_tri_u(tris, first + delta + k, p0, p1, p2);
+          hit = tri_test(p0, p1, p2, r, farv, t, b1, b2);
+        } else {
+          F4 sp4 = ld4u(tris, first + delta + k);  // `tris` is the sphere pool here
+          hit = MODE == 2 ? sphere_shadow(sp4, r, farv) : sphere_test(sp4, r, farv, t);
+        }
+        hit = hit && lane_of(am);
         if (MODE == 2) { const LaneMask hm = wave_ballot(hit); occm |= hm; am &= ~hm; }
         else {
           const bool acc = hit && !(R.best_t < t);  // selects, not a branch
@@ -723,7 +738,7 @@ GPK PacketResult bih_tri_packet(const F4* nodes, const F4* tris, uint32_t ref, u
   return R;
 }
 
-template <int MODE, bool COUNT, class STK>
+template <int MODE, bool COUNT, int LEAFK = 0, class STK>
 GD bool bih_tri_wave(const DScene& S, uint32_t hdr, const Ray& r, float d, bool valid, STK& stk, Cnt& cnt, float& best_t, uint32_t& best_rec) {
   hdr = uni(hdr);
   F4 h0 = ld4u(S.bihhdr, 3 * hdr), h1 = ld4u(S.bihhdr, 3 * hdr + 1);
@@ -733,7 +748,7 @@ GD bool bih_tri_wave(const DScene& S, uint32_t hdr, const Ray& r, float d, bool 
   const LaneMask vm = wave_ballot(valid);
   const LaneMask sx = wave_ballot(valid && rcp.x > 0), sy = wave_ballot(valid && rcp.y > 0), sz = wave_ballot(valid && rcp.z > 0);
   const bool packet = !(ref & BREF_LEAF) && (sx == 0 || sx == vm) && (sy == 0 || sy == vm) && (sz == 0 || sz == vm);
-  if (!packet) return valid ? bih_tri<MODE, COUNT>(S, hdr, r, d, stk, cnt, best_t, best_rec) : false;
+  if (!packet) return valid ? bih_tri<MODE, COUNT, LEAFK>(S, hdr, r, d, stk, cnt, best_t, best_rec) : false;
   const uint32_t fwdbits = uni((sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u));  // per axis: do the rays run towards +axis
   float nearv, farv;
   bbclip_ub(r, v3(h0), v3(h1), nearv, farv);
@@ -744,7 +759,7 @@ GD bool bih_tri_wave(const DScene& S, uint32_t hdr, const Ray& r, float d, bool 
   const LaneMask am = wave_ballot(valid && !(nearv > farv));
   if (COUNT) { if (valid && nearv > farv) cnt.bih++; }  // a root branch entered with an empty interval is counted and left (Bih.hs:343)
   if (am == 0) return false;
-  PacketResult R = bih_tri_packet<MODE, COUNT, STK>(S.bihnodes, S.tris, ref, delta, fwdbits, (uint32_t)am, (uint32_t)(am >> 32), nearv, farv, r.o, r.d, rcp, best_t, stk);
+  PacketResult R = bih_tri_packet<MODE, COUNT, LEAFK, STK>(S.bihnodes, LEAFK == 0 ? S.tris : S.spheres, ref, delta, fwdbits, (uint32_t)am, (uint32_t)(am >> 32), nearv, farv, r.o, r.d, rcp, best_t, stk);
   if (COUNT) { cnt.bih += R.n_bih; cnt.prim += R.n_prim; }
   if (MODE != 2 && R.best_rec != kNoRec) { best_t = R.best_t; best_rec = R.best_rec; }
   return MODE == 2 ? lane_of((LaneMask)R.occ_lo | ((LaneMask)R.occ_hi << 32)) : false;
@@ -848,7 +863,8 @@ GD Cand closest_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt,
     uint32_t cls = 0;
     if (kind == R_BIH) { cls = as_u(ld4(S.bihhdr, 3 * rec.y + 1).w); if (WAVE) cls = uni(cls); }
     const bool tri_bih = kind == R_BIH && (CLS & CLS_BIH_TRI) && (CLS == CLS_BIH_TRI || cls == BC_TRI);
-    if (WAVE && !valid && !tri_bih) continue;  // only the packet walk needs the lanes without a ray
+    const bool sph_bih = kind == R_BIH && (CLS & CLS_BIH_SPHERE) && cls == BC_SPHERE;
+    if (WAVE && !valid && !tri_bih && !sph_bih) continue;  // only the packet walks need the lanes without a ray
     // tmax for this entry; a hit replaces the running best when !(best.t < t)  (nearest: ties -> later)
     float dd = (FAITHFUL || best.id == CAND_NONE) ? d : gminf(d, best.t);
     if (kind == R_BIH) {
@@ -860,16 +876,12 @@ GD Cand closest_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt,
         if (WAVE) bih_tri_wave<FAITHFUL ? 0 : 1, COUNT>(S, rec.y, r, dd, valid, stk, cnt, bt, brec);
         else bih_tri<FAITHFUL ? 0 : 1, COUNT>(S, rec.y, r, dd, stk, cnt, bt, brec);
         if (brec != CAND_NONE) { best.t = bt; best.id = brec; best.aux = e; }
-      } else if ((CLS & CLS_BIH_SPHERE) && cls == BC_SPHERE) {
-        bih_traverse<FAITHFUL ? 0 : 1, COUNT>(S, rec.y, r, dd, stk, stk.total_cap(), cnt,
-          [&](uint32_t frec, uint32_t fprim, uint32_t count, float tmax) {
-            for (uint32_t k = 0; k < count; k++) {
-              float t;
-              if (COUNT) cnt.prim++;
-              if (sphere_test(ld4(S.spheres, fprim + k), r, tmax, t)) { accept(t, frec + k); if (!FAITHFUL) tmax = gminf(tmax, best.t); }
-            }
-            return false;
-          }, bestt);
+      } else if (sph_bih) {
+        float bt = best.id == CAND_NONE ? kNoBest : best.t;
+        uint32_t brec = CAND_NONE;
+        if (WAVE) bih_tri_wave<FAITHFUL ? 0 : 1, COUNT, 1>(S, rec.y, r, dd, valid, stk, cnt, bt, brec);
+        else bih_tri<FAITHFUL ? 0 : 1, COUNT, 1>(S, rec.y, r, dd, stk, cnt, bt, brec);
+        if (brec != CAND_NONE) { best.t = bt; best.id = brec; best.aux = e; }
       } else if (CLS & CLS_BIH_SIMPLE) {  // BC_SIMPLE: mixed simple primitives, possibly with NoShadow / OnlyShadow flags
         bih_traverse<FAITHFUL ? 0 : 1, COUNT>(S, rec.y, r, dd, stk, stk.total_cap(), cnt,
           [&](uint32_t frec, uint32_t, uint32_t count, float tmax) {
@@ -949,7 +961,8 @@ GD bool occluded_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt
     uint32_t cls = 0;
     if (kind == R_BIH) { cls = as_u(ld4(S.bihhdr, 3 * rec.y + 1).w); if (WAVE) cls = uni(cls); }
     const bool tri_bih = kind == R_BIH && (CLS & CLS_BIH_TRI) && (CLS == CLS_BIH_TRI || cls == BC_TRI);
-    if (WAVE) { if (!wave_any(valid)) break; if (!valid && !tri_bih) continue; }
+    const bool sph_bih = kind == R_BIH && (CLS & CLS_BIH_SPHERE) && cls == BC_SPHERE;
+    if (WAVE) { if (!wave_any(valid)) break; if (!valid && !tri_bih && !sph_bih) continue; }
     if (kind == R_BIH) {
       bool occ = false;
       auto nobest = [&]() { return 0.0f; };
@@ -957,16 +970,10 @@ GD bool occluded_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt
         float bt = kNoBest; uint32_t brec = CAND_NONE;
         if (WAVE) occ = bih_tri_wave<2, COUNT>(S, rec.y, r, d, valid, stk, cnt, bt, brec);
         else occ = bih_tri<2, COUNT>(S, rec.y, r, d, stk, cnt, bt, brec);
-      } else if ((CLS & CLS_BIH_SPHERE) && cls == BC_SPHERE) {
-        bih_traverse<2, COUNT>(S, rec.y, r, d, stk, stk.total_cap(), cnt,
-          [&](uint32_t, uint32_t fprim, uint32_t count, float tmax) {
-            float dd = gminf(d, tmax);
-            for (uint32_t k = 0; k < count; k++) {
-              if (COUNT) cnt.prim++;
-              if (sphere_shadow(ld4(S.spheres, fprim + k), r, dd)) { occ = true; return true; }
-            }
-            return false;
-          }, nobest);
+      } else if (sph_bih) {
+        float bt = kNoBest; uint32_t brec = CAND_NONE;
+        if (WAVE) occ = bih_tri_wave<2, COUNT, 1>(S, rec.y, r, d, valid, stk, cnt, bt, brec);
+        else occ = bih_tri<2, COUNT, 1>(S, rec.y, r, d, stk, cnt, bt, brec);
       } else if (CLS & CLS_BIH_SIMPLE) {
         bih_traverse<2, COUNT>(S, rec.y, r, d, stk, stk.total_cap(), cnt,
           [&](uint32_t frec, uint32_t, uint32_t count, float tmax) {
@@ -1190,8 +1197,15 @@ template <class TIER> struct TraceFn<0, TIER> {
 // Called by all lanes of a wave together (`valid` = the lane has a pixel): the primary rays and, where the first
 // material of the hit is a Surface -- which always forces the light list (Trace.hs:63, Shader.hs:96) -- the shadow rays
 // are traced wave-wide; every other case (lazy light lists under Reflect / Blend, secondary rays) stays per lane.
-template <class TIER> GD CA trace_primary(TIER& T, const Ray& ray, float tmax, int maxdepth, bool valid, HitG* hout) {
+// `coherent`: the wave's rays leave neighbouring pixels (an 8x8 block of a tile).  The adaptive sampler's compacted
+// sample lists are not -- 64 entries can span a whole tile -- and a packet over them visits nearly the sum of what
+// its rays visit, so those waves trace per lane.
+template <class TIER> GD CA trace_primary(TIER& T, const Ray& ray, float tmax, int maxdepth, bool valid, HitG* hout, bool coherent = true) {
   if (maxdepth <= 0) { *hout = hit_miss(); return ca(0, 0, 0, 0); }
+  if (!coherent) {
+    if (!valid) { *hout = hit_miss(); return ca(0, 0, 0, 0); }
+    return trace_body<kMaxTraceDepth, true>(T, ray, tmax, maxdepth, hout);
+  }
   HitG h = T.closest_wave(ray, tmax, valid);
   *hout = h;
   LightCache lc; lc.done = false; lc.mask = 0;
