@@ -36,6 +36,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--mode", type=int, default=0, help="0 = renderTile (1 ray/pixel), 1 = renderTileSubsample (adaptive)")
     ap.add_argument("--lanes", type=int, default=4, help="frames kept in flight per GPU (HIP streams / context slots)")
+    ap.add_argument("--product", default="packed", choices=["packed", "rgbad"],
+                    help="what a frame is: GlomeView's framebuffer of packed 0x00RRGGBB pixels (blitTile; 4 B/pixel cross xGMI) "
+                         "or the float (r,g,b,a,depth) tuples (20 B/pixel)")
     args = ap.parse_args()
 
     import torch  # device memory, streams, torch.distributed (RCCL)
@@ -72,7 +75,7 @@ def main():
     lights = [api.light(p, c, r, s) for (p, c, r, s) in sd.lights]
     P = api.render_params(width=W, height=H, maxdepth=maxdepth, mode=args.mode)
 
-    sf = dist.ShardedFrame(scene, P, rank, world, device, lanes=args.lanes)
+    sf = dist.ShardedFrame(scene, P, rank, world, device, lanes=args.lanes, product=args.product)
 
     def barrier():
         if world > 1:
@@ -201,7 +204,7 @@ def main():
         "config": {"workload": f"{args.scene}: " + {"S3": "100,352-triangle heightfield under bih (BASELINE configs[2]), 1 light, primary + shadow rays, maxdepth 1",
                                                      "S3mesh": "100,352-triangle heightfield as mesh (2-box BVH)", "S5": "1,002,528-triangle heightfield under bih"}.get(args.scene, args.scene),
                    "width": W, "height": H, "rays_per_frame": {"primary": rays[0], "shadow": rays[1], "secondary": rays[2]},
-                   "sampling": "renderTile, 1 primary ray/pixel" if args.mode == 0 else "renderTileSubsample (adaptive, 1/8..2 primary rays/pixel)", "frames_in_flight": args.lanes, "tiles": "65x65 reference tiles, round-robin over ranks, one RCCL gather to rank 0 per frame, gather of frame k overlapped with render of frame k+1" if world > 1 else "65x65 reference tiles, one GPU",
+                   "sampling": "renderTile, 1 primary ray/pixel" if args.mode == 0 else "renderTileSubsample (adaptive, 1/8..2 primary rays/pixel)", "frames_in_flight": args.lanes, "frame_product": "packed 0x00RRGGBB framebuffer (trace + blitTile fused, 4 B/pixel)" if args.product == "packed" else "float (r,g,b,a,depth) per pixel, 20 B/pixel", "tiles": "65x65 reference tiles, round-robin over ranks, one RCCL gather to rank 0 per frame, gather of frame k overlapped with render of frame k+1" if world > 1 else "65x65 reference tiles, one GPU",
                    "scene_setup_s": round(setup_s, 2), "device_bytes": info["device_bytes"]},
         "roofline": roofline, "cpu_baseline": cpu,
     }

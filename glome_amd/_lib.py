@@ -114,6 +114,8 @@ SYMBOLS = [
     ("glome_tiles_pack_dev", C.c_int, [vp, C.POINTER(RenderParams), vp, vp]),
     ("glome_tiles_blit_dev", C.c_int, [vp, C.POINTER(RenderParams), C.c_int, C.c_int, vp, vp, vp]),
     ("glome_tiles_blit_all_dev", C.c_int, [vp, C.POINTER(RenderParams), C.c_int, vp, C.c_int64, vp, vp]),
+    ("glome_render_tiles_packed_dev", C.c_int, [vp, C.POINTER(Camera), C.POINTER(Light), C.c_int, C.POINTER(RenderParams), vp, C.POINTER(Stats)]),
+    ("glome_tiles_blit_all_packed_dev", C.c_int, [vp, C.POINTER(RenderParams), C.c_int, vp, C.c_int64, vp]),
 ]
 
 _lib = None

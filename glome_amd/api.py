@@ -330,6 +330,6 @@ class Scene:
         """Device-pointer render (e.g. a torch tensor's data_ptr()); asynchronous unless want_stats."""
         la = (L.Light * max(1, len(lights)))(*lights)
         st = L.Stats()
-        self._chk(self.lib.glome_render_dev(self.h, C.byref(cam), la, len(lights), C.byref(params), C.c_void_p(rgbad_ptr),
+        self._chk(self.lib.glome_render_dev(self.h, C.byref(cam), la, len(lights), C.byref(params), C.c_void_p(rgbad_ptr) if rgbad_ptr else None,
                                             C.c_void_p(packed_ptr) if packed_ptr else None, C.byref(st) if want_stats else None), "glome_render_dev")
         return _stats_dict(st) if want_stats else None

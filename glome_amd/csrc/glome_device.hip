@@ -193,8 +193,10 @@ __device__ __forceinline__ void render_loop(const DRenderArgs& A, TIER& T) {
     float r = c.r;
     if (A.fog) r = r + (depth / 400);      // renderTile's debug fog (Glome.hs:174, Q20)
     size_t o = A.dense ? dense_off : (size_t)py * A.width + px;
-    float* out = A.out5 + o * 5;
-    out[0] = r; out[1] = c.g; out[2] = c.b; out[3] = c.a; out[4] = depth;
+    if (A.out5) {
+      float* out = A.out5 + o * 5;
+      out[0] = r; out[1] = c.g; out[2] = c.b; out[3] = c.a; out[4] = depth;
+    }
     if (A.packed) A.packed[o] = rgbf(r * c.a, c.g * c.a, c.b * c.a);  // blitTile (Glome.hs:353-358)
 #if defined(GLOME_EXP_TIMING)
     if (lane == 0) T.cnt.mesh += (uint32_t)(__builtin_readcyclecounter() - tw0);
@@ -245,8 +247,8 @@ __device__ __forceinline__ size_t ss_out_index(const DRenderArgs& A, const DTile
 }
 __device__ __forceinline__ void ss_write_out(const DRenderArgs& A, const DTile& t, int dx, int dy, const TC& c) {
   size_t o = ss_out_index(A, t, dx, dy);
-  ss_store(A.out5, o, c);
-  if (A.packed && !A.dense) A.packed[o] = rgbf(c.r * c.a, c.g * c.a, c.b * c.a);
+  if (A.out5) ss_store(A.out5, o, c);
+  if (A.packed) A.packed[o] = rgbf(c.r * c.a, c.g * c.a, c.b * c.a);
 }
 
 __global__ void __launch_bounds__(256) k_ss_decide(DRenderArgs A, int pass) {
@@ -413,6 +415,14 @@ __global__ void k_tiles_blit(const DTile* tiles, int ntiles, int width, const fl
       dst[0] = r; dst[1] = g; dst[2] = b; dst[3] = a; dst[4] = d;
       if (packed) packed[o] = rgbf(r * a, g * a, b * a);
     }
+  }
+}
+__global__ void k_tiles_blit_packed(const DTile* tiles, int ntiles, int width, const uint32_t* payload, uint32_t* packed) {
+  for (int t = blockIdx.y; t < ntiles; t += gridDim.y) {
+    DTile T = tiles[t];
+    int np = T.w * T.h;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < np; p += gridDim.x * blockDim.x)
+      packed[(size_t)(T.y + p / T.w) * width + (T.x + p % T.w)] = payload[(size_t)T.pix_base + p];
   }
 }
 
@@ -724,7 +734,7 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
                        float* rgbad_dev, uint32_t* packed_dev, glome_stats* stats, int dense) {
   if (!s) return GLOME_E_INVALID;
   glome_ctx* ctx = s->ctx;
-  if (!cam || !rgbad_dev || nlights < 0 || (nlights > 0 && !lights)) { ctx->err = "bad argument"; return GLOME_E_INVALID; }
+  if (!cam || (!rgbad_dev && !(dense != 1 && packed_dev)) || nlights < 0 || (nlights > 0 && !lights)) { ctx->err = "bad argument"; return GLOME_E_INVALID; }
   if (nlights > kMaxLights) { ctx->err = "too many lights"; return GLOME_E_LIMIT; }
   int rc = check_params(ctx, P);
   if (rc) return rc;
@@ -744,7 +754,8 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
   A.nlights = nlights; A.width = P->width; A.height = P->height; A.fog = P->fog; A.maxdepth = P->maxdepth;
   memcpy(A.thresholds, P->thresholds, 16);
   A.tiles = tt->dev; A.ntiles = (int)tt->host.size(); A.total_waves = tt->total_waves;
-  A.out5 = rgbad_dev; A.packed = dense ? nullptr : packed_dev; A.counters = ctx->slot().d_counters; A.dense = dense;
+  // dense 0: full frame (rgbad and / or packed); 1: dense rgbad tile payload; 2: dense packed-pixel tile payload only
+  A.out5 = dense == 2 ? nullptr : rgbad_dev; A.packed = dense == 1 ? nullptr : packed_dev; A.counters = ctx->slot().d_counters; A.dense = dense != 0;
   HIPCHK(ctx, hipMemsetAsync(ctx->slot().d_counters, 0, sizeof(DCounters), ctx->stream));
   hipEvent_t ev_start = ctx->ev0, ev_stop = ctx->ev1;
   if (A.ntiles > 0 && P->mode == GLOME_MODE_SUBSAMPLE) {
@@ -813,6 +824,10 @@ int glome_render_dev(glome_scene* s, const glome_camera* cam, const glome_light*
 int glome_render_tiles_dev(glome_scene* s, const glome_camera* cam, const glome_light* lights, int nlights, const glome_render_params* P,
                            float* payload_dev, glome_stats* stats) {
   return render_impl(s, cam, lights, nlights, P, payload_dev, nullptr, stats, 1);
+}
+int glome_render_tiles_packed_dev(glome_scene* s, const glome_camera* cam, const glome_light* lights, int nlights, const glome_render_params* P,
+                                  uint32_t* payload_dev, glome_stats* stats) {
+  return render_impl(s, cam, lights, nlights, P, nullptr, payload_dev, stats, 2);
 }
 
 int glome_render(glome_scene* s, const glome_camera* cam, const glome_light* lights, int nlights, const glome_render_params* P, float* rgbad,
@@ -989,23 +1004,17 @@ int glome_tiles_pack_dev(glome_ctx* ctx, const glome_render_params* P, const flo
   HIPCHK(ctx, hipGetLastError());
   return 0;
 }
-int glome_tiles_blit_all_dev(glome_ctx* ctx, const glome_render_params* P, int world, const float* gathered_dev, int64_t stride_floats,
-                             float* rgbad_dev, uint32_t* packed_dev) {
-  if (!ctx) return GLOME_E_INVALID;
-  int rc = check_params(ctx, P);
-  if (rc) return rc;
-  if (world <= 0 || stride_floats < 0 || stride_floats % 5 != 0) { ctx->err = "bad world / stride"; return GLOME_E_INVALID; }
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  // one table over every tile of the frame; pix_base = owner rank's slab offset + the tile's offset inside that rank's payload
-  std::vector<int> key{P->width, P->height, P->blocksize, -world, (int)(stride_floats / 5)};
+// one table over every tile of the frame; pix_base = owner rank's slab offset + the tile's offset inside that rank's payload
+static int gathered_table(glome_ctx* ctx, const glome_render_params* P, int world, int64_t stride_pixels, glome_ctx::TileTable** out) {
+  std::vector<int> key{P->width, P->height, P->blocksize, -world, (int)stride_pixels};
   auto it = ctx->tile_cache.find(key);
   if (it == ctx->tile_cache.end()) {
     glome_ctx::TileTable tt;
     for (int r = 0; r < world; r++) {
       std::vector<DTile> t; uint32_t w; int64_t px;
       owned_tiles(P->width, P->height, P->blocksize, r, world, t, w, px);
-      if ((int64_t)r * (stride_floats / 5) + px > 0xffffffffll) { ctx->err = "gathered payload too large"; return GLOME_E_LIMIT; }
-      for (DTile& d : t) { d.pix_base += (uint32_t)(r * (stride_floats / 5)); tt.host.push_back(d); }
+      if ((int64_t)r * stride_pixels + px > 0xffffffffll) { ctx->err = "gathered payload too large"; return GLOME_E_LIMIT; }
+      for (DTile& d : t) { d.pix_base += (uint32_t)(r * stride_pixels); tt.host.push_back(d); }
       tt.pixels += px;
     }
     size_t bytes = std::max<size_t>(1, tt.host.size()) * sizeof(DTile);
@@ -1013,9 +1022,34 @@ int glome_tiles_blit_all_dev(glome_ctx* ctx, const glome_render_params* P, int w
     if (!tt.host.empty()) HIPCHK(ctx, hipMemcpy(tt.dev, tt.host.data(), tt.host.size() * sizeof(DTile), hipMemcpyHostToDevice));
     it = ctx->tile_cache.emplace(key, std::move(tt)).first;
   }
-  glome_ctx::TileTable* tt = &it->second;
+  *out = &it->second;
+  return 0;
+}
+int glome_tiles_blit_all_dev(glome_ctx* ctx, const glome_render_params* P, int world, const float* gathered_dev, int64_t stride_floats,
+                             float* rgbad_dev, uint32_t* packed_dev) {
+  if (!ctx) return GLOME_E_INVALID;
+  int rc = check_params(ctx, P);
+  if (rc) return rc;
+  if (world <= 0 || stride_floats < 0 || stride_floats % 5 != 0) { ctx->err = "bad world / stride"; return GLOME_E_INVALID; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  glome_ctx::TileTable* tt;
+  if ((rc = gathered_table(ctx, P, world, stride_floats / 5, &tt))) return rc;
   if (tt->host.empty()) return 0;
   hipLaunchKernelGGL(k_tiles_blit, dim3(17, std::min<int>((int)tt->host.size(), 1024)), dim3(256), 0, ctx->stream, tt->dev, (int)tt->host.size(), P->width, gathered_dev, rgbad_dev, packed_dev);
+  HIPCHK(ctx, hipGetLastError());
+  return 0;
+}
+int glome_tiles_blit_all_packed_dev(glome_ctx* ctx, const glome_render_params* P, int world, const uint32_t* gathered_dev, int64_t stride_pixels,
+                                    uint32_t* packed_dev) {
+  if (!ctx) return GLOME_E_INVALID;
+  int rc = check_params(ctx, P);
+  if (rc) return rc;
+  if (world <= 0 || stride_pixels < 0 || !gathered_dev || !packed_dev) { ctx->err = "bad world / stride / buffer"; return GLOME_E_INVALID; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  glome_ctx::TileTable* tt;
+  if ((rc = gathered_table(ctx, P, world, stride_pixels, &tt))) return rc;
+  if (tt->host.empty()) return 0;
+  hipLaunchKernelGGL(k_tiles_blit_packed, dim3(17, std::min<int>((int)tt->host.size(), 1024)), dim3(256), 0, ctx->stream, tt->dev, (int)tt->host.size(), P->width, gathered_dev, packed_dev);
   HIPCHK(ctx, hipGetLastError());
   return 0;
 }

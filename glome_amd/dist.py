@@ -29,16 +29,19 @@ def payload_floats(params, first, stride):
 
 
 def blit_numpy(frame, payload, layout):
-    """Host mirror of glome_tiles_blit_dev for CPU tests: scatter a dense payload into frame[h, w, 5]."""
+    """Host mirror of glome_tiles_blit_dev for CPU tests: scatter a dense payload into frame[h, w, unit]
+    (unit = 5 floats per pixel, or 1 packed word per pixel for a frame[h, w] array)."""
+    u = 1 if frame.ndim == 2 else frame.shape[2]
     for x, y, w, h, base in layout:
-        frame[y:y + h, x:x + w, :] = payload[base * 5:(base + w * h) * 5].reshape(h, w, 5)
+        frame[y:y + h, x:x + w] = payload[base * u:(base + w * h) * u].reshape((h, w) if frame.ndim == 2 else (h, w, u))
     return frame
 
 
 def pack_numpy(frame, layout):
-    out = np.zeros(int(sum(w * h for _, _, w, h, _ in layout)) * 5, frame.dtype)
+    u = 1 if frame.ndim == 2 else frame.shape[2]
+    out = np.zeros(int(sum(w * h for _, _, w, h, _ in layout)) * u, frame.dtype)
     for x, y, w, h, base in layout:
-        out[base * 5:(base + w * h) * 5] = frame[y:y + h, x:x + w, :].reshape(-1)
+        out[base * u:(base + w * h) * u] = frame[y:y + h, x:x + w].reshape(-1)
     return out
 
 
@@ -54,12 +57,13 @@ class ShardPlan:
     """Who owns which tiles, how big each rank's payload is, and the one exchange step.  Backend agnostic: the GPU
     path (ShardedFrame) and the CPU multi-process test drive the same plan."""
 
-    def __init__(self, params, rank, world):
-        self.rank, self.world = rank, world
+    def __init__(self, params, rank, world, unit=5):
+        """unit: payload words per pixel -- 5 (the float (r, g, b, a, depth) tuple) or 1 (the packed display pixel)."""
+        self.rank, self.world, self.unit = rank, world, unit
         self.P = _clone_params(params, tile_first=0, tile_stride=1)
         self.P_local = _clone_params(params, tile_first=rank, tile_stride=world)
-        self.sizes = [payload_floats(self.P, r, world) for r in range(world)]
-        self.maxp = max(self.sizes + [5])  # gather needs equal-sized tensors: pad to the largest shard
+        self.sizes = [payload_floats(self.P, r, world) // 5 * unit for r in range(world)]
+        self.maxp = max(self.sizes + [unit])  # gather needs equal-sized tensors: pad to the largest shard
 
     def layout(self, r):
         return owned_layout(self.P, r, self.world)
@@ -118,25 +122,33 @@ class FramePipeline:
 class ShardedFrame:
     """Renders one frame per step() over all ranks of the default process group; frames land on rank 0.
     Up to `lanes` frames are in flight (each on its own HIP stream and context slot): call flush() before reading
-    `frame` (the most recently completed one on rank 0)."""
+    `frame` (the most recently completed one on rank 0).
 
-    def __init__(self, scene, params, rank, world, device, lanes=4):
+    product: "packed" -- the frame is GlomeView's framebuffer, one 0x00RRGGBB word per pixel (int32 [h, w]); trace and
+    blitTile are fused and 4 bytes per pixel cross xGMI.  "rgbad" -- the float (r, g, b, a, depth) tuples ([h, w, 5]),
+    20 bytes per pixel."""
+
+    def __init__(self, scene, params, rank, world, device, lanes=4, product="rgbad"):
         import torch
         self.torch = torch
         self.scene, self.ctx, self.lib = scene, scene.ctx, scene.lib
-        self.plan = ShardPlan(params, rank, world)
+        if product not in ("packed", "rgbad"):
+            raise ValueError("product must be 'packed' or 'rgbad'")
+        self.packed = product == "packed"
+        self.plan = ShardPlan(params, rank, world, unit=1 if self.packed else 5)
         self.rank, self.world, self.device = rank, world, device
         self.P, self.P_local = self.plan.P, self.plan.P_local
         h, w = params.height, params.width
         self.n = max(1, min(int(lanes), 4))
         self.streams = [torch.cuda.Stream(device=device) for _ in range(self.n)]
-        self.frames = [torch.zeros((h, w, 5), dtype=torch.float32, device=device) for _ in range(self.n)] if rank == 0 else None
+        dt = torch.int32 if self.packed else torch.float32
+        self.frames = [torch.zeros((h, w) if self.packed else (h, w, 5), dtype=dt, device=device) for _ in range(self.n)] if rank == 0 else None
         self.last = 0
         self.k = 0
         self.cam = self.lights = self.la = None
         if world > 1:
-            payloads = [torch.zeros(self.plan.maxp, dtype=torch.float32, device=device) for _ in range(self.n)]
-            gathereds = [torch.zeros((world, self.plan.maxp), dtype=torch.float32, device=device) if rank == 0 else None for _ in range(self.n)]
+            payloads = [torch.zeros(self.plan.maxp, dtype=dt, device=device) for _ in range(self.n)]
+            gathereds = [torch.zeros((world, self.plan.maxp), dtype=dt, device=device) if rank == 0 else None for _ in range(self.n)]
             self.pipe = FramePipeline(self.plan, payloads, gathereds, self._render, self._blit, self._lane)
         torch.cuda.synchronize(device)
 
@@ -150,14 +162,19 @@ class ShardedFrame:
         return self.torch.cuda.stream(s)
 
     def _render(self, slot, payload, stats=None):
-        rc = self.lib.glome_render_tiles_dev(self.scene.h, C.byref(self.cam), self.la, len(self.lights), C.byref(self.P_local),
+        fn = self.lib.glome_render_tiles_packed_dev if self.packed else self.lib.glome_render_tiles_dev
+        rc = fn(self.scene.h, C.byref(self.cam), self.la, len(self.lights), C.byref(self.P_local),
                                              C.c_void_p(payload.data_ptr()), C.byref(stats) if stats is not None else None)
         if rc != 0:
             raise api.GlomeError("glome_render_tiles_dev: " + self.ctx.err())
 
     def _blit(self, slot, gathered):
-        rc = self.lib.glome_tiles_blit_all_dev(self.ctx.h, C.byref(self.P), self.world, C.c_void_p(gathered.data_ptr()), self.plan.maxp,
-                                               C.c_void_p(self.frames[slot].data_ptr()), None)
+        if self.packed:
+            rc = self.lib.glome_tiles_blit_all_packed_dev(self.ctx.h, C.byref(self.P), self.world, C.c_void_p(gathered.data_ptr()), self.plan.maxp,
+                                                          C.c_void_p(self.frames[slot].data_ptr()))
+        else:
+            rc = self.lib.glome_tiles_blit_all_dev(self.ctx.h, C.byref(self.P), self.world, C.c_void_p(gathered.data_ptr()), self.plan.maxp,
+                                                   C.c_void_p(self.frames[slot].data_ptr()), None)
         if rc != 0:
             raise api.GlomeError("glome_tiles_blit_all_dev: " + self.ctx.err())
         self.last = slot
@@ -177,7 +194,8 @@ class ShardedFrame:
             slot = self.k % self.n
             self.k += 1
             with self._lane(slot):
-                st = self.scene.render_dev(cam, lights, self.P, self.frames[slot].data_ptr(), None, want_stats=stats)
+                fp = self.frames[slot].data_ptr()
+                st = self.scene.render_dev(cam, lights, self.P, None if self.packed else fp, fp if self.packed else None, want_stats=stats)
             self.last = slot
             return st
         if stats:

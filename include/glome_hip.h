@@ -173,7 +173,8 @@ typedef struct glome_stats {
 int glome_render(glome_scene*, const glome_camera*, const glome_light* lights, int nlights,
                  const glome_render_params*, float* rgbad, uint32_t* packed, glome_stats*);
 /* Device-pointer variant.  Asynchronous on the ctx stream unless stats != NULL (then it synchronizes to read
- * the counters and the event timer). */
+ * the counters and the event timer).  rgbad_dev may be NULL when packed_dev is given: only the displayable pixels are
+ * then written (trace and blitTile fused; the float tuple never leaves registers). */
 int glome_render_dev(glome_scene*, const glome_camera*, const glome_light* lights, int nlights,
                      const glome_render_params*, float* rgbad_dev, uint32_t* packed_dev, glome_stats*);
 /* Render the tiles owned by (params->tile_first, params->tile_stride) straight into a dense tile payload (what a
@@ -181,6 +182,12 @@ int glome_render_dev(glome_scene*, const glome_camera*, const glome_light* light
  * `Tile Rect (UV.Vector TColor)` (Glome.hs:153-154). */
 int glome_render_tiles_dev(glome_scene*, const glome_camera*, const glome_light* lights, int nlights,
                            const glome_render_params*, float* payload_dev, glome_stats*);
+/* The same render, but only the displayable pixel leaves the kernel: payload_dev receives one packed 0x00RRGGBB word per
+ * owned pixel (rgbf of the premultiplied colour -- what blitTile, Glome.hs:353-358, pokes into GlomeView's framebuffer),
+ * tiles in owned order, row major inside a tile.  This is the payload of the multi-GPU framebuffer gather (4 bytes per
+ * pixel instead of 20).  GLOME_MODE_TILE and GLOME_MODE_SUBSAMPLE alike. */
+int glome_render_tiles_packed_dev(glome_scene*, const glome_camera*, const glome_light* lights, int nlights,
+                                  const glome_render_params*, uint32_t* payload_dev, glome_stats*);
 /* Tile payload transport for multi-GPU sharding (Tile = Rect + pixel vector, Glome.hs:153-154).
  * pack: copy this rank's owned tiles from a full frame into a dense payload (tiles in owned order, row major
  * inside a tile, 5 floats per pixel).  blit: scatter a payload of the tiles owned by (tile_first, tile_stride)
@@ -196,6 +203,10 @@ int glome_tiles_blit_dev(glome_ctx*, const glome_render_params*, int tile_first,
  * gathered_dev + r * stride_floats).  One launch blits every rank's tiles into the frame. */
 int glome_tiles_blit_all_dev(glome_ctx*, const glome_render_params*, int world, const float* gathered_dev, int64_t stride_floats,
                              float* rgbad_dev, uint32_t* packed_dev);
+/* The packed-pixel form: `gathered_dev` holds `world` slabs of `stride_pixels` words (glome_render_tiles_packed_dev
+ * payloads); one launch writes every rank's tiles into the packed framebuffer (width*height words). */
+int glome_tiles_blit_all_packed_dev(glome_ctx*, const glome_render_params*, int world, const uint32_t* gathered_dev, int64_t stride_pixels,
+                                    uint32_t* packed_dev);
 
 #ifdef __cplusplus
 }

@@ -41,6 +41,20 @@ def _worker(rank, world, port, outdir):
             dist.blit_numpy(frame, gathered[r].numpy(), plan.layout(r))
         np.save(os.path.join(outdir, "frame.npy"), frame)
         np.save(os.path.join(outdir, "rays.npy"), rays.numpy())
+    # the packed-pixel product (what bench.py gathers): one 0x00RRGGBB word per pixel, unit = 1
+    plan1 = dist.ShardPlan(P, rank, world, unit=1)
+    assert plan1.sizes[rank] * 5 == plan.sizes[rank] and plan1.maxp * 5 == plan.maxp
+    _, mine_px, _ = o.render(W, H, maxdepth=1, tile_first=rank, tile_stride=world, want_packed=True)
+    pk1 = dist.pack_numpy(mine_px.astype(np.int64), lay)
+    pay1 = torch.zeros(plan1.maxp, dtype=torch.int64)
+    pay1[:pk1.size] = torch.from_numpy(pk1)
+    gat1 = torch.zeros((world, plan1.maxp), dtype=torch.int64) if rank == 0 else None
+    plan1.gather(pay1, gat1)
+    if rank == 0:
+        fpx = np.full((H, W), -1, np.int64)
+        for r in range(world):
+            dist.blit_numpy(fpx, gat1[r].numpy(), plan1.layout(r))
+        np.save(os.path.join(outdir, "frame_packed.npy"), fpx)
     # the pipelined path (FramePipeline): 5 frames with different lights in flight two at a time
     frames = []
     state = {"k": 0}
@@ -82,9 +96,10 @@ def test_two_rank_tile_sharding_reassembles_the_frame(built, tmp_path):
     from helpers import oracle_for
     from glome_amd import scenes
     o, om, _ = oracle_for(scenes.s1(nlights=1))
-    whole, _, cnt = o.render(W, H, maxdepth=1, want_packed=False)
+    whole, whole_px, cnt = o.render(W, H, maxdepth=1, want_packed=True)
     assert not np.isnan(frame).any()          # every pixel is owned by exactly one rank
     assert np.array_equal(frame, whole)       # bit exact
+    assert np.array_equal(np.load(tmp_path / "frame_packed.npy"), whole_px.astype(np.int64))  # the packed framebuffer too
     assert np.load(tmp_path / "rays.npy").tolist() == [cnt["rays_primary"], cnt["rays_shadow"]]
     pf = np.load(tmp_path / "pipe_frames.npy")
     assert pf.shape[0] == 5

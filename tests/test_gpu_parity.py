@@ -140,6 +140,20 @@ def test_full_size_tile_shards_reassemble_bit_exactly(gpu_ctx, s3_full, world):
     assert sc.lib.glome_tiles_blit_all_dev(gpu_ctx.h, C.byref(P), world, C.c_void_p(gathered.data_ptr()), plans[0].maxp, C.c_void_p(frame2.data_ptr()), None) == 0
     gpu_ctx.synchronize()
     assert torch.equal(frame2, whole)
+    # the packed-pixel product: each rank's dense 0x00RRGGBB payload, one blit -> the packed framebuffer of the
+    # whole-frame render (float tuple and packed pixel written together), and of a packed-only whole-frame render
+    whole_px = torch.zeros((1080, 1920), dtype=torch.int32, device=dev)
+    sc.render_dev(cam, lights, P, whole.data_ptr(), whole_px.data_ptr())
+    only_px = torch.zeros((1080, 1920), dtype=torch.int32, device=dev)
+    sc.render_dev(cam, lights, P, None, only_px.data_ptr())
+    plans1 = [dist.ShardPlan(P, r, world, unit=1) for r in range(world)]
+    gathered_px = torch.zeros((world, plans1[0].maxp), dtype=torch.int32, device=dev)
+    for r in range(world):
+        assert sc.lib.glome_render_tiles_packed_dev(sc.h, C.byref(cam), la, len(lights), C.byref(plans1[r].P_local), C.c_void_p(gathered_px[r].data_ptr()), None) == 0
+    frame_px = torch.full((1080, 1920), -1, dtype=torch.int32, device=dev)
+    assert sc.lib.glome_tiles_blit_all_packed_dev(gpu_ctx.h, C.byref(P), world, C.c_void_p(gathered_px.data_ptr()), plans1[0].maxp, C.c_void_p(frame_px.data_ptr())) == 0
+    gpu_ctx.synchronize()
+    assert torch.equal(only_px, whole_px) and torch.equal(frame_px, whole_px)
 
 
 def test_full_size_csg_generic_tier_vs_oracle_tile_sample(gpu_ctx):
