@@ -35,12 +35,17 @@ def main():
     ap.add_argument("--scene", default="S3", help="S1 S2 S3 S3mesh S4 S5 (default: the headline workload S3)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--mode", type=int, default=0, help="0 = renderTile (1 ray/pixel), 1 = renderTileSubsample (adaptive)")
-    ap.add_argument("--lanes", type=int, default=4, help="frames kept in flight per GPU (HIP streams / context slots)")
+    ap.add_argument("--lanes", type=int, default=4, help="launches kept in flight per GPU (HIP streams / context slots)")
+    ap.add_argument("--time-every", type=int, default=4, help="HIP-event pair on every k-th launch of the timed region (roofline kernel time)")
+    ap.add_argument("--group", type=int, default=0, help="frames per launch (and per RCCL gather); default 2 on one GPU, 4 on several")
     ap.add_argument("--product", default="packed", choices=["packed", "rgbad"],
                     help="what a frame is: GlomeView's framebuffer of packed 0x00RRGGBB pixels (blitTile; 4 B/pixel cross xGMI) "
                          "or the float (r,g,b,a,depth) tuples (20 B/pixel)")
     args = ap.parse_args()
 
+    # the frames in flight run on separate HIP streams; give them separate hardware queues (the runtime's default is 4,
+    # which makes the frame period depend on how the streams happen to share queues)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch  # device memory, streams, torch.distributed (RCCL)
 
     from glome_amd import _lib as L
@@ -75,7 +80,9 @@ def main():
     lights = [api.light(p, c, r, s) for (p, c, r, s) in sd.lights]
     P = api.render_params(width=W, height=H, maxdepth=maxdepth, mode=args.mode)
 
-    sf = dist.ShardedFrame(scene, P, rank, world, device, lanes=args.lanes, product=args.product)
+    if args.group <= 0:
+        args.group = 1 if (args.mode != 0 or args.product != "packed") else (2 if world == 1 else 4)
+    sf = dist.ShardedFrame(scene, P, rank, world, device, lanes=args.lanes, product=args.product, group=args.group)
 
     def barrier():
         if world > 1:
@@ -96,7 +103,9 @@ def main():
         sf.step(cam, lights)
     sf.flush()
     barrier()
-    ctx.lib.glome_ctx_timing_begin(ctx.h, args.steps)
+    # every 4th launch carries a HIP-event pair (the event records are packets on the launch stream: timing every launch
+    # costs ~15 % of the frame rate at 0.4 ms per frame)
+    ctx.lib.glome_ctx_timing_begin_sampled(ctx.h, args.steps, max(1, args.time_every))
     t_start = time.perf_counter()
     for _ in range(args.steps):
         sf.step(cam, lights)
@@ -139,7 +148,7 @@ def main():
         return (s["rays_primary"] + s["rays_secondary"]) * 64 + s["rays_shadow"] * 36 + (s["bih_nodes"] * 16 + s["mesh_nodes"] * 64) + s["prim_tests"] * s_prim
 
     kavg_ms = float(np.mean(kms[:nk])) if nk > 0 else float("nan")
-    bytes_ref = algo_bytes(stf)
+    bytes_ref = algo_bytes(stf) * sf.G  # a launch carries sf.G frames of this rank's tiles
     achieved = bytes_ref / (kavg_ms * 1e-3) / 1e9
     traffic = None
     pmc = os.path.join(HERE, "profiles", "pmc_traffic.json")  # written from a separate rocprofv3 --pmc run (profiles/README.md)
@@ -154,11 +163,11 @@ def main():
         "kernel": "k_render_flat" if info["tier"] == 0 else "k_render_generic", "kernel_ms_avg": round(kavg_ms, 4), "launches_timed": int(nk),
         "algorithmic_bytes_per_launch": int(bytes_ref),
         "per_ray": {"nodes": round((stf["bih_nodes"] + stf["mesh_nodes"]) / max(1, sum(rays) // world), 2), "prims": round(stf["prim_tests"] / max(1, sum(rays) // world), 2)},
-        "visited_bytes_per_launch_early_out": int(algo_bytes(stc)),
+        "visited_bytes_per_launch_early_out": int(algo_bytes(stc)) * sf.G, "frames_per_launch": sf.G, "timed": f"every {max(1, args.time_every)}th launch of the timed region",
         "frac_of_measured_copy_ceiling_6290GBs": round(achieved / 6290.0, 4),
         # with several frames in flight the launches overlap, so each launch's own duration (above) is longer than the
         # frame period; the same bytes over the measured frame period:
-        "effective_GBs_over_frame_period": round(bytes_ref / (ms_per_step * 1e-3) / 1e9, 1),
+        "effective_GBs_over_frame_period": round(bytes_ref / sf.G / (ms_per_step * 1e-3) / 1e9, 1),
     }
 
     # ---- cpu_baseline: the oracle on a bounded sample of the same frame (every 4th tile), all host cores ----
@@ -204,7 +213,7 @@ def main():
         "config": {"workload": f"{args.scene}: " + {"S3": "100,352-triangle heightfield under bih (BASELINE configs[2]), 1 light, primary + shadow rays, maxdepth 1",
                                                      "S3mesh": "100,352-triangle heightfield as mesh (2-box BVH)", "S5": "1,002,528-triangle heightfield under bih"}.get(args.scene, args.scene),
                    "width": W, "height": H, "rays_per_frame": {"primary": rays[0], "shadow": rays[1], "secondary": rays[2]},
-                   "sampling": "renderTile, 1 primary ray/pixel" if args.mode == 0 else "renderTileSubsample (adaptive, 1/8..2 primary rays/pixel)", "frames_in_flight": args.lanes, "frame_product": "packed 0x00RRGGBB framebuffer (trace + blitTile fused, 4 B/pixel)" if args.product == "packed" else "float (r,g,b,a,depth) per pixel, 20 B/pixel", "tiles": "65x65 reference tiles, round-robin over ranks, one RCCL gather to rank 0 per frame, gather of frame k overlapped with render of frame k+1" if world > 1 else "65x65 reference tiles, one GPU",
+                   "sampling": "renderTile, 1 primary ray/pixel" if args.mode == 0 else "renderTileSubsample (adaptive, 1/8..2 primary rays/pixel)", "launches_in_flight": sf.n, "frames_per_launch": sf.G, "frame_product": "packed 0x00RRGGBB framebuffer (trace + blitTile fused, 4 B/pixel)" if args.product == "packed" else "float (r,g,b,a,depth) per pixel, 20 B/pixel", "tiles": f"65x65 reference tiles, round-robin over ranks; a launch renders a rank's tiles of {sf.G} frames, one RCCL gather to rank 0 per launch, overlapped with the next launch" if world > 1 else "65x65 reference tiles, one GPU",
                    "scene_setup_s": round(setup_s, 2), "device_bytes": info["device_bytes"]},
         "roofline": roofline, "cpu_baseline": cpu,
     }

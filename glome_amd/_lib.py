@@ -55,6 +55,7 @@ SYMBOLS = [
     ("glome_ctx_use_stream", C.c_int, [vp, vp]),
     ("glome_ctx_use_slot", C.c_int, [vp, vp, C.c_int]),
     ("glome_ctx_timing_begin", C.c_int, [vp, C.c_int]),
+    ("glome_ctx_timing_begin_sampled", C.c_int, [vp, C.c_int, C.c_int]),
     ("glome_ctx_timing_end", C.c_int, [vp, c_fp, C.c_int]),
     ("glome_ctx_device_info", C.c_int, [vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("glome_xfm_translate", C.c_int, [c_dp, c_dp]),
@@ -116,6 +117,8 @@ SYMBOLS = [
     ("glome_tiles_blit_all_dev", C.c_int, [vp, C.POINTER(RenderParams), C.c_int, vp, C.c_int64, vp, vp]),
     ("glome_render_tiles_packed_dev", C.c_int, [vp, C.POINTER(Camera), C.POINTER(Light), C.c_int, C.POINTER(RenderParams), vp, C.POINTER(Stats)]),
     ("glome_tiles_blit_all_packed_dev", C.c_int, [vp, C.POINTER(RenderParams), C.c_int, vp, C.c_int64, vp]),
+    ("glome_render_tiles_packed_batch_dev", C.c_int, [vp, C.POINTER(Camera), C.c_int, C.POINTER(Light), C.c_int, C.POINTER(RenderParams), vp, C.c_int64, C.POINTER(Stats)]),
+    ("glome_render_packed_batch_dev", C.c_int, [vp, C.POINTER(Camera), C.c_int, C.POINTER(Light), C.c_int, C.POINTER(RenderParams), vp, C.c_int64, C.POINTER(Stats)]),
 ]
 
 _lib = None

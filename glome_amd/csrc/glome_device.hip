@@ -173,9 +173,11 @@ __device__ __forceinline__ void render_loop(const DRenderArgs& A, TIER& T) {
   int lane = threadIdx.x & 63;
   for (;;) {
     uint32_t w = 0;
-    if (lane == 0) w = atomicAdd(&A.counters->next_work, 1u);
+    if (lane == 0) w = atomicAdd(&A.counters->next_work, 1u) - A.work_base;
     w = __shfl(w, 0, 64);
-    if (w >= A.total_waves) break;
+    if (w >= A.total_waves * (uint32_t)A.nframes) break;
+    const uint32_t frame = w / A.total_waves;  // wave-uniform
+    w -= frame * A.total_waves;
 #if defined(GLOME_EXP_TIMING)
     unsigned long long tw0 = __builtin_readcyclecounter();
 #endif
@@ -184,7 +186,7 @@ __device__ __forceinline__ void render_loop(const DRenderArgs& A, TIER& T) {
     const bool valid = work_to_pixel(A, w, lane, px, py, dense_off);  // lanes past the end of a leftover strip idle along
     float xc, yc;
     get_coordsf(A.width, A.height, (float)px, (float)py, xc, yc);
-    Ray ray = primary_ray(A.cam, xc, yc);
+    Ray ray = primary_ray(frame == 0 ? A.cam : A.more_cams[frame - 1], xc, yc);
     if (valid) T.cnt.primary++;
     HitG h;
     CA c = trace_primary(T, ray, kInf, A.maxdepth, valid, &h);  // Trace.trace lights shader sld ray infinity maxdepth (Glome.hs:33)
@@ -192,14 +194,19 @@ __device__ __forceinline__ void render_loop(const DRenderArgs& A, TIER& T) {
     float depth = h.hit ? h.t : kInf;      // ridepth
     float r = c.r;
     if (A.fog) r = r + (depth / 400);      // renderTile's debug fog (Glome.hs:174, Q20)
-    size_t o = A.dense ? dense_off : (size_t)py * A.width + px;
+    size_t o = (A.dense ? dense_off : (size_t)py * A.width + px) + (size_t)frame * A.frame_stride;
     if (A.out5) {
       float* out = A.out5 + o * 5;
       out[0] = r; out[1] = c.g; out[2] = c.b; out[3] = c.a; out[4] = depth;
     }
     if (A.packed) A.packed[o] = rgbf(r * c.a, c.g * c.a, c.b * c.a);  // blitTile (Glome.hs:353-358)
 #if defined(GLOME_EXP_TIMING)
-    if (lane == 0) T.cnt.mesh += (uint32_t)(__builtin_readcyclecounter() - tw0);
+    if (lane == 0) {
+      unsigned long long dtc = __builtin_readcyclecounter() - tw0;
+      T.cnt.mesh += (uint32_t)dtc;
+      atomicMax(&A.counters->rays_secondary, dtc);  // experiment only: the longest item
+    }
+    { unsigned int d32 = (unsigned int)(__builtin_readcyclecounter() - tw0); d32 = __shfl(d32, 0, 64); if (A.out5) A.out5[o * 5 + 4] = (float)d32; }
 #endif
   }
 }
@@ -435,6 +442,7 @@ struct glome_ctx {
   std::vector<hipEvent_t> pool;
   int pool_used = 0;
   bool timing = false;
+  int timing_stride = 1, timing_seen = 0;  // every timing_stride-th launch is timed
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipDeviceProp_t prop;
   // Per-slot launch state, so several frames can be in flight on different streams (their work queues, counters and
@@ -445,8 +453,11 @@ struct glome_ctx {
     size_t ovf_bytes = 0;
     float* d_scratch = nullptr;  // adaptive sampler working buffer
     size_t scratch_bytes = 0;
+    // value of d_counters->next_work once the launches queued on this slot have run: a render launch that needs no
+    // statistics does not reset the counters, it takes its work items relative to this base (one stream packet per frame)
+    uint32_t work_base = 0;
   };
-  static constexpr int kSlots = 4;
+  static constexpr int kSlots = 8;
   Slot slots[kSlots];
   int cur = 0;
   Slot& slot() { return slots[cur]; }
@@ -531,7 +542,7 @@ glome_ctx* glome_ctx_create(int device_ordinal) {
   if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return fail("hipEventCreate", e);
   if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return fail("hipEventCreate", e);
   for (int k = 0; k < glome_ctx::kSlots; k++)
-    if ((e = hipMalloc((void**)&c->slots[k].d_counters, sizeof(DCounters))) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipMalloc((void**)&c->slots[k].d_counters, sizeof(DCounters))) != hipSuccess || (e = hipMemset(c->slots[k].d_counters, 0, sizeof(DCounters))) != hipSuccess) return fail("hipMalloc", e);
   return c;
 }
 void glome_ctx_destroy(glome_ctx* c) {
@@ -572,7 +583,13 @@ int glome_ctx_timing_begin(glome_ctx* c, int max_launches) {
   }
   c->pool_used = 0;
   c->timing = true;
+  c->timing_stride = 1; c->timing_seen = 0;
   return 0;
+}
+int glome_ctx_timing_begin_sampled(glome_ctx* c, int max_launches, int stride) {
+  int rc = glome_ctx_timing_begin(c, max_launches);
+  if (rc == 0) c->timing_stride = stride < 1 ? 1 : stride;
+  return rc;
 }
 int glome_ctx_timing_end(glome_ctx* c, float* ms_out, int cap) {
   if (!c) return GLOME_E_INVALID;
@@ -695,6 +712,12 @@ static int check_device_error(glome_ctx* ctx) {
   return 0;
 }
 
+static int reset_counters(glome_ctx* ctx) {
+  HIPCHK(ctx, hipMemsetAsync(ctx->slot().d_counters, 0, sizeof(DCounters), ctx->stream));
+  ctx->slot().work_base = 0;
+  return 0;
+}
+
 static void launch_render(glome_scene* s, const DRenderArgs& A, const glome_render_params* P, int grid, size_t lds) {
   hipStream_t st = s->ctx->stream;
   bool faithful = P->faithful != 0, count = P->count_work != 0 || faithful;
@@ -731,7 +754,7 @@ static void launch_render(glome_scene* s, const DRenderArgs& A, const glome_rend
 }
 
 static int render_impl(glome_scene* s, const glome_camera* cam, const glome_light* lights, int nlights, const glome_render_params* P,
-                       float* rgbad_dev, uint32_t* packed_dev, glome_stats* stats, int dense) {
+                       float* rgbad_dev, uint32_t* packed_dev, glome_stats* stats, int dense, int nframes = 1, int64_t frame_stride = 0) {
   if (!s) return GLOME_E_INVALID;
   glome_ctx* ctx = s->ctx;
   if (!cam || (!rgbad_dev && !(dense != 1 && packed_dev)) || nlights < 0 || (nlights > 0 && !lights)) { ctx->err = "bad argument"; return GLOME_E_INVALID; }
@@ -747,6 +770,10 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
   memset(&A, 0, sizeof(A));
   A.S = s->dev;
   memcpy(&A.cam, cam, sizeof(DCamera));
+  if (nframes < 1 || nframes > kMaxBatchFrames) { ctx->err = "a launch carries 1..8 frames"; return GLOME_E_LIMIT; }
+  if (nframes > 1 && (P->mode != GLOME_MODE_TILE || frame_stride <= 0 || frame_stride > 0xffffffffll)) { ctx->err = "frame batches: renderTile mode, positive frame stride"; return GLOME_E_INVALID; }
+  for (int f = 1; f < nframes; f++) memcpy(&A.more_cams[f - 1], cam + f, sizeof(DCamera));
+  A.nframes = nframes; A.frame_stride = nframes > 1 ? (uint32_t)frame_stride : 0u;
   for (int i = 0; i < nlights; i++) {
     memcpy(A.lights[i].pos, lights[i].pos, 12); memcpy(A.lights[i].color, lights[i].color, 12);
     A.lights[i].rad = lights[i].rad; A.lights[i].shadow = lights[i].shadow;
@@ -756,7 +783,11 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
   A.tiles = tt->dev; A.ntiles = (int)tt->host.size(); A.total_waves = tt->total_waves;
   // dense 0: full frame (rgbad and / or packed); 1: dense rgbad tile payload; 2: dense packed-pixel tile payload only
   A.out5 = dense == 2 ? nullptr : rgbad_dev; A.packed = dense == 1 ? nullptr : packed_dev; A.counters = ctx->slot().d_counters; A.dense = dense != 0;
-  HIPCHK(ctx, hipMemsetAsync(ctx->slot().d_counters, 0, sizeof(DCounters), ctx->stream));
+  // a plain frame (no statistics wanted, renderTile mode) does not reset the counters: its work queue starts at the
+  // slot's running base, so the frame is a single packet on the stream
+  const bool bare = !stats && P->mode == GLOME_MODE_TILE && !P->faithful && !P->count_work && ctx->slot().work_base < 0x70000000u;
+  if (!bare && (rc = reset_counters(ctx))) return rc;
+  A.work_base = ctx->slot().work_base;
   hipEvent_t ev_start = ctx->ev0, ev_stop = ctx->ev1;
   if (A.ntiles > 0 && P->mode == GLOME_MODE_SUBSAMPLE) {
     // scratch: v (5 floats per owned pixel) | list (one u32 per owned pixel) | 16 counters (list lengths, queue heads)
@@ -767,7 +798,7 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
     A.ss_cnt = (unsigned int*)(A.ss_list + npx);
     A.total_pixels = (uint32_t)npx;
     HIPCHK(ctx, hipMemsetAsync(A.ss_cnt, 0, 16 * sizeof(unsigned int), ctx->stream));
-    bool pooled = ctx->timing && ctx->pool_used + 2 <= (int)ctx->pool.size();
+    bool pooled = ctx->timing && (ctx->timing_seen++ % ctx->timing_stride) == 0 && ctx->pool_used + 2 <= (int)ctx->pool.size();
     hipEvent_t e0 = pooled ? ctx->pool[ctx->pool_used] : ctx->ev0, e1 = pooled ? ctx->pool[ctx->pool_used + 1] : ctx->ev1;
     if (pooled) ctx->pool_used += 2;
     ev_start = e0; ev_stop = e1;
@@ -792,16 +823,18 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
     HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
   } else if (A.ntiles > 0) {
     size_t lds = s->dev.tier == 0 ? flat_lds_bytes(s->stack_cap) : 0;
-    int grid = persistent_grid(ctx, lds, A.total_waves);
+    int grid = persistent_grid(ctx, lds, A.total_waves * (uint32_t)nframes);
     if (s->dev.tier == 0 && s->ovf_cap && (rc = ensure_overflow(ctx, grid, 1, s->ovf_cap))) return rc;
-    bool pooled = ctx->timing && ctx->pool_used + 2 <= (int)ctx->pool.size();
+    bool pooled = ctx->timing && (ctx->timing_seen++ % ctx->timing_stride) == 0 && ctx->pool_used + 2 <= (int)ctx->pool.size();
     hipEvent_t e0 = pooled ? ctx->pool[ctx->pool_used] : ctx->ev0, e1 = pooled ? ctx->pool[ctx->pool_used + 1] : ctx->ev1;
     if (pooled) ctx->pool_used += 2;
     ev_start = e0; ev_stop = e1;
-    HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
+    const bool timed = stats || pooled;
+    if (timed) HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
     launch_render(s, A, P, grid, lds);
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
+    if (timed) HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
+    ctx->slot().work_base += A.total_waves * (uint32_t)nframes + (uint32_t)grid;  // every wave of the grid takes one ticket past the end
   }
   if (stats) {
     memset(stats, 0, sizeof(*stats));
@@ -828,6 +861,15 @@ int glome_render_tiles_dev(glome_scene* s, const glome_camera* cam, const glome_
 int glome_render_tiles_packed_dev(glome_scene* s, const glome_camera* cam, const glome_light* lights, int nlights, const glome_render_params* P,
                                   uint32_t* payload_dev, glome_stats* stats) {
   return render_impl(s, cam, lights, nlights, P, nullptr, payload_dev, stats, 2);
+}
+
+int glome_render_tiles_packed_batch_dev(glome_scene* s, const glome_camera* cams, int nframes, const glome_light* lights, int nlights,
+                                        const glome_render_params* P, uint32_t* payload_dev, int64_t frame_stride_pixels, glome_stats* stats) {
+  return render_impl(s, cams, lights, nlights, P, nullptr, payload_dev, stats, 2, nframes, frame_stride_pixels);
+}
+int glome_render_packed_batch_dev(glome_scene* s, const glome_camera* cams, int nframes, const glome_light* lights, int nlights,
+                                  const glome_render_params* P, uint32_t* packed_dev, int64_t frame_stride_pixels, glome_stats* stats) {
+  return render_impl(s, cams, lights, nlights, P, nullptr, packed_dev, stats, 0, nframes, frame_stride_pixels);
 }
 
 int glome_render(glome_scene* s, const glome_camera* cam, const glome_light* lights, int nlights, const glome_render_params* P, float* rgbad,
@@ -877,7 +919,7 @@ int glome_rayint_batch_dev(glome_scene* s, size_t n, const float* ox, const floa
     if (s->ovf_cap && (rc = ensure_overflow(ctx, grid, 1, s->ovf_cap))) return rc;
     hipLaunchKernelGGL((k_rayint_batch_flat<false>), dim3(grid), dim3(64), lds, ctx->stream, s->dev, n, R, H, s->stack_cap, s->ovf_cap ? ctx->slot().d_ovf : nullptr, s->ovf_cap);
   } else {
-    HIPCHK(ctx, hipMemsetAsync(ctx->slot().d_counters, 0, sizeof(DCounters), ctx->stream));
+    if (int rcc = reset_counters(ctx)) return rcc;
     hipLaunchKernelGGL(k_rayint_batch_generic, dim3(batch_grid(ctx, n, 0)), dim3(64), 0, ctx->stream, s->dev, n, R, H, ctx->slot().d_counters);
   }
   HIPCHK(ctx, hipGetLastError());
@@ -897,7 +939,7 @@ int glome_shadow_batch_dev(glome_scene* s, size_t n, const float* ox, const floa
     if (s->ovf_cap && (rc = ensure_overflow(ctx, grid, 1, s->ovf_cap))) return rc;
     hipLaunchKernelGGL(k_shadow_batch_flat, dim3(grid), dim3(64), lds, ctx->stream, s->dev, n, R, occluded, s->stack_cap, s->ovf_cap ? ctx->slot().d_ovf : nullptr, s->ovf_cap);
   } else {
-    HIPCHK(ctx, hipMemsetAsync(ctx->slot().d_counters, 0, sizeof(DCounters), ctx->stream));
+    if (int rcc = reset_counters(ctx)) return rcc;
     hipLaunchKernelGGL(k_shadow_batch_generic, dim3(batch_grid(ctx, n, 0)), dim3(64), 0, ctx->stream, s->dev, n, R, occluded, ctx->slot().d_counters);
   }
   HIPCHK(ctx, hipGetLastError());
@@ -975,7 +1017,7 @@ int glome_inside_batch(glome_scene* s, size_t n, const float* px, const float* p
   float *dx = st.in(px, n), *dy = st.in(py, n), *dz = st.in(pz, n);
   uint8_t* din = st.in<uint8_t>(nullptr, n);
   if (!dx || !dy || !dz || !din) { ctx->err = "staging allocation failed"; return GLOME_E_HIP; }
-  HIPCHK(ctx, hipMemsetAsync(ctx->slot().d_counters, 0, sizeof(DCounters), ctx->stream));
+  if (int rcc = reset_counters(ctx)) return rcc;
   hipLaunchKernelGGL(k_inside_batch, dim3(batch_grid(ctx, n, 0)), dim3(64), 0, ctx->stream, s->dev, n, dx, dy, dz, din, ctx->slot().d_counters);
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

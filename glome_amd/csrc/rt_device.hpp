@@ -91,6 +91,8 @@ GD bool wave_any(bool p) { return __ballot(p) != 0ull; }
 GD bool lane_of(LaneMask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }  // this lane's bit (m is wave-uniform)
 GD uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }  // a value every lane agrees on -> SGPR
 GD LaneMask uni(LaneMask m) { return (LaneMask)uni((uint32_t)m) | ((LaneMask)uni((uint32_t)(m >> 32)) << 32); }
+// v of the lowest lane set in m (m != 0, wave-uniform)
+GD uint32_t first_lane_value(LaneMask m, uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_ctzll(m)); }
 // loads at a wave-uniform index through the constant address space with a 32-bit byte offset, so they become scalar
 // loads (s_load_dwordx4 sdst, sbase, soffset); `i` counts 16-byte words and the pools are far below 4 GiB
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -125,6 +127,7 @@ GD bool wave_any(bool p) { return p; }
 GD bool lane_of(LaneMask m) { return (m & 1ull) != 0; }
 GD uint32_t uni(uint32_t v) { return v; }
 GD LaneMask uni(LaneMask m) { return m; }
+GD uint32_t first_lane_value(LaneMask, uint32_t v) { return v; }
 GD F4 ld4u(const F4* p, uint32_t i) { return p[i]; }
 #define LD_NODE ld4u
 GD void ld_tri_u(const F4* p, uint32_t tri, F4& q0, F4& q1, F4& q2) { q0 = p[3 * tri]; q1 = p[3 * tri + 1]; q2 = p[3 * tri + 2]; }
@@ -744,25 +747,34 @@ GD bool bih_tri_wave(const DScene& S, uint32_t hdr, const Ray& r, float d, bool 
   F4 h0 = ld4u(S.bihhdr, 3 * hdr), h1 = ld4u(S.bihhdr, 3 * hdr + 1);
   const uint32_t delta = uni(as_u(ld4u(S.bihhdr, 3 * hdr + 2).x));
   const uint32_t ref = uni(as_u(h0.w));
+  if (ref & BREF_LEAF) return valid ? bih_tri<MODE, COUNT, LEAFK>(S, hdr, r, d, stk, cnt, best_t, best_rec) : false;  // a one-leaf tree
   const V3 rcp = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
-  const LaneMask vm = wave_ballot(valid);
-  const LaneMask sx = wave_ballot(valid && rcp.x > 0), sy = wave_ballot(valid && rcp.y > 0), sz = wave_ballot(valid && rcp.z > 0);
-  const bool packet = !(ref & BREF_LEAF) && (sx == 0 || sx == vm) && (sy == 0 || sy == vm) && (sz == 0 || sz == vm);
-  if (!packet) return valid ? bih_tri<MODE, COUNT, LEAFK>(S, hdr, r, d, stk, cnt, best_t, best_rec) : false;
-  const uint32_t fwdbits = uni((sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u));  // per axis: do the rays run towards +axis
   float nearv, farv;
   bbclip_ub(r, v3(h0), v3(h1), nearv, farv);
   farv = gminf(d, farv);  // `traverse root near (fmin d far)`, Bih.hs:368
+  if (COUNT) { if (valid && nearv > farv) cnt.bih++; }  // a root branch entered with an empty interval is counted and left (Bih.hs:343)
+  // Children are taken near-first by the signs of the ray direction, so one packet needs one sign pattern.  Almost
+  // every wave has a single pattern; a block straddling an axis plane through the eye has two or four, and is walked
+  // once per pattern with the other lanes switched off (a lane takes part in exactly one walk).
+  const uint32_t oct = (rcp.x > 0 ? 1u : 0u) | (rcp.y > 0 ? 2u : 0u) | (rcp.z > 0 ? 4u : 0u);
   // `am`: the lanes whose ray has a non-empty interval in the current node.  Their (near, far) are live; the other
   // lanes' are don't-cares, so no sentinel values are needed and plain min / max serve (a NaN plane distance only
   // arises on a lane that fails the activity test of that child).
-  const LaneMask am = wave_ballot(valid && !(nearv > farv));
-  if (COUNT) { if (valid && nearv > farv) cnt.bih++; }  // a root branch entered with an empty interval is counted and left (Bih.hs:343)
-  if (am == 0) return false;
-  PacketResult R = bih_tri_packet<MODE, COUNT, LEAFK, STK>(S.bihnodes, LEAFK == 0 ? S.tris : S.spheres, ref, delta, fwdbits, (uint32_t)am, (uint32_t)(am >> 32), nearv, farv, r.o, r.d, rcp, best_t, stk);
-  if (COUNT) { cnt.bih += R.n_bih; cnt.prim += R.n_prim; }
-  if (MODE != 2 && R.best_rec != kNoRec) { best_t = R.best_t; best_rec = R.best_rec; }
-  return MODE == 2 ? lane_of((LaneMask)R.occ_lo | ((LaneMask)R.occ_hi << 32)) : false;
+  LaneMask todo = wave_ballot(valid && !(nearv > farv));
+  bool occ = false;
+  while (todo != 0) {
+    const uint32_t fwdbits = uni(first_lane_value(todo, oct));  // per axis: do the rays of this walk run towards +axis
+    const LaneMask am = todo & wave_ballot(oct == fwdbits);
+    todo &= ~am;
+    PacketResult R = bih_tri_packet<MODE, COUNT, LEAFK, STK>(S.bihnodes, LEAFK == 0 ? S.tris : S.spheres, ref, delta, fwdbits, (uint32_t)am, (uint32_t)(am >> 32),
+                                                              nearv, farv, r.o, r.d, rcp, best_t, stk);
+    if (lane_of(am)) {
+      if (COUNT) { cnt.bih += R.n_bih; cnt.prim += R.n_prim; }
+      if (MODE != 2 && R.best_rec != kNoRec) { best_t = R.best_t; best_rec = R.best_rec; }
+      if (MODE == 2) occ = lane_of((LaneMask)R.occ_lo | ((LaneMask)R.occ_hi << 32));
+    }
+  }
+  return occ;
 }
 
 // ------------------------------------------------------------------ Mesh 2-box BVH (Mesh.hs:136-198; Q12)

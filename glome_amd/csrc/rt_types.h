@@ -52,7 +52,8 @@ constexpr int kGenericDepth = 6;   // composite nesting levels the generic inter
 constexpr int kCsgMaxAdvance = 32; // ray-advance steps per CSG node before giving up (reference: unbounded)
 constexpr int kIsectFrames = 40;   // explicit frames for rayint_intersection's list recursion
 constexpr int kMaxTraceDepth = 4;  // maxdepth values the render kernels are instantiated for
-constexpr int kMaxMatNest = 2;     // Blend / AdditiveLayers nesting the shader is instantiated for
+constexpr int kMaxMatNest = 2;
+constexpr int kMaxBatchFrames = 8;  // frames one render launch can carry     // Blend / AdditiveLayers nesting the shader is instantiated for
 
 struct F4 { float x, y, z, w; };
 struct U4 { uint32_t x, y, z, w; };
@@ -105,6 +106,7 @@ struct DRenderArgs {
   const DTile* tiles;  // owned tiles
   int32_t ntiles;
   uint32_t total_waves;
+  uint32_t work_base;   // value of counters->next_work when this launch starts (0 after a counter reset)
   int32_t dense;       // 1: out5 is a dense tile payload (tile order, row major inside a tile) instead of a frame
   float* scratch;      // adaptive sampler: dense per-tile working buffer `v` (owned pixels * 5 floats)
   uint32_t* ss_list;   // adaptive sampler: pixels (dense index) that need a traced sample in the current pass
@@ -113,6 +115,11 @@ struct DRenderArgs {
   float* out5;         // width*height*5
   uint32_t* packed;    // width*height or null
   DCounters* counters;
+  // several independent frames in one launch (same scene and lights, one camera each): frame f's work items follow
+  // frame f-1's in the queue, its pixels go frame_stride pixels further into out5 / packed
+  int32_t nframes;
+  uint32_t frame_stride;
+  DCamera more_cams[kMaxBatchFrames - 1];
 };
 
 }  // namespace glome

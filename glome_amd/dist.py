@@ -76,59 +76,74 @@ class ShardPlan:
 
 
 class FramePipeline:
-    """Frames are independent, so several are kept in flight:
+    """Frames are independent, so they are rendered and moved in groups of G, several groups in flight:
 
-        step k:   on lane k % n:  render(k) -> payload[k % n] ; start gather(k) (asynchronous)
-                  then finish frame k-1 on its own lane (wait its gather, blit it)
+        step(view):  buffer the view; with the G-th view of a group, on lane s = group index % n:
+                         render_group(s, payload[s], views)    ONE launch renders the rank's tiles of all G frames
+                         ONE gather moves the group's payload   (asynchronous)
+                     then the oldest pending group is finished: wait for its gather, blit its G frames.
 
-    Each lane is a (HIP stream, context slot) pair: the render kernel of frame k+1 starts filling the GPU while the tail
-    of frame k's persistent kernel drains, and the collective of frame k (on the backend's own stream) runs under the
-    render of frame k+1.  `flush()` completes the frames still in flight.  render(slot, payload) and blit(slot, gathered)
-    are callables and `lane(slot)` a context manager, so the same control flow is exercised on CPU tensors with gloo
+    A rank's share of one frame is a few thousand work items -- not enough to fill the GPU beyond its slowest item --
+    and a collective and a launch per frame cost more host time than the frame's GPU work; a group restores long launches
+    and amortises both.  A lane is a (HIP stream, context slot) pair: the launch of group k+1 overlaps the tail of group
+    k's, and group k's collective (on the backend's own stream) runs under the render of group k+1.  `flush()` completes
+    what is in flight (a partial group included).  render_group(slot, payload, views), blit(slot, row, gathered) and
+    lane(slot) (a context manager) are callables, so the same control flow is exercised on CPU tensors with gloo
     (tests/test_dist_gloo.py)."""
 
-    def __init__(self, plan, payloads, gathereds, render, blit, lane=None):
+    def __init__(self, plan, payloads, gathereds, render_group, blit, lane=None, group=1):
         import contextlib
-        self.plan, self.payloads, self.gathereds, self.render, self.blit = plan, payloads, gathereds, render, blit
+        self.plan, self.payloads, self.gathereds, self.render_group, self.blit = plan, payloads, gathereds, render_group, blit
         self.lane = lane if lane is not None else (lambda slot: contextlib.nullcontext())
-        self.n = len(payloads)
-        self.k = 0
+        self.G = int(group)
+        self.n = len(payloads)  # lanes = groups in flight
+        self.k = 0              # groups launched
+        self.views = []
         self.pending = []
         self.done = 0
 
-    def step(self):
+    def _launch(self):
         slot = self.k % self.n
+        views, self.views = self.views, []
         with self.lane(slot):
-            self.render(slot, self.payloads[slot])
-            work = self.plan.gather(self.payloads[slot], self.gathereds[slot] if self.plan.rank == 0 else None, async_op=True)
-        self.pending.append((slot, work))
+            self.render_group(slot, self.payloads[slot], views)
+            work = self.plan.gather(self.payloads[slot].view(-1), self.gathereds[slot] if self.plan.rank == 0 else None, async_op=True)
+        self.pending.append((slot, len(views), work))
         self.k += 1
-        while len(self.pending) > self.n - 1 or len(self.pending) > 1:
-            self._finish(self.pending.pop(0))
+
+    def step(self, view=None):
+        self.views.append(view)
+        if len(self.views) == self.G:
+            self._launch()
+            while len(self.pending) > max(self.n - 1, 1) or (self.n == 1 and self.pending):
+                self._finish(self.pending.pop(0))
 
     def _finish(self, pending):
-        slot, work = pending
+        slot, nrows, work = pending
         with self.lane(slot):
             work.wait()  # RCCL: this lane's stream waits for the collective; gloo: the host does
             if self.plan.rank == 0:
-                self.blit(slot, self.gathereds[slot])
-        self.done += 1
+                for g in range(nrows):
+                    self.blit(slot, g, self.gathereds[slot])
+        self.done += nrows
 
     def flush(self):
+        if self.views:  # a partial group
+            self._launch()
         while self.pending:
             self._finish(self.pending.pop(0))
 
 
 class ShardedFrame:
-    """Renders one frame per step() over all ranks of the default process group; frames land on rank 0.
-    Up to `lanes` frames are in flight (each on its own HIP stream and context slot): call flush() before reading
-    `frame` (the most recently completed one on rank 0).
+    """Renders frames over all ranks of the default process group; frames land on rank 0.  `lanes` groups of `group`
+    frames are in flight (each group on its own HIP stream and context slot): call flush() before reading `frame` (the
+    most recently completed one on rank 0).
 
     product: "packed" -- the frame is GlomeView's framebuffer, one 0x00RRGGBB word per pixel (int32 [h, w]); trace and
     blitTile are fused and 4 bytes per pixel cross xGMI.  "rgbad" -- the float (r, g, b, a, depth) tuples ([h, w, 5]),
-    20 bytes per pixel."""
+    20 bytes per pixel (one frame per launch)."""
 
-    def __init__(self, scene, params, rank, world, device, lanes=4, product="rgbad"):
+    def __init__(self, scene, params, rank, world, device, lanes=4, product="rgbad", group=1):
         import torch
         self.torch = torch
         self.scene, self.ctx, self.lib = scene, scene.ctx, scene.lib
@@ -138,77 +153,115 @@ class ShardedFrame:
         self.plan = ShardPlan(params, rank, world, unit=1 if self.packed else 5)
         self.rank, self.world, self.device = rank, world, device
         self.P, self.P_local = self.plan.P, self.plan.P_local
-        h, w = params.height, params.width
-        self.n = max(1, min(int(lanes), 4))
+        self.h, self.w = params.height, params.width
+        self.n = max(1, min(int(lanes), 8))  # the context has 8 launch slots
+        self.G = max(1, min(int(group), 8)) if self.packed else 1  # frames per launch (and per gather)
         self.streams = [torch.cuda.Stream(device=device) for _ in range(self.n)]
         dt = torch.int32 if self.packed else torch.float32
-        self.frames = [torch.zeros((h, w) if self.packed else (h, w, 5), dtype=dt, device=device) for _ in range(self.n)] if rank == 0 else None
-        self.last = 0
+        shape = (self.G, self.h, self.w) if self.packed else (self.G, self.h, self.w, 5)
+        self.frames = [torch.zeros(shape, dtype=dt, device=device) for _ in range(self.n)] if rank == 0 else None
+        self.last = (0, 0)
         self.k = 0
-        self.cam = self.lights = self.la = None
+        self.batch = []
+        self.lights = self.la = None
         if world > 1:
-            payloads = [torch.zeros(self.plan.maxp, dtype=dt, device=device) for _ in range(self.n)]
-            gathereds = [torch.zeros((world, self.plan.maxp), dtype=dt, device=device) if rank == 0 else None for _ in range(self.n)]
-            self.pipe = FramePipeline(self.plan, payloads, gathereds, self._render, self._blit, self._lane)
+            payloads = [torch.zeros(self.G * self.plan.maxp, dtype=dt, device=device) for _ in range(self.n)]
+            gathereds = [torch.zeros((world, self.G * self.plan.maxp), dtype=dt, device=device) if rank == 0 else None for _ in range(self.n)]
+            self.pipe = FramePipeline(self.plan, payloads, gathereds, self._render_group, self._blit, self._lane, group=self.G)
         torch.cuda.synchronize(device)
 
     @property
     def frame(self):
-        return self.frames[self.last] if self.frames is not None else None
+        return self.frames[self.last[0]][self.last[1]] if self.frames is not None else None
 
     def _lane(self, slot):
         s = self.streams[slot]
         self.lib.glome_ctx_use_slot(self.ctx.h, C.c_void_p(s.cuda_stream), slot)
         return self.torch.cuda.stream(s)
 
-    def _render(self, slot, payload, stats=None):
-        fn = self.lib.glome_render_tiles_packed_dev if self.packed else self.lib.glome_render_tiles_dev
-        rc = fn(self.scene.h, C.byref(self.cam), self.la, len(self.lights), C.byref(self.P_local),
-                                             C.c_void_p(payload.data_ptr()), C.byref(stats) if stats is not None else None)
-        if rc != 0:
-            raise api.GlomeError("glome_render_tiles_dev: " + self.ctx.err())
+    def _cams(self, views):
+        cams = (L.Camera * len(views))()
+        for i, v in enumerate(views):
+            C.memmove(C.byref(cams[i]), C.byref(v), C.sizeof(L.Camera))
+        return cams
 
-    def _blit(self, slot, gathered):
+    def _render_group(self, slot, payload, views, stats=None):
+        st = C.byref(stats) if stats is not None else None
         if self.packed:
-            rc = self.lib.glome_tiles_blit_all_packed_dev(self.ctx.h, C.byref(self.P), self.world, C.c_void_p(gathered.data_ptr()), self.plan.maxp,
-                                                          C.c_void_p(self.frames[slot].data_ptr()))
+            rc = self.lib.glome_render_tiles_packed_batch_dev(self.scene.h, self._cams(views), len(views), self.la, len(self.lights), C.byref(self.P_local),
+                                                              C.c_void_p(payload.data_ptr()), self.plan.maxp, st)
         else:
-            rc = self.lib.glome_tiles_blit_all_dev(self.ctx.h, C.byref(self.P), self.world, C.c_void_p(gathered.data_ptr()), self.plan.maxp,
-                                                   C.c_void_p(self.frames[slot].data_ptr()), None)
+            rc = self.lib.glome_render_tiles_dev(self.scene.h, C.byref(views[0]), self.la, len(self.lights), C.byref(self.P_local), C.c_void_p(payload.data_ptr()), st)
         if rc != 0:
-            raise api.GlomeError("glome_tiles_blit_all_dev: " + self.ctx.err())
-        self.last = slot
+            raise api.GlomeError("render tiles: " + self.ctx.err())
 
-    def set_view(self, cam, lights):
-        self.cam, self.lights = cam, lights
+    def _blit(self, slot, g, gathered):
+        # rank r's slab starts at r * (G * maxp); frame g of the group sits g * maxp words into every slab
+        base = C.c_void_p(gathered.data_ptr() + g * self.plan.maxp * gathered.element_size())
+        stride = self.G * self.plan.maxp
+        dst = C.c_void_p(self.frames[slot][g].data_ptr())
+        if self.packed:
+            rc = self.lib.glome_tiles_blit_all_packed_dev(self.ctx.h, C.byref(self.P), self.world, base, stride, dst)
+        else:
+            rc = self.lib.glome_tiles_blit_all_dev(self.ctx.h, C.byref(self.P), self.world, base, stride, dst, None)
+        if rc != 0:
+            raise api.GlomeError("blit: " + self.ctx.err())
+        self.last = (slot, g)
+
+    def set_lights(self, lights):
+        self.lights = lights
         self.la = (L.Light * max(1, len(lights)))(*lights)
 
+    def _launch_local(self):
+        """world == 1: the batch goes straight into this lane's frames (no payload, no collective)."""
+        slot = self.k % self.n
+        self.k += 1
+        views, self.batch = self.batch, []
+        with self._lane(slot):
+            fp = self.frames[slot].data_ptr()
+            if self.packed:
+                rc = self.lib.glome_render_packed_batch_dev(self.scene.h, self._cams(views), len(views), self.la, len(self.lights), C.byref(self.P),
+                                                            C.c_void_p(fp), self.h * self.w, None)
+            else:
+                rc = self.lib.glome_render_dev(self.scene.h, C.byref(views[0]), self.la, len(self.lights), C.byref(self.P), C.c_void_p(fp), None, None)
+            if rc != 0:
+                raise api.GlomeError("render: " + self.ctx.err())
+        self.last = (slot, len(views) - 1)
+
     def step(self, cam, lights, stats=False):
-        """One frame.  stats=True renders it alone (no overlap) and returns this rank's stats dict (it synchronises)."""
-        if cam is not self.cam or lights is not self.lights:
-            self.set_view(cam, lights)
+        """One frame (the view `cam`; the lights are shared by the frames of a group).  stats=True renders it alone (no
+        overlap) and returns this rank's stats dict (it synchronises)."""
+        if lights is not self.lights:
+            self.flush()
+            self.set_lights(lights)
         if stats:
             self.flush()
             self.torch.cuda.synchronize(self.device)
-        if self.world == 1:
-            slot = self.k % self.n
-            self.k += 1
-            with self._lane(slot):
-                fp = self.frames[slot].data_ptr()
-                st = self.scene.render_dev(cam, lights, self.P, None if self.packed else fp, fp if self.packed else None, want_stats=stats)
-            self.last = slot
-            return st
-        if stats:
             st = L.Stats()
             with self._lane(0):
-                self._render(0, self.pipe.payloads[0], st)
-                self.plan.gather(self.pipe.payloads[0], self.pipe.gathereds[0] if self.rank == 0 else None)
-                if self.rank == 0:
-                    self._blit(0, self.pipe.gathereds[0])
+                if self.world == 1:
+                    fp = self.frames[0].data_ptr()
+                    rc = self.lib.glome_render_dev(self.scene.h, C.byref(cam), self.la, len(self.lights), C.byref(self.P), None if self.packed else C.c_void_p(fp),
+                                                   C.c_void_p(fp) if self.packed else None, C.byref(st))
+                    if rc != 0:
+                        raise api.GlomeError("render: " + self.ctx.err())
+                else:
+                    self._render_group(0, self.pipe.payloads[0], [cam], st)
+                    self.plan.gather(self.pipe.payloads[0].view(-1), self.pipe.gathereds[0] if self.rank == 0 else None)
+                    if self.rank == 0:
+                        self._blit(0, 0, self.pipe.gathereds[0])
+            self.last = (0, 0)
             return api._stats_dict(st)
-        self.pipe.step()
+        if self.world == 1:
+            self.batch.append(cam)
+            if len(self.batch) == self.G:
+                self._launch_local()
+            return None
+        self.pipe.step(cam)
         return None
 
     def flush(self):
         if self.world > 1:
             self.pipe.flush()
+        elif self.batch:
+            self._launch_local()

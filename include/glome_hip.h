@@ -52,13 +52,16 @@ void* glome_ctx_stream(glome_ctx*);    /* the hipStream_t, for interop */
 int glome_ctx_synchronize(glome_ctx*);
 /* Run on an external HIP stream (e.g. torch's current stream) instead of the context's own; NULL restores it. */
 int glome_ctx_use_stream(glome_ctx*, void* hip_stream);
-/* Several frames in flight: a context has 4 launch slots, each with its own work queue, counters and workspaces.  Select
+/* Several frames in flight: a context has 8 launch slots, each with its own work queue, counters and workspaces.  Select
  * (stream, slot) before a launch; launches that may overlap in time must use different slots (and streams). */
 int glome_ctx_use_slot(glome_ctx*, void* hip_stream, int slot);
 /* Per-launch kernel timing without extra synchronisation: between begin and end every render launch records its own
  * HIP-event pair on the context's stream; end synchronises once and returns the number of launches, writing their
  * durations (ms) to ms_out[0..cap). */
 int glome_ctx_timing_begin(glome_ctx*, int max_launches);
+/* The same, but only every `stride`-th render launch carries an event pair: event records are extra packets on the
+ * launch stream and cost frame rate when a frame is a fraction of a millisecond. */
+int glome_ctx_timing_begin_sampled(glome_ctx*, int max_launches, int stride);
 int glome_ctx_timing_end(glome_ctx*, float* ms_out, int cap);
 int glome_ctx_device_info(glome_ctx*, char* name, int cap, int* cu_count, int* warp_size);
 
@@ -188,6 +191,15 @@ int glome_render_tiles_dev(glome_scene*, const glome_camera*, const glome_light*
  * pixel instead of 20).  GLOME_MODE_TILE and GLOME_MODE_SUBSAMPLE alike. */
 int glome_render_tiles_packed_dev(glome_scene*, const glome_camera*, const glome_light* lights, int nlights,
                                   const glome_render_params*, uint32_t* payload_dev, glome_stats*);
+/* Several independent frames in ONE launch (an animation's next views: same scene and lights, cams[0..nframes), at
+ * most 8).  Frame f's pixels land frame_stride_pixels words after frame f-1's: rows of a dense tile payload
+ * (..._tiles_packed_batch_dev; stride >= this rank's payload size) or whole packed framebuffers (..._packed_batch_dev;
+ * stride >= width*height).  A rank's share of one frame is a few thousand work items -- too little to fill the GPU
+ * beyond its slowest item; a batch restores long launches.  renderTile mode only. */
+int glome_render_tiles_packed_batch_dev(glome_scene*, const glome_camera* cams, int nframes, const glome_light* lights, int nlights,
+                                        const glome_render_params*, uint32_t* payload_dev, int64_t frame_stride_pixels, glome_stats*);
+int glome_render_packed_batch_dev(glome_scene*, const glome_camera* cams, int nframes, const glome_light* lights, int nlights,
+                                  const glome_render_params*, uint32_t* packed_dev, int64_t frame_stride_pixels, glome_stats*);
 /* Tile payload transport for multi-GPU sharding (Tile = Rect + pixel vector, Glome.hs:153-154).
  * pack: copy this rank's owned tiles from a full frame into a dense payload (tiles in owned order, row major
  * inside a tile, 5 floats per pixel).  blit: scatter a payload of the tiles owned by (tile_first, tile_stride)

@@ -55,30 +55,39 @@ def _worker(rank, world, port, outdir):
         for r in range(world):
             dist.blit_numpy(fpx, gat1[r].numpy(), plan1.layout(r))
         np.save(os.path.join(outdir, "frame_packed.npy"), fpx)
-    # the pipelined path (FramePipeline): 5 frames with different lights in flight two at a time
+    # the pipelined path (FramePipeline): frames with different lights, in groups, several groups in flight
     frames = []
-    state = {"k": 0}
 
-    def render(slot, payload_t):
-        k = state["k"]; state["k"] += 1
-        o.clear_lights()
-        o.add_light([-100 + 40 * k, 70, 140], [7000, 5600, 5600])
-        img, _, _ = o.render(W, H, maxdepth=1, tile_first=rank, tile_stride=world, want_packed=False)
-        pk = dist.pack_numpy(img, lay)
-        payload_t[:pk.size] = torch.from_numpy(pk)
+    def render_group(slot, payload_t, views):
+        rows = payload_t.view(-1, plan.maxp)
+        for g, k in enumerate(views):
+            o.clear_lights()
+            o.add_light([-100 + 40 * k, 70, 140], [7000, 5600, 5600])
+            img, _, _ = o.render(W, H, maxdepth=1, tile_first=rank, tile_stride=world, want_packed=False)
+            pk = dist.pack_numpy(img, lay)
+            rows[g][:pk.size] = torch.from_numpy(pk)
 
-    def blit(slot, gathered_t):
+    def blit(slot, g, gathered_t):
         f = np.full((H, W, 5), np.nan)
         for r in range(world):
-            dist.blit_numpy(f, gathered_t[r].numpy(), plan.layout(r))
+            dist.blit_numpy(f, gathered_t[r].numpy()[g * plan.maxp:(g + 1) * plan.maxp], plan.layout(r))
         frames.append(f)
 
+    # one frame per group, three groups in flight
     pipe = dist.FramePipeline(plan, [torch.zeros(plan.maxp, dtype=torch.float64) for _ in range(3)],
-                              [torch.zeros((world, plan.maxp), dtype=torch.float64) if rank == 0 else None for _ in range(3)], render, blit)
-    for _ in range(5):
-        pipe.step()
+                              [torch.zeros((world, plan.maxp), dtype=torch.float64) if rank == 0 else None for _ in range(3)], render_group, blit)
+    for k in range(5):
+        pipe.step(k)
     pipe.flush()
     assert pipe.done == 5
+    # two frames per launch and per collective, two groups in flight, 5 more frames (the last group is partial)
+    G = 2
+    pipe2 = dist.FramePipeline(plan, [torch.zeros(G * plan.maxp, dtype=torch.float64) for _ in range(2)],
+                               [torch.zeros((world, G * plan.maxp), dtype=torch.float64) if rank == 0 else None for _ in range(2)], render_group, blit, group=G)
+    for k in range(5, 10):
+        pipe2.step(k)
+    pipe2.flush()
+    assert pipe2.done == 5 and pipe2.k == 3
     if rank == 0:
         np.save(os.path.join(outdir, "pipe_frames.npy"), np.stack(frames))
     tdist.barrier()
@@ -102,8 +111,8 @@ def test_two_rank_tile_sharding_reassembles_the_frame(built, tmp_path):
     assert np.array_equal(np.load(tmp_path / "frame_packed.npy"), whole_px.astype(np.int64))  # the packed framebuffer too
     assert np.load(tmp_path / "rays.npy").tolist() == [cnt["rays_primary"], cnt["rays_shadow"]]
     pf = np.load(tmp_path / "pipe_frames.npy")
-    assert pf.shape[0] == 5
-    for k in range(5):  # every pipelined frame equals its single-process render, in order
+    assert pf.shape[0] == 10
+    for k in range(10):  # every pipelined frame (5 ungrouped, then 5 in groups of 2) equals its single-process render, in order
         o.clear_lights()
         o.add_light([-100 + 40 * k, 70, 140], [7000, 5600, 5600])
         ref, _, _ = o.render(W, H, maxdepth=1, want_packed=False)

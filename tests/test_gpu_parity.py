@@ -156,6 +156,74 @@ def test_full_size_tile_shards_reassemble_bit_exactly(gpu_ctx, s3_full, world):
     assert torch.equal(only_px, whole_px) and torch.equal(frame_px, whole_px)
 
 
+def test_sharded_frame_pipeline_rehearsal_on_one_gpu(gpu_ctx):
+    """The N = 2 frame pipeline (dist.ShardedFrame: lanes, frame groups rendered by one launch each, packed payloads, one
+    blit per frame) with both ranks living in this process on one GPU; the collective is replaced by device copies.
+    Every frame that comes out equals the single-GPU render of the same view, in order.  Then the one-GPU batch path."""
+    import torch
+    sd = scenes.s3(64)
+    cam0, lights = product_camera_lights(sd)
+    dev = torch.device("cuda:0")
+    P = api.render_params(width=640, height=360, maxdepth=1)
+    ranks = []
+    for r in range(2):
+        b = api.Builder(); nm, _ = sd.replay(b)
+        ctx = gpu_ctx if r == 0 else api.Context(0)
+        ranks.append((ctx, ctx.commit(b, nm[sd.root])))
+    # a moving camera: frame k looks from a different eye point
+    pos, at, up, fov = sd.cam
+    cams = [api.camera((pos[0] + 3.0 * k, pos[1] + 1.0 * k, pos[2]), at, up, fov) for k in range(7)]
+    sfs = [dist.ShardedFrame(ranks[r][1], P, r, 2, dev, lanes=2, product="packed", group=3) for r in range(2)]
+    assert sfs[0].G == 3 and sfs[0].n == 2
+    mailbox = []
+
+    class Done:
+        def wait(self):
+            return True
+
+    def gather1(payload, gathered, async_op=False):
+        mailbox.append(payload.clone())
+        torch.cuda.current_stream().synchronize()
+        return Done()
+
+    def gather0(payload, gathered, async_op=False):
+        gathered[0].copy_(payload)
+        gathered[1].copy_(mailbox.pop(0))
+        return Done()
+
+    sfs[1].plan.gather = gather1
+    sfs[0].plan.gather = gather0
+    for k in range(7):
+        for r in (1, 0):
+            sfs[r].step(cams[k], lights)
+    for r in (1, 0):
+        sfs[r].flush()
+    torch.cuda.synchronize()
+    assert sfs[0].pipe.done == 7 and not mailbox
+
+    def single(k):
+        want = torch.zeros((360, 640), dtype=torch.int32, device=dev)
+        ranks[0][1].render_dev(cams[k], lights, P, None, want.data_ptr())
+        gpu_ctx.synchronize()
+        return want
+
+    # groups: frames 0-2 on lane 0, 3-5 on lane 1, 6 (a partial group) on lane 0 again
+    for k, (lane, g) in {3: (1, 0), 4: (1, 1), 5: (1, 2), 6: (0, 0), 1: (0, 1), 2: (0, 2)}.items():
+        assert torch.equal(sfs[0].frames[lane][g], single(k)), k
+    assert torch.equal(sfs[0].frame, single(6))
+    # one GPU, two frames per launch
+    gpu_ctx.lib.glome_ctx_use_slot(gpu_ctx.h, None, 0)
+    sf1 = dist.ShardedFrame(ranks[0][1], P, 0, 1, dev, lanes=2, product="packed", group=2)
+    for k in range(5):
+        sf1.step(cams[k], lights)
+    sf1.flush()
+    torch.cuda.synchronize()
+    for k, (lane, g) in {2: (1, 0), 3: (1, 1), 4: (0, 0), 1: (0, 1)}.items():
+        assert torch.equal(sf1.frames[lane][g], single(k)), k
+    gpu_ctx.lib.glome_ctx_use_slot(gpu_ctx.h, None, 0)
+    ranks[1][1].release(); ranks[0][1].release()
+
+
 def test_full_size_csg_generic_tier_vs_oracle_tile_sample(gpu_ctx):
     sd = scenes.s4()
     b, nm, sc = commit(gpu_ctx, sd)

@@ -24,7 +24,7 @@ for world in (1, 2, 4, 8):
             ms.append(st.kernel_ms)
         per_rank.append(min(ms[2:]))
     # rank 0's steady state without the collective: its shard rendered with `lanes` frames in flight + one blit per frame
-    for lanes in (1, 2, 4):
+    for lanes in (1, 4):
         streams = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
         pay = [torch.zeros(plans[0].maxp, dtype=torch.float32, device=dev) for _ in range(lanes)]
         K = 300
@@ -33,11 +33,34 @@ for world in (1, 2, 4, 8):
         for i in range(K):
             sl = i % lanes
             sc.lib.glome_ctx_use_slot(ctx.h, C.c_void_p(streams[sl].cuda_stream), sl)
-            sc.lib.glome_render_tiles_dev(sc.h, C.byref(cam), la, len(lights), C.byref(plans[0].P_local), C.c_void_p(pay[sl].data_ptr()), None)
+            sc.lib.glome_render_tiles_packed_dev(sc.h, C.byref(cam), la, len(lights), C.byref(plans[0].P_local), C.c_void_p(pay[sl].data_ptr()), None)
             if world > 1:
-                sc.lib.glome_tiles_blit_all_dev(ctx.h, C.byref(P), world, C.c_void_p(gathered.data_ptr()), plans[0].maxp, C.c_void_p(frame.data_ptr()), None)
+                sc.lib.glome_tiles_blit_all_packed_dev(ctx.h, C.byref(P), world, C.c_void_p(gathered.data_ptr()), plans[0].maxp // 5, C.c_void_p(frame.data_ptr()))
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / K * 1e3
         print(json.dumps({"world": world, "lanes": lanes, "rank0_step_ms_no_collective": round(dt, 4)}), flush=True)
     sc.lib.glome_ctx_use_slot(ctx.h, None, 0)
     print(json.dumps({"world": world, "render_ms_per_rank_alone": [round(x, 4) for x in per_rank], "max_over_mean": round(max(per_rank) / (sum(per_rank) / world), 3)}), flush=True)
+
+# rank 0's whole step through dist.ShardedFrame (lanes, frame groups, packed payload, blit), the collective replaced by a
+# device copy: the frame period a rank can sustain before RCCL enters
+class _Done:
+    def wait(self):
+        return True
+for world, lanes, group in ((8, 4, 4), (8, 2, 8), (8, 4, 8), (8, 4, 2), (4, 4, 4), (4, 4, 8), (2, 4, 4), (2, 4, 2), (1, 4, 1), (1, 4, 2), (1, 2, 4)):
+    sf = dist.ShardedFrame(sc, P, 0, world, dev, lanes=lanes, product="packed", group=group)
+    def fake(payload, gathered, async_op=False):
+        gathered[0].copy_(payload)
+        return _Done()
+    sf.plan.gather = fake
+    for i in range(48):
+        sf.step(cam, lights)
+    sf.flush(); torch.cuda.synchronize()
+    K = 480
+    t0 = time.perf_counter()
+    for i in range(K):
+        sf.step(cam, lights)
+    sf.flush(); torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / K * 1e3
+    print(json.dumps({"world": world, "launches_in_flight": sf.n, "frames_per_launch": sf.G, "rank0_pipeline_ms_per_frame_fake_gather": round(dt, 4)}), flush=True)
+    sc.lib.glome_ctx_use_slot(ctx.h, None, 0)
