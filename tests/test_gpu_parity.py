@@ -193,13 +193,16 @@ def test_sharded_frame_pipeline_rehearsal_on_one_gpu(gpu_ctx):
 
     sfs[1].plan.gather = gather1
     sfs[0].plan.gather = gather0
+    # the synchronous statistics step bench.py starts with: both ranks, one frame, ray counts add up to the frame's
+    sts = [sfs[r].step(cams[0], lights, stats=True) for r in (1, 0)]
+    assert sum(st["rays_primary"] for st in sts) == 640 * 360 and not mailbox
     for k in range(7):
         for r in (1, 0):
             sfs[r].step(cams[k], lights)
     for r in (1, 0):
         sfs[r].flush()
     torch.cuda.synchronize()
-    assert sfs[0].pipe.done == 7 and not mailbox
+    assert sfs[0].pipe.done == 7 and not mailbox  # (the statistics step goes around the pipeline)
 
     def single(k):
         want = torch.zeros((360, 640), dtype=torch.int32, device=dev)
