@@ -85,6 +85,9 @@ def camera_from_vectors(pos, fwd, up, right):
     return cam
 
 
+WEIGHT_PERLIN, WEIGHT_STRIPE_SQUARE, WEIGHT_STRIPE_TRIANGLE, WEIGHT_STRIPE_SINE = 1, 2, 3, 4  # GLOME_WEIGHT_*
+
+
 def light(pos, color, rad=1000000.0, shadow=True):
     """light pos clr = Light pos clr (\\x -> 1/(x*x)) infinity True (Shader.hs:22-23)."""
     li = L.Light()
@@ -198,6 +201,11 @@ class Builder:
     def material_refract(self, refl, refr, ior): return self._call("glome_sb_material_refract", float(refl), float(refr), float(ior))
     def material_layers(self, mats): return self._ids("glome_sb_material_layers", mats)
     def material_blend(self, a, b, w): return self._chk(self.lib.glome_sb_material_blend(self.h, int(a), int(b), float(w)), "glome_sb_material_blend")
+
+    def material_blend_fn(self, a, b, fn, params):
+        """Blend a b (f pos): fn = WEIGHT_PERLIN (params = [scale]) or WEIGHT_STRIPE_* (params = axis), TestScene.hs:214-234."""
+        wp = (C.c_double * 4)(*([float(x) for x in params] + [0.0] * (4 - len(params))))
+        return self._chk(self.lib.glome_sb_material_blend_fn(self.h, int(a), int(b), int(fn), wp), "glome_sb_material_blend_fn")
 
     # host-side inspection
     def primcount(self, node):

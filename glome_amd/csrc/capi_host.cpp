@@ -124,6 +124,15 @@ int32_t glome_sb_material_layers(glome_sb* sb, const int32_t* mats, int n) {
 int32_t glome_sb_material_blend(glome_sb* sb, int32_t a, int32_t b, double weight) {
   return guard(sb, [&] { sb->graph.check_mat(a); sb->graph.check_mat(b); Mat m; m.kind = MAT_BLEND; m.a = a; m.b = b; m.weight = weight; return sb->graph.add_mat(m); });
 }
+int32_t glome_sb_material_blend_fn(glome_sb* sb, int32_t a, int32_t b, int32_t weight_fn, const double* params4) {
+  return guard(sb, [&] {
+    sb->graph.check_mat(a); sb->graph.check_mat(b);
+    if (weight_fn < GLOME_WEIGHT_PERLIN || weight_fn > GLOME_WEIGHT_STRIPE_SINE || !params4) throw std::invalid_argument("bad weight function");
+    Mat m; m.kind = MAT_BLEND; m.a = a; m.b = b; m.wfn = weight_fn;
+    for (int k = 0; k < 4; k++) m.wp[k] = params4[k];
+    return sb->graph.add_mat(m);
+  });
+}
 
 int glome_sb_primcount(glome_sb* sb, int32_t id, long out3[3]) {
   return guard(sb, [&] { out3[0] = out3[1] = out3[2] = 0; sb->graph.primcount(id, out3); return 0; });

@@ -81,7 +81,10 @@ class Flattener {
         case MAT_REFLECT: m1 = mk4(m.refl, 0, 0, 0); break;
         case MAT_REFRACT: m1 = mk4(m.refl, m.refr, m.ior, 0); break;
         case MAT_LAYERS: a = (uint32_t)F.matkids.size(); b = (uint32_t)m.kids.size(); for (int k : m.kids) F.matkids.push_back((uint32_t)k); break;
-        case MAT_BLEND: a = (uint32_t)m.a; b = (uint32_t)m.b; w = f32(m.weight); break;
+        case MAT_BLEND:
+          a = (uint32_t)m.a; b = (uint32_t)m.b; w = f32(m.weight);
+          m1 = F4{as_float_bits((uint32_t)m.wfn), f32(m.wp[0]), f32(m.wp[1]), f32(m.wp[2])};  // weight function + parameters
+          break;
       }
       F.mats.push_back(F4{as_float_bits((uint32_t)m.kind), as_float_bits(a), as_float_bits(b), w});
       F.mats.push_back(m1);

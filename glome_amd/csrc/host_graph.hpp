@@ -177,6 +177,8 @@ struct Mat {  // Material, Shader.hs:43-52 (Warp excluded: closure + second scen
   double color[3] = {0, 0, 0}, alpha = 1, amb = 0, kd = 0, ks = 0, shine = 0, refl = 0, refr = 0, ior = 1, weight = 0;
   std::vector<int> kids;
   int a = -1, b = -1;
+  int wfn = 0;                 // Blend weight: 0 constant, else a solid texture function of the hit position (GLOME_WEIGHT_*)
+  double wp[4] = {0, 0, 0, 0};
 };
 
 struct Graph {

@@ -1020,6 +1020,53 @@ GD CA caweight(CA c1, CA c2, float w) {  // Clr.hs:87-91
 }
 GD float aclamp(float x) { return x > 1 ? 1.0f : (x < 0 ? 0.0f : x); }  // Clr.hs:75-79
 
+// ------------------------------------------------------------------ solid texture functions (GlomeVec Texture.hs)
+// Scalar fields 0..1 over the hit position, used as Blend weights by TestScene.hs's t_mottled / t_stripe closures
+// (TestScene.hs:214-234): Perlin noise with the reference's omega / phi / gamma tables (Texture.hs:48-117) and
+// stripe = wave . vdot axis (Texture.hs:11-41).
+GD float tx_omega(float t_) {  // Texture.hs:48-53
+  float t = fabsf(t_), tsqr = t * t, tcube = tsqr * t;
+  return (-6.0f) * tcube * tsqr + 15.0f * tcube * t - 10.0f * tcube + 1.0f;
+}
+GD int tx_phi(int i) {  // Texture.hs:56-57 -- [3,0,2,7,4,1,5,11,8,10,9,6] packed four bits apiece
+  return (int)((0x69A8B5147203ull >> (4 * i)) & 15ull);
+}
+GD V3 tx_grad(int c) {  // Texture.hs:59-64: the 12 edge directions in the comprehension's order (x outermost)
+  // x: -1 for c < 4, 0 for 4..7, +1 for 8..11; within a group of four: (y, z) = (-1,0) (0,-1) (0,1) (1,0) when x != 0,
+  // (-1,-1) (-1,1) (1,-1) (1,1) when x == 0
+  int g = c >> 2, k = c & 3;
+  float x = (float)(g - 1);
+  float y, z;
+  if (g == 1) { y = (k & 2) ? 1.0f : -1.0f; z = (k & 1) ? 1.0f : -1.0f; }
+  else { y = k == 0 ? -1.0f : (k == 3 ? 1.0f : 0.0f); z = k == 1 ? -1.0f : (k == 2 ? 1.0f : 0.0f); }
+  return v3(x, y, z);
+}
+GD int tx_iabs(int v) { return v < 0 ? -v : v; }
+GD float tx_knot(int i, int j, int k, V3 v) {  // Texture.hs:66-76
+  int a = tx_phi(tx_iabs(k) % 12);
+  int b = tx_phi(tx_iabs(j + a) % 12);
+  int c = tx_phi(tx_iabs(i + b) % 12);
+  return tx_omega(v.x) * tx_omega(v.y) * tx_omega(v.z) * vdot(tx_grad(c), v);
+}
+GD float tx_noise(V3 p) {  // Texture.hs:92-107
+  float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+  int i = (int)fx, j = (int)fy, k = (int)fz;
+  float u = p.x - fx, v = p.y - fy, w = p.z - fz;
+  return tx_knot(i, j, k, v3(u, v, w)) + tx_knot(i + 1, j, k, v3(u - 1, v, w)) + tx_knot(i, j + 1, k, v3(u, v - 1, w)) +
+         tx_knot(i, j, k + 1, v3(u, v, w - 1)) + tx_knot(i + 1, j + 1, k, v3(u - 1, v - 1, w)) + tx_knot(i + 1, j, k + 1, v3(u - 1, v, w - 1)) +
+         tx_knot(i, j + 1, k + 1, v3(u, v - 1, w - 1)) + tx_knot(i + 1, j + 1, k + 1, v3(u - 1, v - 1, w - 1));
+}
+// weight of a Blend: fn 0 constant, 1 perlin (vscale pos p0), 2/3/4 square / triangle / sine wave of (vdot pos (p0,p1,p2))
+GD float tx_weight(uint32_t fn, float constant, float p0, float p1, float p2, V3 pos) {
+  if (fn == 0u) return constant;
+  if (fn == 1u) return (tx_noise(pos * p0) + 1.0f) * 0.5f;  // perlin, Texture.hs:109-117
+  float x = vdot(pos, v3(p0, p1, p2));
+  float offset = x - floorf(x);
+  if (fn == 2u) return offset < 0.5f ? 0.0f : 1.0f;                        // square_wave, Texture.hs:11-14
+  if (fn == 3u) return offset < 0.5f ? offset * 2 : 2 - offset * 2;        // triangle_wave, Texture.hs:16-21
+  return sinf(x * 2 * 3.14159265358979323846f) * 0.5f + 0.5f;              // sine_wave, Texture.hs:23-24
+}
+
 // ------------------------------------------------------------------ trace / shade (Trace.hs:59-82, Shader.hs:65-184)
 // TIER supplies closest / occluded (force-inlined, for the primary path) and closest_ni / occluded_ni (one shared
 // out-of-line copy each, for secondary rays), and carries the lights + counters.
@@ -1162,7 +1209,7 @@ GD CA postshade_body(TIER& T, LightCache& lc, uint32_t mat, const Ray& ray, cons
     if (kind == DM_BLEND) {  // Shader.hs:181-184
       CA a = PostFn<R, MD - 1, TIER>::run(T, lc, as_u(m0.y), ray, h, recurs);
       CA b = PostFn<R, MD - 1, TIER>::run(T, lc, as_u(m0.z), ray, h, recurs);
-      return caweight(a, b, m0.w);
+      return caweight(a, b, tx_weight(as_u(m1.x), m0.w, m1.y, m1.z, m1.w, p));  // constant or a solid texture function of the hit point
     }
   }
   return ca(0, 0, 0, 0);

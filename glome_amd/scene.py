@@ -14,7 +14,7 @@ def r32(x):
 NODE_OPS = {"sphere", "triangle", "trianglenorm", "box", "plane", "plane_offset", "disc", "cylinder", "cone", "group",
             "transform", "difference", "intersection", "bih", "mesh", "tex", "tag", "noshadow", "onlyshadow", "bound_object",
             "innerbound", "flatten_transform", "tolist", "triangles_bulk"}
-MAT_OPS = {"material_surface", "material_reflect", "material_refract", "material_layers", "material_blend"}
+MAT_OPS = {"material_surface", "material_reflect", "material_refract", "material_layers", "material_blend", "material_blend_fn"}
 
 
 class SceneDesc:
@@ -81,6 +81,7 @@ class SceneDesc:
     def material_refract(self, refl, refr, ior): return self._mat("material_refract", self._q(refl), self._q(refr), self._q(ior))
     def material_layers(self, mats): return self._mat("material_layers", list(mats))
     def material_blend(self, a, b, w): return self._mat("material_blend", a, b, self._q(w))
+    def material_blend_fn(self, a, b, fn, params): return self._mat("material_blend_fn", a, b, int(fn), self._q(list(params)))
 
     def set_root(self, node): self.root = node
     def add_light(self, pos, color, rad=1000000.0, shadow=True): self.lights.append((self._q(pos), self._q(color), float(rad), bool(shadow)))
@@ -97,6 +98,8 @@ class SceneDesc:
                     mmap.append(backend.material_layers([mmap[m] for m in args[0]]))
                 elif name == "material_blend":
                     mmap.append(backend.material_blend(mmap[args[0]], mmap[args[1]], args[2]))
+                elif name == "material_blend_fn":
+                    mmap.append(backend.material_blend_fn(mmap[args[0]], mmap[args[1]], args[2], args[3]))
                 else:
                     mmap.append(getattr(backend, name)(*args))
             elif kind == "N":

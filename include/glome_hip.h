@@ -107,6 +107,15 @@ int32_t glome_sb_material_reflect(glome_sb*, double refl);
 int32_t glome_sb_material_refract(glome_sb*, double refl, double refr, double ior);
 int32_t glome_sb_material_layers(glome_sb*, const int32_t* mats, int n);
 int32_t glome_sb_material_blend(glome_sb*, int32_t a, int32_t b, double weight);
+/* A Blend whose weight is a solid texture function of the hit position (GlomeVec/Data/Glome/Texture.hs) -- the
+ * defunctionalised form of the closures t_mottled / t_stripe (TestScene.hs:214-234):
+ *   GLOME_WEIGHT_PERLIN            weight = perlin (vscale pos params[0])                      (Texture.hs:109-117)
+ *   GLOME_WEIGHT_STRIPE_SQUARE / _TRIANGLE / _SINE   weight = wave (vdot pos params[0..2])     (Texture.hs:11-41) */
+#define GLOME_WEIGHT_PERLIN 1
+#define GLOME_WEIGHT_STRIPE_SQUARE 2
+#define GLOME_WEIGHT_STRIPE_TRIANGLE 3
+#define GLOME_WEIGHT_STRIPE_SINE 4
+int32_t glome_sb_material_blend_fn(glome_sb*, int32_t a, int32_t b, int32_t weight_fn, const double* params4);
 /* host-side inspection (no GPU needed) */
 int glome_sb_primcount(glome_sb*, int32_t id, long out3[3]);  /* primcount, Solid.hs:197,251 */
 int glome_sb_bound(glome_sb*, int32_t id, double out6[6]);    /* bound, Solid.hs:171 */

@@ -1223,6 +1223,49 @@ template <class R> struct Mesh : Solid<R> {
 template <class R> struct Light {  // Shader.hs:13-23; falloff fixed to \x -> 1/(x*x) as `light` builds it
   Vec<R> pos; Color<R> col; R rad = Math<R>::infinity(); bool shadow = true;
 };
+// ---- solid texture functions (GlomeVec/Data/Glome/Texture.hs): scalar fields 0..1 used as Blend weights by
+// TestScene.hs's t_stripe / t_mottled (TestScene.hs:214-234)
+enum WeightFn { W_CONST = 0, W_PERLIN = 1, W_STRIPE_SQUARE = 2, W_STRIPE_TRIANGLE = 3, W_STRIPE_SINE = 4 };
+template <class R> R tx_omega(R t_) {  // Texture.hs:48-53
+  R t = std::fabs(t_), tsqr = t * t, tcube = tsqr * t;
+  return R(-6) * tcube * tsqr + R(15) * tcube * t - R(10) * tcube + R(1);
+}
+inline int tx_phi(int i) { static const int phi[12] = {3, 0, 2, 7, 4, 1, 5, 11, 8, 10, 9, 6}; return phi[i]; }  // Texture.hs:56-57
+template <class R> Vec<R> tx_grad(int i) {  // Texture.hs:59-64: the 12 edge directions, x outermost in the comprehension
+  static const int g[12][3] = {{-1, -1, 0}, {-1, 0, -1}, {-1, 0, 1}, {-1, 1, 0}, {0, -1, -1}, {0, -1, 1}, {0, 1, -1}, {0, 1, 1}, {1, -1, 0}, {1, 0, -1}, {1, 0, 1}, {1, 1, 0}};
+  return Vec<R>{R(g[i][0]), R(g[i][1]), R(g[i][2])};
+}
+template <class R> Vec<R> tx_gamma(long i, long j, long k) {  // Texture.hs:66-71
+  int a = tx_phi((int)(std::labs(k) % 12));
+  int b = tx_phi((int)(std::labs(j + a) % 12));
+  int c = tx_phi((int)(std::labs(i + b) % 12));
+  return tx_grad<R>(c);
+}
+template <class R> R tx_knot(long i, long j, long k, Vec<R> v) {  // Texture.hs:73-76
+  return tx_omega(v.x) * tx_omega(v.y) * tx_omega(v.z) * vdot(tx_gamma<R>(i, j, k), v);
+}
+template <class R> R tx_noise(Vec<R> p) {  // Texture.hs:92-107
+  long i = (long)std::floor(p.x), j = (long)std::floor(p.y), k = (long)std::floor(p.z);
+  R u = p.x - R(i), v = p.y - R(j), w = p.z - R(k);
+  return tx_knot(i, j, k, Vec<R>{u, v, w}) + tx_knot(i + 1, j, k, Vec<R>{u - 1, v, w}) + tx_knot(i, j + 1, k, Vec<R>{u, v - 1, w}) +
+         tx_knot(i, j, k + 1, Vec<R>{u, v, w - 1}) + tx_knot(i + 1, j + 1, k, Vec<R>{u - 1, v - 1, w}) + tx_knot(i + 1, j, k + 1, Vec<R>{u - 1, v, w - 1}) +
+         tx_knot(i, j + 1, k + 1, Vec<R>{u, v - 1, w - 1}) + tx_knot(i + 1, j + 1, k + 1, Vec<R>{u - 1, v - 1, w - 1});
+}
+template <class R> R tx_perlin(Vec<R> v) { return (tx_noise(v) + 1) * R(0.5); }  // Texture.hs:109-117 (the range errors cannot fire: |noise| <= 1)
+template <class R> R tx_wave(int fn, R x) {  // Texture.hs:11-25
+  R offset = x - std::floor(x);
+  if (fn == W_STRIPE_SQUARE) return offset < R(0.5) ? R(0) : R(1);
+  if (fn == W_STRIPE_TRIANGLE) return offset < R(0.5) ? offset * 2 : 2 - offset * 2;
+  return std::sin(x * 2 * R(M_PI)) * R(0.5) + R(0.5);
+}
+// the weight of a Blend whose closure was `\_ hit -> Blend a b (f (pos hit))`: perlin (vscale pos s) (TestScene.hs:216)
+// or (stripe axis wave) pos = wave (vdot pos axis) (Texture.hs:35-41, TestScene.hs:227)
+template <class R> R tx_weight(int fn, const R* wp, R constant, Vec<R> pos) {
+  if (fn == W_CONST) return constant;
+  if (fn == W_PERLIN) return tx_perlin(vscale(pos, wp[0]));
+  return tx_wave(fn, vdot(pos, Vec<R>{wp[0], wp[1], wp[2]}));
+}
+
 enum MatKind { M_SURFACE = 0, M_REFLECT = 1, M_REFRACT = 2, M_LAYERS = 3, M_BLEND = 4 };
 template <class R> struct Material {  // Shader.hs:43-52 (Warp is out of scope: closure + second scene)
   int kind = M_SURFACE;
@@ -1231,6 +1274,7 @@ template <class R> struct Material {  // Shader.hs:43-52 (Warp is out of scope: 
   R refl = 0, refr = 0, ior = 1;                    // Reflect / Refract
   std::vector<int> kids;                            // AdditiveLayers
   int ma = -1, mb = -1; R weight = 0;               // Blend
+  int wfn = W_CONST; R wp[4] = {0, 0, 0, 0};        // Blend weight as a solid texture function of the hit position
 };
 template <class R> struct Camera { Vec<R> pos, fwd, up, right; };  // Scene.hs:35
 template <class R> Camera<R> camera(Vec<R> pos, Vec<R> at, Vec<R> up, R angle) {  // Scene.hs:48-57
@@ -1334,7 +1378,7 @@ template <class R> struct Tracer {
       case M_BLEND: {
         ColorA<R> ca = postshade(lz, m.ma, ray, ri, recurs);
         ColorA<R> cb = postshade(lz, m.mb, ray, ri, recurs);
-        return caweight(ca, cb, m.weight);
+        return caweight(ca, cb, tx_weight<R>(m.wfn, m.wp, m.weight, ri.pos));
       }
     }
     return {0, 0, 0, 0};

@@ -39,6 +39,7 @@ struct IOracle {
   virtual int mat_refract(double refl, double refr, double ior) = 0;
   virtual int mat_layers(const int* ids, int n) = 0;
   virtual int mat_blend(int a, int b, double w) = 0;
+  virtual int mat_blend_fn(int a, int b, int fn, const double* wp) = 0;
   virtual void set_root(int id) = 0;
   virtual void set_camera(const double* c12) = 0;
   virtual void clear_lights() = 0;
@@ -223,6 +224,14 @@ template <class R> struct Impl : IOracle {
     Material<R> m; m.kind = M_BLEND; m.ma = a; m.mb = b; m.weight = R(w);
     return addmat(m);
   }
+  int mat_blend_fn(int a, int b, int fn, const double* wp) override {  // TestScene.hs:214-234 (t_mottled / t_stripe)
+    int nm = (int)scene.mats.size();
+    if (a < 0 || a >= nm || b < 0 || b >= nm) throw std::runtime_error("bad material id");
+    if (fn < W_PERLIN || fn > W_STRIPE_SINE) throw std::runtime_error("bad weight function");
+    Material<R> m; m.kind = M_BLEND; m.ma = a; m.mb = b; m.wfn = fn;
+    for (int k = 0; k < 4; k++) m.wp[k] = R(wp[k]);
+    return addmat(m);
+  }
   void set_root(int id) override { scene.root = get(id); }
   void set_camera(const double* c) override { scene.cam = {V(c), V(c + 3), V(c + 6), V(c + 9)}; }
   void clear_lights() override { scene.lights.clear(); }
@@ -337,6 +346,12 @@ int glo_material_reflect(void* h, double refl) { return guard(h, [&](IOracle* o)
 int glo_material_refract(void* h, double refl, double refr, double ior) { return guard(h, [&](IOracle* o) { return o->mat_refract(refl, refr, ior); }); }
 int glo_material_layers(void* h, const int* ids, int n) { return guard(h, [&](IOracle* o) { return o->mat_layers(ids, n); }); }
 int glo_material_blend(void* h, int a, int b, double w) { return guard(h, [&](IOracle* o) { return o->mat_blend(a, b, w); }); }
+int glo_material_blend_fn(void* h, int a, int b, int fn, const double* wp) { return guard(h, [&](IOracle* o) { return o->mat_blend_fn(a, b, fn, wp); }); }
+// the scalar field alone (tests): fn as in WeightFn, wp[4], n points
+int glo_weight_fn(int fn, const double* wp, int n, const double* xyz, double* out) {
+  for (int i = 0; i < n; i++) out[i] = tx_weight<double>(fn, wp, 0.0, Vec<double>{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]});
+  return 0;
+}
 int glo_set_root(void* h, int id) { return guard(h, [&](IOracle* o) { o->set_root(id); return 0; }); }
 int glo_set_camera(void* h, const double* c12) { return guard(h, [&](IOracle* o) { o->set_camera(c12); return 0; }); }
 int glo_clear_lights(void* h) { return guard(h, [&](IOracle* o) { o->clear_lights(); return 0; }); }

@@ -129,6 +129,10 @@ class Oracle:
     def material_layers(self, mats): return self._ids("glo_material_layers", mats)
     def material_blend(self, a, b, w): return self._chk(self.L.glo_material_blend(self.h, C.c_int(int(a)), C.c_int(int(b)), C.c_double(float(w))), "glo_material_blend")
 
+    def material_blend_fn(self, a, b, fn, params):
+        wp = (C.c_double * 4)(*([float(x) for x in params] + [0.0] * (4 - len(params))))
+        return self._chk(self.L.glo_material_blend_fn(self.h, C.c_int(int(a)), C.c_int(int(b)), C.c_int(int(fn)), wp), "glo_material_blend_fn")
+
     # ---- scene state ----
     def set_root(self, node): self._chk(self.L.glo_set_root(self.h, C.c_int(int(node))), "glo_set_root")
     def set_camera_vectors(self, pos, fwd, up, right):

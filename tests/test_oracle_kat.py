@@ -193,3 +193,58 @@ def test_trace_recursion_and_empty_stack(o):
     o.set_root(o.plane([0, 0, 0], [0, 1, 0]))  # hit with an empty texture stack
     img, _, _ = o.render(1, 1, maxdepth=3, want_packed=False)
     assert np.allclose(img[0, 0, :4], [0, 0, 0, 0]) and img[0, 0, 4] == pytest.approx(2)
+
+
+# ------------------------------------------------------------------ solid texture functions (GlomeVec Texture.hs)
+def _weight(fn, params, pts):
+    import ctypes as C
+    from oracle import oracle_py as O
+    lib = O.lib()
+    pts = np.ascontiguousarray(np.asarray(pts, np.float64).reshape(-1, 3))
+    out = np.zeros(len(pts))
+    wp = (C.c_double * 4)(*([float(x) for x in params] + [0.0] * (4 - len(params))))
+    lib.glo_weight_fn(C.c_int(fn), wp, C.c_int(len(pts)), pts.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out
+
+
+def test_perlin_is_half_on_the_lattice_and_stays_in_range():
+    # at a lattice point every knot vanishes: the own knot has v = 0 (vdot gamma 0 = 0), the others have an omega(+-1) = 0
+    lattice = [(i, j, k) for i in (-3, 0, 2) for j in (-1, 0, 5) for k in (-2, 0, 1)]
+    assert np.allclose(_weight(1, [1.0], lattice), 0.5, atol=1e-15)
+    rng = np.random.default_rng(7)
+    p = rng.uniform(-20, 20, (4000, 3))
+    w = _weight(1, [3.0], p)
+    assert w.min() >= 0 and w.max() <= 1 and 0.3 < w.mean() < 0.7 and w.std() > 0.05
+
+
+def test_perlin_matches_an_independent_numpy_restatement():
+    phi = [3, 0, 2, 7, 4, 1, 5, 11, 8, 10, 9, 6]
+    grad = [np.array((x, y, z), float) for x in (-1, 0, 1) for y in (-1, 0, 1) for z in (-1, 0, 1) if 1.1 < np.sqrt(x * x + y * y + z * z) < 1.5]
+    assert len(grad) == 12
+
+    def omega(t):
+        t = abs(t)
+        return -6 * t**5 + 15 * t**4 - 10 * t**3 + 1
+
+    def knot(i, j, k, v):
+        a = phi[abs(k) % 12]; b = phi[abs(j + a) % 12]; c = phi[abs(i + b) % 12]
+        return omega(v[0]) * omega(v[1]) * omega(v[2]) * float(np.dot(grad[c], v))
+
+    def noise(p):
+        i, j, k = (int(np.floor(c)) for c in p)
+        u, v, w = p[0] - i, p[1] - j, p[2] - k
+        return sum(knot(i + a, j + b, k + c, np.array((u - a, v - b, w - c))) for a in (0, 1) for b in (0, 1) for c in (0, 1))
+
+    rng = np.random.default_rng(11)
+    pts = rng.uniform(-9, 9, (200, 3))
+    want = np.array([(noise(2.5 * p) + 1) * 0.5 for p in pts])
+    assert np.allclose(_weight(1, [2.5], pts), want, atol=1e-12)
+
+
+def test_stripe_waves():
+    x = np.array([0.0, 0.25, 0.5, 0.75, 1.25, -0.25])
+    pts = np.stack([x, np.zeros_like(x), np.zeros_like(x)], 1)
+    assert np.allclose(_weight(2, [1, 0, 0], pts), [0, 0, 1, 1, 0, 1])              # square_wave: offset < 0.5 -> 0
+    assert np.allclose(_weight(3, [1, 0, 0], pts), [0, 0.5, 1, 0.5, 0.5, 0.5])      # triangle_wave
+    assert np.allclose(_weight(4, [1, 0, 0], pts), np.sin(x * 2 * np.pi) * 0.5 + 0.5)
+    assert np.allclose(_weight(3, [4, 8, 5], [[0.1, 0.2, 0.3]]), [1.0])             # vdot = 3.5 -> offset 0.5 -> 2 - 1

@@ -133,4 +133,28 @@ def materials():
     return _finish(sd, sd.group([pl, sd.bih(items)]))
 
 
-ALL = {"flat_mixed": flat_mixed, "quadrics": quadrics, "csg": csg, "nested": nested, "mesh": mesh_scene, "materials": materials}
+def textures():
+    """Solid-texture Blend weights (TestScene.hs:214-234): t_mottled = Blend mirror matte (perlin (3 * pos)), t_stripe =
+    Blend shiny_white dull_gray (triangle_wave (pos . (4,8,5))), plus the square and sine waves of Texture.hs:11-24."""
+    from glome_amd import api
+    sd = SceneDesc()
+    m = scenes.materials(sd)
+    shiny_white = sd.material_surface((1, 1, 1), 1, 0.2, 0.8, 0.4, 10)       # TestScene.hs:199
+    dull_gray = sd.material_surface((0.4, 0.3, 0.35), 1, 0.2, 0.8, 0, 0)     # TestScene.hs:211
+    mottled = sd.material_blend_fn(m["mirror"], scenes.matte(sd, (0.15, 0.3, 0.5)), api.WEIGHT_PERLIN, [3.0])
+    stripe = sd.material_blend_fn(shiny_white, dull_gray, api.WEIGHT_STRIPE_TRIANGLE, [4, 8, 5])
+    square = sd.material_blend_fn(shiny_white, m["shiny_red"], api.WEIGHT_STRIPE_SQUARE, [0, 3, 0])
+    sine = sd.material_blend_fn(dull_gray, m["shiny_red"], api.WEIGHT_STRIPE_SINE, [2, 0, 1])
+    # a bounded floor: on an infinite plane the horizon's hit points are thousands of units out, where fp32 positions no
+    # longer resolve the noise lattice (3 * pos) -- a limit of fp32 hit points, not of the texture code
+    pl = sd.tex(sd.box((-9, -0.5, -9), (9, 0, 9)), mottled)
+    items = [
+        sd.tex(sd.sphere((-4, 1.2, 0), 1.2), stripe),
+        sd.tex(sd.sphere((-1, 1.2, 1), 1.2), mottled),
+        sd.tex(sd.box((1.2, 0, -1), (3.2, 2, 1)), square),
+        sd.tex(sd.cone((5, 0, 0), 1.0, (5, 2.5, 0), 0.2), sine),
+    ]
+    return _finish(sd, sd.group([pl, sd.bih(items)]))
+
+
+ALL = {"flat_mixed": flat_mixed, "quadrics": quadrics, "csg": csg, "nested": nested, "mesh": mesh_scene, "materials": materials, "textures": textures}
