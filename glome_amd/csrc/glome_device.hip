@@ -226,25 +226,18 @@ __global__ void __launch_bounds__(64) k_render_generic(DRenderArgs A) {
 
 
 // ------------------------------------------------------------------------------------------------ adaptive sampler
-// renderTileSubsample (Glome.hs:226-323) as a wavefront.  The reference runs five passes over each 65x65 tile; a pass
-// looks at neighbour contrast (`decide`, Glome.hs:213-219) and either averages or traces a fresh sample.  Here every
-// pass is two launches over ALL owned tiles at once:
-//   k_ss_decide  one thread per owned pixel: candidates of the pass take the contrast test; the ones that settle for
-//                an average write it, the ones that need a sample are appended to a global list (wave-aggregated
-//                atomics, so neighbouring pixels stay neighbours in the list);
-//   k_ss_trace   persistent waves pull 64 list entries at a time and trace them: every lane has a ray.
+// renderTileSubsample (Glome.hs:226-323).  The reference runs five passes over each 65x65 tile; a pass looks at
+// neighbour contrast (`decide`, Glome.hs:213-219) and either averages or traces a fresh sample.  Here a pass is ONE
+// launch over all owned tiles: persistent waves pull regions of a tile's candidate lattice (ss_block_pixel: blocks of
+// 64 candidates of the pass in a compact pixel area, one per lane; 1 or 2x2 blocks per region); a lane takes the
+// contrast test and writes the average when that settles it; the candidates that need a sample are compacted over
+// the region (ballot + LDS list) and traced 64 at a time -- neighbours in the image, so the rays are walked as a
+// packet.  A region in which nobody needs a sample does no tracing at all.
 // The working buffer `v` is a dense per-tile array in global memory (tile order, row major inside a tile), so all
-// neighbour reads stay inside the tile like the reference's getc (Glome.hs:233-235); `v2` is the output.
+// neighbour reads stay inside the tile like the reference's getc (Glome.hs:233-235); `v2` is the output.  A pass reads
+// what the previous passes wrote anywhere in the tile, hence one launch per pass.
 __device__ __forceinline__ TC ss_load(const float* v, size_t i) { const float* p = v + i * 5; return tc(p[0], p[1], p[2], p[3], p[4]); }
 __device__ __forceinline__ void ss_store(float* v, size_t i, const TC& c) { float* p = v + i * 5; p[0] = c.r; p[1] = c.g; p[2] = c.b; p[3] = c.a; p[4] = c.d; }
-__device__ __forceinline__ DTile ss_tile_of(const DRenderArgs& A, uint32_t dense) {  // owned tile holding dense pixel index
-  int lo = 0, hi = A.ntiles - 1;
-  while (lo < hi) {
-    int mid = (lo + hi + 1) >> 1;
-    if (A.tiles[mid].pix_base <= dense) lo = mid; else hi = mid - 1;
-  }
-  return A.tiles[lo];
-}
 __device__ __forceinline__ TC ss_getc(const float* v, const DTile& t, int dx, int dy) {  // getc: outside the tile reads blank
   if (dx >= 0 && dx < t.w && dy >= 0 && dy < t.h) return ss_load(v, (size_t)t.pix_base + (size_t)dy * t.w + dx);
   return tc_blank();
@@ -258,89 +251,89 @@ __device__ __forceinline__ void ss_write_out(const DRenderArgs& A, const DTile& 
   if (A.packed) A.packed[o] = rgbf(c.r * c.a, c.g * c.a, c.b * c.a);
 }
 
-__global__ void __launch_bounds__(256) k_ss_decide(DRenderArgs A, int pass) {
+template <class TIER>
+__device__ __forceinline__ void ss_pass_loop(const DRenderArgs& A, TIER& T, int pass) {
+  __shared__ uint32_t need_list[256];  // candidates of the region that need a sample: dx | dy << 8 (one wave per block)
   float* v = A.scratch;
   const int lane = threadIdx.x & 63;
   const float thr = pass >= 2 ? A.thresholds[pass - 2] : 0.0f;
   int ox[4], oy[4];
   ss_neighbours(pass, ox, oy);
-  // whole waves iterate together so the ballot below always sees 64 lanes
-  const uint32_t total = A.total_pixels, step = gridDim.x * blockDim.x;
-  for (uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) - lane; base < total; base += step) {
-    uint32_t idx = base + lane;
-    bool need = false;
-    if (idx < total) {
-      DTile t = ss_tile_of(A, idx);
-      int i = (int)(idx - t.pix_base), dx = i % t.w, dy = i / t.w;
-      if (pass == 1) ss_store(v, idx, tc_blank());  // MUV.replicate ... (0,0,0,0,infinity), Glome.hs:231
-      if (ss_candidate(pass, dx, dy)) {
-        need = true;
-        if (pass >= 2) {
-          TC a = ss_getc(v, t, dx + ox[0], dy + oy[0]), b = ss_getc(v, t, dx + ox[1], dy + oy[1]);
-          TC c = ss_getc(v, t, dx + ox[2], dy + oy[2]), d = ss_getc(v, t, dx + ox[3], dy + oy[3]);
-          need = gmaxf(ccmp(a, c), ccmp(b, d)) > thr;  // decide, Glome.hs:215-216
-          if (!need) {
-            TC avg = cavg4(a, b, c, d);
-            if (pass < 5) ss_store(v, idx, avg);
-            else ss_write_out(A, t, dx, dy, ss_pass5_blend(avg, a, b, c, d, dx == t.w - 1, dy == t.h - 1));
-          }
-        }
-      }
-    }
-    unsigned long long m = __ballot(need);
-    if (m) {
-      uint32_t start = 0;
-      if (lane == 0) start = atomicAdd(&A.ss_cnt[pass], (unsigned int)__popcll(m));
-      start = __shfl(start, 0, 64);
-      if (need) A.ss_list[start + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = idx;
-    }
-  }
-}
-
-template <class TIER>
-__device__ __forceinline__ void ss_trace_loop(const DRenderArgs& A, TIER& T, int pass) {
-  float* v = A.scratch;
-  const int lane = threadIdx.x & 63;
-  const uint32_t n = A.ss_cnt[pass];
-  int ox[4], oy[4];
-  ss_neighbours(pass, ox, oy);
+  int bw, bh, nrx;
+  ss_block_shape(pass, bw, bh);
+  const int rb = ss_region_blocks(pass);
+  const uint32_t per_tile = (uint32_t)ss_regions_per_tile(pass, A.blocksize, nrx);  // laid out for full tiles; edge tiles leave regions empty
+  const uint32_t total = per_tile * (uint32_t)A.ntiles;
   for (;;) {
     uint32_t w = 0;
     if (lane == 0) w = atomicAdd(&A.ss_cnt[8 + pass], 1u);  // queue head of this pass
     w = __shfl(w, 0, 64);
-    if ((unsigned long long)w * 64 >= n) break;
-    uint32_t k = w * 64 + lane;
-    const bool valid = k < n;
-    uint32_t idx = A.ss_list[valid ? k : n - 1];
-    DTile t = ss_tile_of(A, idx);
-    int i = (int)(idx - t.pix_base), dx = i % t.w, dy = i / t.w;
-    float off = pass == 5 ? 0.5f : 0.0f;  // pass 5 samples between pixels (getCoordsf (x+.5) (y+.5), Glome.hs:307)
-    float xc, yc;
-    get_coordsf(A.width, A.height, (float)(t.x + dx) + off, (float)(t.y + dy) + off, xc, yc);
-    Ray ray = primary_ray(A.cam, xc, yc);
-    if (valid) T.cnt.primary++;
-    HitG h;
-    CA c = trace_primary(T, ray, kInf, A.maxdepth, valid, &h, false);  // a compacted sample list: per-lane traversal
-    if (!valid) continue;
-    TC s = tc(c.r, c.g, c.b, c.a, h.hit ? h.t : kInf);
-    if (pass < 5) ss_store(v, idx, s);
-    else {
-      TC a = ss_getc(v, t, dx + ox[0], dy + oy[0]), b = ss_getc(v, t, dx + ox[1], dy + oy[1]);
-      TC cc = ss_getc(v, t, dx + ox[2], dy + oy[2]), d = ss_getc(v, t, dx + ox[3], dy + oy[3]);
-      ss_write_out(A, t, dx, dy, ss_pass5_blend(s, a, b, cc, d, dx == t.w - 1, dy == t.h - 1));
+    if (w >= total) break;
+    const DTile t = A.tiles[w / per_tile];
+    const int r = (int)(w % per_tile), rx = r % nrx, ry = r / nrx;
+    // ---- decide: every candidate of the region takes the contrast test; the ones that need a sample are listed
+    uint32_t n = 0;  // wave-uniform
+    for (int sb = 0; sb < rb * rb; sb++) {
+      const int bx = rx * rb + (sb % rb), by = ry * rb + (sb / rb);
+      if (bx * bw >= t.w || by * bh >= t.h) continue;  // wave-uniform: the block lies outside a clipped edge tile
+      if (pass == 1) {  // MUV.replicate ... (0,0,0,0,infinity), Glome.hs:231: this block's pixels start blank
+        for (int i = lane; i < bw * bh; i += 64) {
+          int px = bx * bw + i % bw, py = by * bh + i / bw;
+          if (px < t.w && py < t.h) ss_store(v, (size_t)t.pix_base + (size_t)py * t.w + px, tc_blank());
+        }
+      }
+      int dx, dy;
+      ss_block_pixel(pass, bx, by, lane, dx, dy);
+      bool need = dx < t.w && dy < t.h;
+      if (need && pass >= 2) {
+        TC a = ss_getc(v, t, dx + ox[0], dy + oy[0]), bb = ss_getc(v, t, dx + ox[1], dy + oy[1]);
+        TC c = ss_getc(v, t, dx + ox[2], dy + oy[2]), d = ss_getc(v, t, dx + ox[3], dy + oy[3]);
+        need = gmaxf(ccmp(a, c), ccmp(bb, d)) > thr;  // decide, Glome.hs:215-216
+        if (!need) {
+          TC avg = cavg4(a, bb, c, d);
+          if (pass < 5) ss_store(v, (size_t)t.pix_base + (size_t)dy * t.w + dx, avg);
+          else ss_write_out(A, t, dx, dy, ss_pass5_blend(avg, a, bb, c, d, dx == t.w - 1, dy == t.h - 1));
+        }
+      }
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(need);
+      if (need) need_list[n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)dx | ((uint32_t)dy << 8);
+      n += (uint32_t)__popcll(m);
     }
+    __syncthreads();  // one wave per block: makes the list visible across lanes
+    // ---- trace: 64 listed candidates at a time -- neighbours in the image, walked as a packet
+    for (uint32_t base = 0; base < n; base += 64) {
+      const bool valid = base + lane < n;
+      const uint32_t e = need_list[valid ? base + lane : base];
+      const int dx = (int)(e & 255u), dy = (int)(e >> 8);
+      const float off = pass == 5 ? 0.5f : 0.0f;  // pass 5 samples between pixels (getCoordsf (x+.5) (y+.5), Glome.hs:307)
+      float xc, yc;
+      get_coordsf(A.width, A.height, (float)(t.x + dx) + off, (float)(t.y + dy) + off, xc, yc);
+      Ray ray = primary_ray(A.cam, xc, yc);
+      if (valid) T.cnt.primary++;
+      HitG h;
+      CA col = trace_primary(T, ray, kInf, A.maxdepth, valid, &h);
+      if (!valid) continue;
+      TC s = tc(col.r, col.g, col.b, col.a, h.hit ? h.t : kInf);
+      if (pass < 5) ss_store(v, (size_t)t.pix_base + (size_t)dy * t.w + dx, s);
+      else {
+        TC a = ss_getc(v, t, dx + ox[0], dy + oy[0]), bb = ss_getc(v, t, dx + ox[1], dy + oy[1]);
+        TC c = ss_getc(v, t, dx + ox[2], dy + oy[2]), d = ss_getc(v, t, dx + ox[3], dy + oy[3]);
+        ss_write_out(A, t, dx, dy, ss_pass5_blend(s, a, bb, c, d, dx == t.w - 1, dy == t.h - 1));
+      }
+    }
+    __syncthreads();  // the list is reused by the next region
   }
 }
 template <bool FULL, int CLS>
-__global__ void __launch_bounds__(64) k_ss_trace_flat(DRenderArgs A, int pass, int stack_cap, uint32_t* ovf, int ovf_cap) {
+__global__ void __launch_bounds__(64) k_ss_pass_flat(DRenderArgs A, int pass, int stack_cap, uint32_t* ovf, int ovf_cap) {
   extern __shared__ uint32_t lds[];
   FlatTier<false, false, FULL, CLS> T{A.S, A.lights, A.nlights, lane_stack(lds, stack_cap, ovf, ovf_cap), Cnt()};
-  ss_trace_loop(A, T, pass);
+  ss_pass_loop(A, T, pass);
   flush_counters(A.counters, T.cnt, 0);
 }
-__global__ void __launch_bounds__(64) k_ss_trace_generic(DRenderArgs A, int pass) {
+__global__ void __launch_bounds__(64) k_ss_pass_generic(DRenderArgs A, int pass) {
   GenericTier T{A.S, A.lights, A.nlights, Cnt()};
-  ss_trace_loop(A, T, pass);
+  ss_pass_loop(A, T, pass);
   flush_counters(A.counters, T.cnt, T.err);
 }
 
@@ -790,13 +783,12 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
   A.work_base = ctx->slot().work_base;
   hipEvent_t ev_start = ctx->ev0, ev_stop = ctx->ev1;
   if (A.ntiles > 0 && P->mode == GLOME_MODE_SUBSAMPLE) {
-    // scratch: v (5 floats per owned pixel) | list (one u32 per owned pixel) | 16 counters (list lengths, queue heads)
+    // scratch: v (5 floats per owned pixel) | 16 counters (per-pass queue heads)
     size_t npx = (size_t)tt->pixels;
-    if ((rc = ensure_scratch(ctx, npx * 5 * sizeof(float) + npx * sizeof(uint32_t) + 16 * sizeof(unsigned int)))) return rc;
+    if ((rc = ensure_scratch(ctx, npx * 5 * sizeof(float) + 16 * sizeof(unsigned int)))) return rc;
     A.scratch = ctx->slot().d_scratch;
-    A.ss_list = (uint32_t*)(A.scratch + npx * 5);
-    A.ss_cnt = (unsigned int*)(A.ss_list + npx);
-    A.total_pixels = (uint32_t)npx;
+    A.ss_cnt = (unsigned int*)(A.scratch + npx * 5);
+    A.blocksize = P->blocksize;
     HIPCHK(ctx, hipMemsetAsync(A.ss_cnt, 0, 16 * sizeof(unsigned int), ctx->stream));
     bool pooled = ctx->timing && (ctx->timing_seen++ % ctx->timing_stride) == 0 && ctx->pool_used + 2 <= (int)ctx->pool.size();
     hipEvent_t e0 = pooled ? ctx->pool[ctx->pool_used] : ctx->ev0, e1 = pooled ? ctx->pool[ctx->pool_used + 1] : ctx->ev1;
@@ -804,20 +796,21 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
     ev_start = e0; ev_stop = e1;
     HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
     size_t lds = s->dev.tier == 0 ? flat_lds_bytes(s->stack_cap) : 0;
-    int tgrid = persistent_grid(ctx, lds, (uint32_t)((npx + 63) / 64));
-    if (s->dev.tier == 0 && s->ovf_cap && (rc = ensure_overflow(ctx, tgrid, 1, s->ovf_cap))) return rc;
     bool full = s->has_nested_mats || (s->has_secondary_mats && P->maxdepth > 1);
     bool tri = s->dev.tier == 0 && (s->cls_mask & ~CLS_BIH_TRI) == 0;
     uint32_t* ov = s->ovf_cap ? ctx->slot().d_ovf : nullptr;
-    int dgrid = (int)std::min<size_t>((npx + 255) / 256, (size_t)ctx->prop.multiProcessorCount * 16);
     for (int pass = 1; pass <= 5; pass++) {
-      hipLaunchKernelGGL(k_ss_decide, dim3(dgrid), dim3(256), 0, ctx->stream, A, pass);
+      int nbx;
+      uint32_t items = (uint32_t)ss_regions_per_tile(pass, P->blocksize, nbx) * (uint32_t)A.ntiles;
+      int tgrid = persistent_grid(ctx, lds, items);
+      if (s->dev.tier == 0 && s->ovf_cap && (rc = ensure_overflow(ctx, tgrid, 1, s->ovf_cap))) return rc;
+      ov = s->ovf_cap ? ctx->slot().d_ovf : nullptr;
       dim3 g(tgrid), blk(64);
-      if (s->dev.tier != 0) hipLaunchKernelGGL(k_ss_trace_generic, g, blk, 0, ctx->stream, A, pass);
-      else if (tri && !full) hipLaunchKernelGGL((k_ss_trace_flat<false, CLS_BIH_TRI>), g, blk, lds, ctx->stream, A, pass, s->stack_cap, ov, s->ovf_cap);
-      else if (tri) hipLaunchKernelGGL((k_ss_trace_flat<true, CLS_BIH_TRI>), g, blk, lds, ctx->stream, A, pass, s->stack_cap, ov, s->ovf_cap);
-      else if (!full) hipLaunchKernelGGL((k_ss_trace_flat<false, CLS_ALL>), g, blk, lds, ctx->stream, A, pass, s->stack_cap, ov, s->ovf_cap);
-      else hipLaunchKernelGGL((k_ss_trace_flat<true, CLS_ALL>), g, blk, lds, ctx->stream, A, pass, s->stack_cap, ov, s->ovf_cap);
+      if (s->dev.tier != 0) hipLaunchKernelGGL(k_ss_pass_generic, g, blk, 0, ctx->stream, A, pass);
+      else if (tri && !full) hipLaunchKernelGGL((k_ss_pass_flat<false, CLS_BIH_TRI>), g, blk, lds, ctx->stream, A, pass, s->stack_cap, ov, s->ovf_cap);
+      else if (tri) hipLaunchKernelGGL((k_ss_pass_flat<true, CLS_BIH_TRI>), g, blk, lds, ctx->stream, A, pass, s->stack_cap, ov, s->ovf_cap);
+      else if (!full) hipLaunchKernelGGL((k_ss_pass_flat<false, CLS_ALL>), g, blk, lds, ctx->stream, A, pass, s->stack_cap, ov, s->ovf_cap);
+      else hipLaunchKernelGGL((k_ss_pass_flat<true, CLS_ALL>), g, blk, lds, ctx->stream, A, pass, s->stack_cap, ov, s->ovf_cap);
     }
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(e1, ctx->stream));

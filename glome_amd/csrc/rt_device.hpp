@@ -16,10 +16,12 @@
 #include <hip/hip_runtime.h>
 #define GD __device__ __forceinline__
 #define GDN __device__ __noinline__
+#define GHD __host__ __device__ inline
 #else
 #include <cmath>
 #include <cstring>
 #define GD inline
+#define GHD inline
 #define GDN
 #endif
 
@@ -1338,6 +1340,33 @@ GD void ss_neighbours(int p, int* ox, int* oy) {
     case 3: ox[0] = -1; oy[0] = -1; ox[1] = 1; oy[1] = -1; ox[2] = 1; oy[2] = 1; ox[3] = -1; oy[3] = 1; break;  // :274-277
     case 4: ox[0] = -1; oy[0] = 0; ox[1] = 0; oy[1] = 1; ox[2] = 1; oy[2] = 0; ox[3] = 0; oy[3] = -1; break;    // :287-290
     default: ox[0] = 0; oy[0] = 0; ox[1] = 0; oy[1] = 1; ox[2] = 1; oy[2] = 1; ox[3] = 1; oy[3] = 0; break;     // pass 5, :303-306
+  }
+}
+// One wave = one block of a tile's candidate lattice.  Block shapes are chosen so a block holds 64 candidates of its pass:
+//   passes 1, 2   32x16 pixels: the even lattice (2i, 2j), i + j even (pass 1) or odd (pass 2)
+//   pass 3        16x16 pixels: the odd-odd lattice
+//   pass 4        16x8 pixels: dx + dy odd
+//   pass 5        8x8 pixels: every pixel
+GHD void ss_block_shape(int p, int& bw, int& bh) {
+  switch (p) { case 1: case 2: bw = 32; bh = 16; break; case 3: bw = 16; bh = 16; break; case 4: bw = 16; bh = 8; break; default: bw = 8; bh = 8; break; }
+}
+// A work item (region) is 1x1 block in passes 1-2 (nearly every candidate is sampled) and 2x2 blocks in passes 3-5, where
+// only some candidates need a sample: those are compacted over the region before they are traced, so the packets stay full.
+GHD int ss_region_blocks(int p) { return p <= 2 ? 1 : 2; }
+GHD int ss_regions_per_tile(int p, int tile_size, int& nrx) {
+  int bw, bh; ss_block_shape(p, bw, bh);
+  const int rb = ss_region_blocks(p);
+  nrx = (tile_size + bw * rb - 1) / (bw * rb);
+  return nrx * ((tile_size + bh * rb - 1) / (bh * rb));
+}
+// candidate pixel (tile-local) of `lane` in block (bx, by) of pass p; every lane of a block maps to a distinct candidate
+GD void ss_block_pixel(int p, int bx, int by, int lane, int& dx, int& dy) {
+  const int k = lane & 7, ly = lane >> 3;
+  switch (p) {
+    case 1: case 2: { int j = by * 8 + ly; int i = bx * 16 + 2 * k + ((j + (p - 1)) & 1); dx = 2 * i; dy = 2 * j; break; }
+    case 3: dx = bx * 16 + 2 * k + 1; dy = by * 16 + 2 * ly + 1; break;
+    case 4: dy = by * 8 + ly; dx = bx * 16 + 2 * k + (1 - (dy & 1)); break;
+    default: dx = bx * 8 + k; dy = by * 8 + ly; break;
   }
 }
 // pass 5's write: the new sample blended with the pixel's neighbourhood; edge pixels use two-sample averages (:309-316)

@@ -109,9 +109,8 @@ struct DRenderArgs {
   uint32_t work_base;   // value of counters->next_work when this launch starts (0 after a counter reset)
   int32_t dense;       // 1: out5 is a dense tile payload (tile order, row major inside a tile) instead of a frame
   float* scratch;      // adaptive sampler: dense per-tile working buffer `v` (owned pixels * 5 floats)
-  uint32_t* ss_list;   // adaptive sampler: pixels (dense index) that need a traced sample in the current pass
-  unsigned int* ss_cnt;  // [pass] list length, [8 + pass] queue head
-  uint32_t total_pixels;  // owned pixels
+  unsigned int* ss_cnt;  // adaptive sampler: [8 + pass] work-queue head of the pass
+  int32_t blocksize;     // adaptive sampler: tile edge (<= 65); work items are laid out for full-size tiles
   float* out5;         // width*height*5
   uint32_t* packed;    // width*height or null
   DCounters* counters;
