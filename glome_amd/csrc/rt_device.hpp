@@ -12,6 +12,7 @@
 #pragma once
 #include "rt_types.h"
 
+#include <type_traits>
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define GD __device__ __forceinline__
@@ -656,6 +657,111 @@ GD bool bih_tri(const DScene& S, uint32_t hdr, const Ray& r, float d, STK& stk, 
 // when they do not (a block straddling an axis plane through the eye), or the root is a leaf, the lanes fall back to
 // bih_tri.  Results, tie order and work counters are identical to the per-lane traversal.
 // `valid`: the lane holds a ray.  All lanes of the wave must make this call together.
+// ------------------------------------------------------------------ the branch steps of a packet, hand-scheduled
+// The compiler turns the wave-uniform control flow of the branch step into ~60 instructions, two thirds of them scalar
+// bookkeeping (64-bit lane masks selected as pairs of 32-bit moves, branch conditions materialised as masks); the
+// kernel is bound by instruction issue, so the step is written out here: ~30 instructions, every decision one scalar
+// compare + branch, the three axes and the two directions as separate straight-line pieces.  Same arithmetic, same
+// order of operations as the C++ step in bih_tri_packet (which remains the reference implementation: the host
+// compile, the counting variants and every case this routine declines go through it).
+//   walks down from `ref` while it is a branch; returns 0 when it stands on a leaf (am != 0) or nothing is left
+//   (am == 0); returns 1 -- with the state untouched at that node -- when a push would not fit the LDS part of the stack.
+// Registers s[60:69] and vcc are scratch (named in the clobber list); the LDS rows are `cap_lds` entries apart.
+#if defined(__HIPCC__)
+constexpr int kAsmLdsCap = 12;  // the LDS part of the stack the row offsets below are written for
+GD int bih_descend_asm(const F4* nodes, uint32_t& ref, LaneMask& am, int& sp, float& nearv, float& farv, uint32_t fwdbits, int cap_lds,
+                       V3 o, V3 rcp, uint32_t lds_row) {
+  int status;
+  float dl, dr, tv;
+  uint32_t wv, av;
+  asm volatile(
+      "L_node_%=:\n"
+      "  s_bitcmp1_b32 %[ref], 29\n"
+      "  s_cbranch_scc1 L_done_%=\n"
+      "  s_lshl_b32 s68, %[ref], 4\n"
+      "  s_load_dwordx4 s[60:63], %[nodes], s68\n"
+      "  s_waitcnt lgkmcnt(0)\n"
+      "  s_and_b32 s69, s62, 3\n"
+      "  s_lshr_b32 s62, s62, 2\n"
+      "  s_cmp_eq_u32 s69, 0\n"
+      "  s_cbranch_scc1 L_ax0_%=\n"
+      "  s_cmp_eq_u32 s69, 1\n"
+      "  s_cbranch_scc1 L_ax1_%=\n"
+      "  v_sub_f32 %[dl], s60, %[oz]\n"
+      "  v_sub_f32 %[dr], s61, %[oz]\n"
+      "  v_mul_f32 %[dl], %[dl], %[rz]\n"
+      "  v_mul_f32 %[dr], %[dr], %[rz]\n"
+      "  s_bitcmp1_b32 %[fwd], 2\n"
+      "  s_branch L_join_%=\n"
+      "L_ax0_%=:\n"
+      "  v_sub_f32 %[dl], s60, %[ox]\n"
+      "  v_sub_f32 %[dr], s61, %[ox]\n"
+      "  v_mul_f32 %[dl], %[dl], %[rx]\n"
+      "  v_mul_f32 %[dr], %[dr], %[rx]\n"
+      "  s_bitcmp1_b32 %[fwd], 0\n"
+      "  s_branch L_join_%=\n"
+      "L_ax1_%=:\n"
+      "  v_sub_f32 %[dl], s60, %[oy]\n"
+      "  v_sub_f32 %[dr], s61, %[oy]\n"
+      "  v_mul_f32 %[dl], %[dl], %[ry]\n"
+      "  v_mul_f32 %[dr], %[dr], %[ry]\n"
+      "  s_bitcmp1_b32 %[fwd], 1\n"
+      "L_join_%=:\n"
+      "  s_cbranch_scc1 L_fwd_%=\n"
+      "  v_swap_b32 %[dl], %[dr]\n"      // rays run towards -axis: the near child is the right one
+      "  s_mov_b32 s68, s62\n"
+      "  s_mov_b32 s62, s63\n"
+      "  s_mov_b32 s63, s68\n"
+      "L_fwd_%=:\n"                      // near child s62 ends at dl, far child s63 starts at dr
+      "  v_cmp_lt_f32 vcc, %[near], %[dl]\n"
+      "  s_and_b64 s[64:65], vcc, %[am]\n"
+      "  v_cmp_lt_f32 vcc, %[dr], %[far]\n"
+      "  s_and_b64 s[66:67], vcc, %[am]\n"
+      "  s_cmp_lg_u64 s[64:65], 0\n"
+      "  s_cbranch_scc0 L_no1_%=\n"
+      "  s_cmp_lg_u64 s[66:67], 0\n"
+      "  s_cbranch_scc0 L_nopush_%=\n"
+      "  s_cmp_ge_i32 %[sp], %[cap]\n"
+      "  s_cbranch_scc1 L_slow_%=\n"
+      "  v_max_f32 %[tv], %[dr], %[near]\n"
+      "  v_mov_b32 %[wv], s63\n"
+      "  s_lshl_b32 s68, %[sp], 8\n"
+      "  v_writelane_b32 %[wv], s66, 1\n"
+      "  v_writelane_b32 %[wv], s67, 2\n"
+      "  v_add_u32 %[av], s68, %[lds]\n"
+      "  ds_write_b32 %[av], %[wv]\n"
+      "  ds_write_b32 %[av], %[tv] offset:%[row1]\n"
+      "  ds_write_b32 %[av], %[far] offset:%[row2]\n"
+      "  s_add_i32 %[sp], %[sp], 1\n"
+      "L_nopush_%=:\n"
+      "  v_min_f32 %[far], %[dl], %[far]\n"
+      "  s_mov_b32 %[ref], s62\n"
+      "  s_mov_b64 %[am], s[64:65]\n"
+      "  s_branch L_node_%=\n"
+      "L_no1_%=:\n"
+      "  s_cmp_lg_u64 s[66:67], 0\n"
+      "  s_cbranch_scc0 L_none_%=\n"
+      "  v_max_f32 %[near], %[dr], %[near]\n"
+      "  s_mov_b32 %[ref], s63\n"
+      "  s_mov_b64 %[am], s[66:67]\n"
+      "  s_branch L_node_%=\n"
+      "L_none_%=:\n"
+      "  s_mov_b64 %[am], 0\n"
+      "L_done_%=:\n"
+      "  s_mov_b32 %[status], 0\n"
+      "  s_branch L_end_%=\n"
+      "L_slow_%=:\n"
+      "  s_mov_b32 %[status], 1\n"
+      "L_end_%=:\n"
+      : [ref] "+s"(ref), [am] "+s"(am), [sp] "+s"(sp), [near] "+v"(nearv), [far] "+v"(farv), [status] "=s"(status),
+        [dl] "=&v"(dl), [dr] "=&v"(dr), [tv] "=&v"(tv), [wv] "=&v"(wv), [av] "=&v"(av)
+      : [fwd] "s"(fwdbits), [nodes] "s"(nodes), [cap] "s"(cap_lds), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [rx] "v"(rcp.x), [ry] "v"(rcp.y),
+        [rz] "v"(rcp.z), [lds] "v"(lds_row), [row1] "n"(kAsmLdsCap * 256), [row2] "n"(2 * kAsmLdsCap * 256)
+      : "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "vcc", "scc", "memory");
+  return status;
+}
+#endif
+
 // The packet loop proper.  Every branch in it is wave-uniform (the per-lane decisions are selects), and it takes and
 // returns everything by value, so it can be compiled as a function of its own with plain scalar control flow.
 struct PacketResult { float best_t; uint32_t best_rec; uint32_t occ_lo, occ_hi, n_bih, n_prim; };
@@ -677,6 +783,13 @@ GPK PacketResult bih_tri_packet(const F4* nodes, const F4* tris, uint32_t ref, u
     // ---- branch steps: walk down while the reference is a branch
     while (!(ref & BREF_LEAF)) {
       ref = uni(ref); am = uni(am); sp = (int)uni((uint32_t)sp);  // wave-uniform by construction: keep them in SGPRs
+#if defined(__HIPCC__) && !defined(GLOME_EXP_NO_ASM)
+      if constexpr (!COUNT && std::is_same<STK, LaneStack>::value) {
+        if (stk.cap == kAsmLdsCap) {  // the hand-scheduled branch steps; returns 1 where a push has to go to the overflow columns
+          if (bih_descend_asm(nodes, ref, am, sp, nearv, farv, fwdbits, stk.cap, r.o, rcp, (uint32_t)(uintptr_t)stk.node) == 0) break;
+        }
+      }
+#endif
       F4 n = LD_NODE(nodes, ref);
       const uint32_t w0 = uni(as_u(n.z)), right = uni(as_u(n.w));
       const uint32_t axis = w0 & 3u, left = w0 >> 2;
