@@ -244,9 +244,39 @@ class Flattener {
     uint32_t cls = all_tri ? BC_TRI : (all_sph ? BC_SPHERE : (all_simple ? BC_SIMPLE : BC_GENERIC));
     uint32_t hdr = (uint32_t)(F.bihhdr.size() / 3);
     F.bihhdr.resize(F.bihhdr.size() + 3);  // reserved now: items of a generic BIH may emit nested BIHs before we fill it
+    // Node slots: only branches (and leaves of 7+ items, whose extent lives in a slot) get one.  Branches are laid out
+    // in small treelets -- a node, then its branch children, then a grandchild, four 16-byte nodes to a 64-byte cache
+    // line -- and the treelets depth first, so the step after a fetch usually finds its node in the line just fetched
+    // and a subtree is contiguous.  References are explicit, so the traversal does not care about the order.
+    std::vector<uint32_t> slot(T.nodes.size(), 0xffffffffu);
     uint32_t base = (uint32_t)F.bihnodes.size();
-    F.bihnodes.resize(base + T.nodes.size());  // one slot per tree node; leaf slots are only read for leaves of 7+ items
-    if (base + T.nodes.size() >= BREF_FIRST_LIMIT) throw limit_error("too many BIH nodes");
+    base = (base + 3u) & ~3u;  // line-align this tree's first treelet
+    uint32_t nslots = 0;
+    {
+      std::vector<int> roots;  // treelet roots still to place (a stack: depth first)
+      if (!T.nodes.empty() && !T.nodes[0].leaf) roots.push_back(0);
+      while (!roots.empty()) {
+        int x = roots.back(); roots.pop_back();
+        int group[4]; int ng = 0;
+        group[ng++] = x;
+        for (int q = 0; q < ng && ng < 4; q++) {  // breadth first inside the treelet
+          const BihTree::Node& b = T.nodes[group[q]];
+          if (!T.nodes[b.left].leaf && ng < 4) group[ng++] = b.left;
+          if (!T.nodes[b.right].leaf && ng < 4) group[ng++] = b.right;
+        }
+        for (int q = 0; q < ng; q++) slot[group[q]] = nslots++;
+        // branch children of the group's members that did not fit start treelets of their own; right pushed first so the
+        // left subtree is laid out next
+        for (int q = ng - 1; q >= 0; q--) {
+          const BihTree::Node& b = T.nodes[group[q]];
+          if (!T.nodes[b.right].leaf && slot[b.right] == 0xffffffffu) roots.push_back(b.right);
+          if (!T.nodes[b.left].leaf && slot[b.left] == 0xffffffffu) roots.push_back(b.left);
+        }
+      }
+      for (size_t k = 0; k < T.nodes.size(); k++) if (T.nodes[k].leaf && T.nodes[k].items.size() > 6) slot[k] = nslots++;
+    }
+    F.bihnodes.resize(base + std::max<uint32_t>(nslots, 1u));
+    if (base + nslots >= BREF_FIRST_LIMIT) throw limit_error("too many BIH nodes");
     // pass 1: leaves -- emit the items fresh (no memo) so records and pool entries are consecutive, and build the
     // child reference that describes each leaf (rt_device.hpp: BREF_*)
     std::vector<uint32_t> ref(T.nodes.size(), 0);
@@ -254,7 +284,7 @@ class Flattener {
     bool have_delta = false;
     for (size_t k = 0; k < T.nodes.size(); k++) {
       const BihTree::Node& bn = T.nodes[k];
-      if (!bn.leaf) { ref[k] = base + (uint32_t)k; continue; }
+      if (!bn.leaf) { ref[k] = base + slot[k]; continue; }
       std::vector<U4> items;
       uint32_t first_prim = 0;
       for (size_t q = 0; q < bn.items.size(); q++) {
@@ -278,10 +308,9 @@ class Flattener {
         if (have_delta && dl != delta) throw scene_error("internal: BIH leaf pools are not contiguous");
         delta = dl; have_delta = true;
       }
-      F.bihnodes[base + k] = F4{0.0f, 0.0f, as_float_bits(count), as_float_bits(first_rec)};
       if (count == 0) ref[k] = BREF_LEAF_BIT;
       else if (count <= 6) ref[k] = BREF_LEAF_BIT | (count << 26) | first_rec;
-      else ref[k] = BREF_LEAF_BIT | (7u << 26) | (base + (uint32_t)k);
+      else { F.bihnodes[base + slot[k]] = F4{0.0f, 0.0f, as_float_bits(count), as_float_bits(first_rec)}; ref[k] = BREF_LEAF_BIT | (7u << 26) | (base + slot[k]); }
     }
     // pass 2: branches
     for (size_t k = 0; k < T.nodes.size(); k++) {
@@ -292,7 +321,7 @@ class Flattener {
       // never enters it and needs no test for it.  The other child's interval does not depend on this plane.
       const float inf = std::numeric_limits<float>::infinity();
       float ls = ref[bn.left] == BREF_LEAF_BIT ? -inf : round_up(bn.lsplit), rs = ref[bn.right] == BREF_LEAF_BIT ? inf : round_down(bn.rsplit);
-      F.bihnodes[base + k] = F4{ls, rs, as_float_bits((uint32_t)bn.axis | (ref[bn.left] << 2)), as_float_bits(ref[bn.right])};
+      F.bihnodes[base + slot[k]] = F4{ls, rs, as_float_bits((uint32_t)bn.axis | (ref[bn.left] << 2)), as_float_bits(ref[bn.right])};
     }
     F.bihhdr[3 * hdr] = mk4u(round_down(T.bb.lo.x), round_down(T.bb.lo.y), round_down(T.bb.lo.z), ref[0]);
     F.bihhdr[3 * hdr + 1] = mk4u(round_up(T.bb.hi.x), round_up(T.bb.hi.y), round_up(T.bb.hi.z), cls);
