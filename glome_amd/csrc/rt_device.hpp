@@ -670,7 +670,7 @@ GD bool bih_tri(const DScene& S, uint32_t hdr, const Ray& r, float d, STK& stk, 
 #if defined(__HIPCC__)
 constexpr int kAsmLdsCap = 12;  // the LDS part of the stack the row offsets below are written for
 GD int bih_descend_asm(const F4* nodes, uint32_t& ref, LaneMask& am, int& sp, float& nearv, float& farv, uint32_t fwdbits, int cap_lds,
-                       V3 o, V3 rcp, uint32_t lds_row) {
+                       V3 o, V3 rcp, uint32_t lds_row, uint32_t& g_asm_twait, uint32_t& g_asm_nstep) {
   int status;
   float dl, dr, tv;
   uint32_t wv, av;
@@ -679,8 +679,20 @@ GD int bih_descend_asm(const F4* nodes, uint32_t& ref, LaneMask& am, int& sp, fl
       "  s_bitcmp1_b32 %[ref], 29\n"
       "  s_cbranch_scc1 L_done_%=\n"
       "  s_lshl_b32 s68, %[ref], 4\n"
+#if defined(GLOME_EXP_ASM_TIMING)
+      "  s_memtime s[70:71]\n"
+      "  s_waitcnt lgkmcnt(0)\n"
       "  s_load_dwordx4 s[60:63], %[nodes], s68\n"
       "  s_waitcnt lgkmcnt(0)\n"
+      "  s_memtime s[72:73]\n"
+      "  s_waitcnt lgkmcnt(0)\n"
+      "  s_sub_u32 s72, s72, s70\n"
+      "  s_add_u32 %[twait], %[twait], s72\n"
+      "  s_add_u32 %[nstep], %[nstep], 1\n"
+#else
+      "  s_load_dwordx4 s[60:63], %[nodes], s68\n"
+      "  s_waitcnt lgkmcnt(0)\n"
+#endif
       "  s_and_b32 s69, s62, 3\n"
       "  s_lshr_b32 s62, s62, 2\n"
       "  s_cmp_eq_u32 s69, 0\n"
@@ -755,9 +767,16 @@ GD int bih_descend_asm(const F4* nodes, uint32_t& ref, LaneMask& am, int& sp, fl
       "L_end_%=:\n"
       : [ref] "+s"(ref), [am] "+s"(am), [sp] "+s"(sp), [near] "+v"(nearv), [far] "+v"(farv), [status] "=s"(status),
         [dl] "=&v"(dl), [dr] "=&v"(dr), [tv] "=&v"(tv), [wv] "=&v"(wv), [av] "=&v"(av)
+#if defined(GLOME_EXP_ASM_TIMING)
+        , [twait] "+s"(g_asm_twait), [nstep] "+s"(g_asm_nstep)
+#endif
       : [fwd] "s"(fwdbits), [nodes] "s"(nodes), [cap] "s"(cap_lds), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [rx] "v"(rcp.x), [ry] "v"(rcp.y),
         [rz] "v"(rcp.z), [lds] "v"(lds_row), [row1] "n"(kAsmLdsCap * 256), [row2] "n"(2 * kAsmLdsCap * 256)
-      : "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "vcc", "scc", "memory");
+      : "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69",
+#if defined(GLOME_EXP_ASM_TIMING)
+        "s70", "s71", "s72", "s73",
+#endif
+        "vcc", "scc", "memory");
   return status;
 }
 #endif
@@ -779,6 +798,7 @@ GPK PacketResult bih_tri_packet(const F4* nodes, const F4* tris, uint32_t ref, u
   PacketResult R; R.best_t = best_t; R.best_rec = kNoRec; R.n_bih = 0; R.n_prim = 0;
   int sp = 0;
   LaneMask occm = 0;  // MODE 2: lanes that found an occluder
+  uint32_t exp_twait = 0, exp_nstep = 0;  // GLOME_EXP_ASM_TIMING only
   for (;;) {
     // ---- branch steps: walk down while the reference is a branch
     while (!(ref & BREF_LEAF)) {
@@ -786,7 +806,7 @@ GPK PacketResult bih_tri_packet(const F4* nodes, const F4* tris, uint32_t ref, u
 #if defined(__HIPCC__) && !defined(GLOME_EXP_NO_ASM)
       if constexpr (!COUNT && std::is_same<STK, LaneStack>::value) {
         if (stk.cap == kAsmLdsCap) {  // the hand-scheduled branch steps; returns 1 where a push has to go to the overflow columns
-          if (bih_descend_asm(nodes, ref, am, sp, nearv, farv, fwdbits, stk.cap, r.o, rcp, (uint32_t)(uintptr_t)stk.node) == 0) break;
+          if (bih_descend_asm(nodes, ref, am, sp, nearv, farv, fwdbits, stk.cap, r.o, rcp, (uint32_t)(uintptr_t)stk.node, exp_twait, exp_nstep) == 0) break;
         }
       }
 #endif
@@ -853,6 +873,9 @@ GPK PacketResult bih_tri_packet(const F4* nodes, const F4* tris, uint32_t ref, u
     if (am == 0) break;
   }
   R.occ_lo = (uint32_t)occm; R.occ_hi = (uint32_t)(occm >> 32);
+#if defined(GLOME_EXP_ASM_TIMING)
+  R.n_bih = exp_nstep; R.n_prim = exp_twait;
+#endif
   return R;
 }
 
@@ -883,6 +906,9 @@ GD bool bih_tri_wave(const DScene& S, uint32_t hdr, const Ray& r, float d, bool 
     todo &= ~am;
     PacketResult R = bih_tri_packet<MODE, COUNT, LEAFK, STK>(S.bihnodes, LEAFK == 0 ? S.tris : S.spheres, ref, delta, fwdbits, (uint32_t)am, (uint32_t)(am >> 32),
                                                               nearv, farv, r.o, r.d, rcp, best_t, stk);
+#if defined(GLOME_EXP_ASM_TIMING)
+    if ((threadIdx.x & 63) == 0) { cnt.bih += R.n_bih; cnt.prim += R.n_prim; }
+#endif
     if (lane_of(am)) {
       if (COUNT) { cnt.bih += R.n_bih; cnt.prim += R.n_prim; }
       if (MODE != 2 && R.best_rec != kNoRec) { best_t = R.best_t; best_rec = R.best_rec; }
