@@ -202,6 +202,14 @@ class Builder:
     def material_layers(self, mats): return self._ids("glome_sb_material_layers", mats)
     def material_blend(self, a, b, w): return self._chk(self.lib.glome_sb_material_blend(self.h, int(a), int(b), float(w)), "glome_sb_material_blend")
 
+    def load_nff(self, text, max_lights=16):
+        """A scene in NFF (Spd.hs:89-254): returns (root node, (from, at, up, angle), [(pos, rgb), ...], background rgb)."""
+        cam = (C.c_double * 10)(); lp = (C.c_double * (6 * max_lights))(); nl = C.c_int32(0); bg = (C.c_double * 3)()
+        root = self._chk(self.lib.glome_sb_load_nff(self.h, text.encode() if isinstance(text, str) else text, cam, lp, max_lights, C.byref(nl), bg), "glome_sb_load_nff")
+        c = list(cam)
+        lights = [(tuple(lp[6 * k:6 * k + 3]), tuple(lp[6 * k + 3:6 * k + 6])) for k in range(min(nl.value, max_lights))]
+        return root, (tuple(c[0:3]), tuple(c[3:6]), tuple(c[6:9]), c[9]), lights, tuple(bg)
+
     def material_blend_fn(self, a, b, fn, params):
         """Blend a b (f pos): fn = WEIGHT_PERLIN (params = [scale]) or WEIGHT_STRIPE_* (params = axis), TestScene.hs:214-234."""
         wp = (C.c_double * 4)(*([float(x) for x in params] + [0.0] * (4 - len(params))))

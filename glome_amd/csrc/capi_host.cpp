@@ -1,6 +1,10 @@
 // capi_host.cpp -- host half of the C ABI (include/glome_hip.h): the scene builder (one call per glome
 // constructor), the transform helpers and the host-side inspection calls.  No HIP here.
+#include <algorithm>
+#include <array>
+#include <cstdlib>
 #include <cstring>
+#include <string>
 
 #include "../../include/glome_hip.h"
 #include "capi_shared.hpp"
@@ -140,6 +144,126 @@ int glome_sb_primcount(glome_sb* sb, int32_t id, long out3[3]) {
 int glome_sb_bound(glome_sb* sb, int32_t id, double out6[6]) {
   return guard(sb, [&] { Box3 b = sb->graph.bound(id); out6[0] = b.lo.x; out6[1] = b.lo.y; out6[2] = b.lo.z; out6[3] = b.hi.x; out6[4] = b.hi.y; out6[5] = b.hi.z; return 0; });
 }
+// ---- NFF / SPD scenes (GlomeTrace/Data/Glome/Spd.hs:89-254) ----
+// A restatement of the reference's Read instances: whitespace-separated tokens, `#` starts a comment that runs to the
+// end of the line (lexcr / lexignore, Spd.hs:13-30); statements v / l / b / f / s / c / p / pp; everything else ends
+// the parse like accum_rss's fall-through (Spd.hs:212-242).
+namespace {
+struct NffLex {
+  const char* p;
+  explicit NffLex(const char* t) : p(t) {}
+  void skip() {
+    for (;;) {
+      while (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n') p++;
+      if (*p == '#') { while (*p && *p != '\n') p++; continue; }
+      return;
+    }
+  }
+  bool word(std::string& w) {  // the next token, not consumed unless accepted by the caller
+    skip();
+    const char* q = p;
+    while (*q && !(*q == ' ' || *q == '\t' || *q == '\r' || *q == '\n')) q++;
+    w.assign(p, q);
+    return !w.empty();
+  }
+  void take(const std::string& w) { p += w.size(); }
+  bool number(double& v) {  // reads :: Flt -- a token that parses completely as a number
+    std::string w;
+    if (!word(w)) return false;
+    char* end = nullptr;
+    double x = std::strtod(w.c_str(), &end);
+    if (end == w.c_str() || *end != 0) return false;
+    if (!((w[0] >= '0' && w[0] <= '9') || ((w[0] == '-') && w.size() > 1 && w[1] >= '0' && w[1] <= '9'))) return false;  // Haskell wants a leading digit
+    take(w); v = x;
+    return true;
+  }
+  bool vec(D3& v) { const char* save = p; if (number(v.x) && number(v.y) && number(v.z)) return true; p = save; return false; }
+  bool keyword(const char* k) { std::string w; if (word(w) && w == k) { take(w); return true; } return false; }
+};
+}  // namespace
+
+int32_t glome_sb_load_nff(glome_sb* sb, const char* text, double cam_from_at_up_angle[10], double* light_pos_rgb, int32_t max_lights, int32_t* n_lights,
+                          double bg_rgb[3]) {
+  return guard(sb, [&] {
+    if (!text) throw std::invalid_argument("null NFF text");
+    Graph& G = sb->graph;
+    NffLex L(text);
+    std::vector<int> groups;               // `tex (bih prims) fill`, in order of appearance
+    std::vector<std::array<double, 6>> lights;
+    bool have_cam = false, have_bg = false;
+    double cam[10] = {0}, bg[3] = {0, 0, 0};
+    int fill = -1;
+    std::vector<int> prims;
+    auto close_group = [&] { if (fill >= 0) groups.push_back(G.wrap(K_TEX, G.bih(prims), fill)); prims.clear(); };
+    for (;;) {
+      std::string w;
+      if (!L.word(w)) break;
+      const char* save = L.p;
+      if (w == "v") {  // Spd.hs:89-107
+        L.take(w);
+        D3 from, at, up; double angle, skipn;
+        std::string tok;
+        bool ok = L.keyword("from") && L.vec(from) && L.keyword("at") && L.vec(at) && L.keyword("up") && L.vec(up) && L.keyword("angle") && L.number(angle) &&
+                  L.keyword("hither") && L.word(tok);
+        if (ok) { L.take(tok); ok = L.keyword("resolution") && L.word(tok); }
+        if (ok) { L.take(tok); ok = L.word(tok); }
+        if (ok) L.take(tok);
+        (void)skipn;
+        if (!ok) { L.p = save; break; }
+        double c[10] = {from.x, from.y, from.z, at.x, at.y, at.z, up.x, up.y, up.z, angle};
+        memcpy(cam, c, sizeof(c)); have_cam = true;  // the last camera of the file wins (accum_rss conses)
+      } else if (w == "l") {  // Spd.hs:131-139: colour optional, default white
+        L.take(w);
+        D3 pos, c{1, 1, 1};
+        if (!L.vec(pos)) { L.p = save; break; }
+        D3 cc; if (L.vec(cc)) c = cc;
+        lights.push_back({pos.x, pos.y, pos.z, c.x, c.y, c.z});
+      } else if (w == "b") {  // Spd.hs:123-128
+        L.take(w);
+        D3 c; if (!L.vec(c)) { L.p = save; break; }
+        bg[0] = c.x; bg[1] = c.y; bg[2] = c.z; have_bg = true;
+      } else if (w == "f") {  // Spd.hs:141-153: Surface clr (1 - T) 0 kd ks shine
+        L.take(w);
+        D3 c; double kd, ks, shine, trans, ior;
+        if (!(L.vec(c) && L.number(kd) && L.number(ks) && L.number(shine) && L.number(trans) && L.number(ior))) { L.p = save; break; }
+        close_group();
+        Mat m; m.kind = MAT_SURFACE; m.color[0] = c.x; m.color[1] = c.y; m.color[2] = c.z; m.alpha = 1 - trans; m.amb = 0; m.kd = kd; m.ks = ks; m.shine = shine;
+        fill = G.add_mat(m);
+      } else if (w == "s" || w == "c" || w == "p" || w == "pp") {  // Spd.hs:165-182
+        if (fill < 0) break;  // a primitive needs a fill before it (readsSpdTextureGroup reads the texture first)
+        L.take(w);
+        if (w == "s") { D3 c; double r; if (!(L.vec(c) && L.number(r))) { L.p = save; break; } prims.push_back(G.sphere(c, r)); }
+        else if (w == "c") { D3 a, b; double ra, rb; if (!(L.vec(a) && L.number(ra) && L.vec(b) && L.number(rb))) { L.p = save; break; } prims.push_back(G.cone(a, ra, b, rb)); }
+        else {
+          double n;
+          if (!L.number(n)) { L.p = save; break; }  // the count is read and ignored: vertices are taken while they parse
+          std::vector<D3> vs, ns;
+          for (;;) {
+            D3 v, nn;
+            if (!L.vec(v)) break;
+            if (w == "pp") { if (!L.vec(nn)) break; ns.push_back(nn); }
+            vs.push_back(v);
+          }
+          std::vector<int> fan;  // triangles / trianglesnorms: a fan around the first vertex (Triangle.hs:28-42)
+          for (size_t k = 1; k + 1 < vs.size(); k++)
+            fan.push_back(w == "p" ? G.triangle(vs[0], vs[k], vs[k + 1]) : G.trianglenorm(vs[0], vs[k], vs[k + 1], ns[0], ns[k], ns[k + 1]));
+          prims.push_back(G.group(fan));
+        }
+      } else break;
+    }
+    close_group();
+    if (!have_cam) throw scene_error("NFF: no camera (v) statement");  // readsSpdScene's pattern needs one (Spd.hs:251)
+    if (!have_bg) throw scene_error("NFF: no background (b) statement");
+    std::reverse(groups.begin(), groups.end());  // accum_rss conses: the scene's list is in reverse order of appearance
+    std::reverse(lights.begin(), lights.end());
+    if (cam_from_at_up_angle) memcpy(cam_from_at_up_angle, cam, sizeof(cam));
+    if (bg_rgb) memcpy(bg_rgb, bg, sizeof(bg));
+    if (n_lights) *n_lights = (int32_t)lights.size();
+    for (int k = 0; k < (int)lights.size() && k < max_lights && light_pos_rgb; k++) memcpy(light_pos_rgb + 6 * k, lights[k].data(), 6 * sizeof(double));
+    return G.bih(groups);  // SPD (bih prims) lights cam bgc, Spd.hs:252
+  });
+}
+
 long glome_sb_bih_dump(glome_sb* sb, int32_t id, long cap, double* lsplit, double* rsplit, int* axis, int* nleaf, int32_t* leaf_prims, long cap_prims) {
   if (!sb) return GLOME_E_INVALID;
   try {

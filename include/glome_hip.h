@@ -101,6 +101,14 @@ int32_t glome_sb_bound_object(glome_sb*, int32_t bounding, int32_t bounded);    
 int32_t glome_sb_innerbound(glome_sb*, int32_t inner, int32_t outer);                            /* Bound.hs:116 */
 int32_t glome_sb_flatten_transform(glome_sb*, int32_t id);  /* `SolidItem (flatten_transform s)`, Solid.hs:192,273 */
 int32_t glome_sb_tolist(glome_sb*, int32_t id);             /* `tolist`, Solid.hs:177,230: a list node of the flattened items */
+/* A whole scene in the Neutral File Format of Eric Haines' SPD (GlomeTrace/Data/Glome/Spd.hs:89-254): statements v (camera),
+ * l (light, colour optional), b (background), f (fill -> Surface clr (1-T) 0 kd ks shine), s (sphere), c (cone), p / pp
+ * (polygon / polygon with normals -> a triangle fan); `#` comments.  Returns the root node -- `bih` of one
+ * `tex (bih prims) fill` per fill, in the reference's (reversed) order -- and fills camera (from, at, up, angle), up to
+ * max_lights lights (position + rgb each; *n_lights = how many the file holds) and the background colour. */
+int32_t glome_sb_load_nff(glome_sb*, const char* text, double cam_from_at_up_angle[10], double* light_pos_rgb, int32_t max_lights, int32_t* n_lights,
+                          double bg_rgb[3]);
+
 /* materials (the defunctionalised `Material`, Shader.hs:43-52; a texture is a material id = t_uniform, Shader.hs:55-56) */
 int32_t glome_sb_material_surface(glome_sb*, const double color[3], double alpha, double amb, double kd, double ks, double shine);
 int32_t glome_sb_material_reflect(glome_sb*, double refl);

@@ -342,3 +342,19 @@ def test_device_pointer_seams_match_host_seams(gpu_ctx):
     assert np.array_equal(t.cpu().numpy(), host["t"]) and np.array_equal(prim.cpu().numpy(), host["prim"])
     assert np.array_equal(occ.cpu().numpy().astype(bool), sc.shadow(ro, rd, 1e6))
     sc.release()
+
+
+@pytest.mark.gpu
+def test_nff_scene_renders_like_the_oracle(gpu_ctx):
+    """N2: a scene loaded by glome_sb_load_nff (spheres, cones, polygon fans, three lights) against the oracle fed by the
+    independent Python reading of the same text."""
+    import nff
+    text = nff.balls_nff(3)
+    b = api.Builder()
+    root, cam_desc, light_descs, bg = b.load_nff(text)
+    sc = gpu_ctx.commit(b, root)
+    sd, _ = nff.read_nff(text)
+    cam, lights = product_camera_lights(sd)
+    img, packed, st = sc.render(cam, lights, api.render_params(width=256, height=256, maxdepth=2))
+    parity.check_image(img, (st["rays_primary"], st["rays_shadow"], st["rays_secondary"]), sd, 256, 256, 2)
+    sc.release()
