@@ -358,3 +358,16 @@ def test_nff_scene_renders_like_the_oracle(gpu_ctx):
     img, packed, st = sc.render(cam, lights, api.render_params(width=256, height=256, maxdepth=2))
     parity.check_image(img, (st["rays_primary"], st["rays_shadow"], st["rays_secondary"]), sd, 256, 256, 2)
     sc.release()
+
+
+@pytest.mark.parametrize("kind", ["tri_floor", "tri_only", "sphere_floor"])
+def test_random_soup_renders_like_the_oracle(gpu_ctx, kind):
+    """The packet walk on irregular trees (overlapping items, leaves of more than six, mixed entry lists)."""
+    sd = zoo.soup(2500, 5, spheres=kind.startswith("sphere"), floor=kind.endswith("floor"))
+    b, nm, sc = commit(gpu_ctx, sd)
+    cam, lights = product_camera_lights(sd)
+    img, packed, st = sc.render(cam, lights, api.render_params(width=320, height=200, maxdepth=1))
+    parity.check_image(img, (st["rays_primary"], st["rays_shadow"], st["rays_secondary"]), sd, 320, 200, 1)
+    f, _, sf = sc.render(cam, lights, api.render_params(width=320, height=200, maxdepth=1, faithful=1))
+    assert np.array_equal(img, f)  # early-out packets pick the reference traversal's hits, ties included
+    sc.release()

@@ -10,7 +10,8 @@ from helpers import HostSim, product_camera_lights
 from glome_amd import api, scenes
 
 SCENES = dict(zoo.ALL)
-SCENES.update({"S1": lambda: scenes.s1(nlights=2), "S3small": lambda: scenes.s3(24), "S3mesh_small": lambda: scenes.s3(24, as_mesh=True), "S4": scenes.s4})
+SCENES.update({"soup_tri": lambda: zoo.soup(400, 5), "soup_sphere": lambda: zoo.soup(300, 6, spheres=True), "soup_tri_only": lambda: zoo.soup(400, 7, floor=False),
+               "S1": lambda: scenes.s1(nlights=2), "S3small": lambda: scenes.s3(24), "S3mesh_small": lambda: scenes.s3(24, as_mesh=True), "S4": scenes.s4})
 
 
 def load(name):

@@ -158,3 +158,28 @@ def textures():
 
 
 ALL = {"flat_mixed": flat_mixed, "quadrics": quadrics, "csg": csg, "nested": nested, "mesh": mesh_scene, "materials": materials, "textures": textures}
+
+
+def soup(n=2500, seed=5, spheres=False, floor=True):
+    """A random soup (irregular tree: overlapping items, a clump of coincident triangles that ends up in leaves of more
+    than six items) -- `tex (bih items) matte` lit by one shadow-casting light.  Exercises the packet walk on a tree
+    that is nothing like a height field."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    sd = SceneDesc()
+    mat = scenes.matte(sd, (0.7, 0.6, 0.5))
+    items = []
+    if spheres:
+        c = rng.uniform(-6, 6, (n, 3)); c[:, 1] = np.abs(c[:, 1]) * 0.5 + 0.3
+        r = rng.uniform(0.05, 0.5, n)
+        items = [sd.sphere(tuple(c[i]), float(r[i])) for i in range(n)]
+    else:
+        c = rng.uniform(-6, 6, (n, 3)); c[:, 1] = np.abs(c[:, 1]) * 0.5
+        e = rng.normal(0, 0.35, (n, 2, 3))
+        pts = np.concatenate([c, c + e[:, 0], c + e[:, 1]], axis=1)
+        clump = np.tile(pts[:1], (12, 1)) + rng.normal(0, 1e-3, (12, 9))  # twelve nearly coincident triangles
+        items = sd.triangles_bulk(np.concatenate([pts, clump]))
+    body = sd.tex(sd.bih(items), mat)
+    if not floor:  # the all-triangle (or all-sphere) kernel instance
+        return _finish(sd, body)
+    return _finish(sd, sd.group([sd.tex(sd.box((-8, -0.6, -8), (8, -0.1, 8)), scenes.matte(sd, (0.3, 0.5, 0.3))), body]))
