@@ -278,6 +278,19 @@ def test_adaptive_sampler_tile_shards_reassemble_bit_exactly(gpu_ctx):
         assert sc.lib.glome_tiles_blit_dev(gpu_ctx.h, C.byref(plan.P), r, 3, C.c_void_p(payload.data_ptr()), C.c_void_p(frame.data_ptr()), None) == 0
         gpu_ctx.synchronize()  # the context runs on its own stream: finish before torch recycles `payload`
     assert torch.equal(frame, whole)
+    # the packed-pixel product in adaptive mode (what `bench.py --mode 1` gathers at N > 1): whole frame and 3 shards
+    whole_px = torch.zeros((480, 720), dtype=torch.int32, device=dev)
+    sc.render_dev(cam, lights, P, whole.data_ptr(), whole_px.data_ptr())
+    only_px = torch.zeros((480, 720), dtype=torch.int32, device=dev)
+    sc.render_dev(cam, lights, P, None, only_px.data_ptr())
+    plans1 = [dist.ShardPlan(P, r, 3, unit=1) for r in range(3)]
+    gathered = torch.zeros((3, plans1[0].maxp), dtype=torch.int32, device=dev)
+    for r in range(3):
+        assert sc.lib.glome_render_tiles_packed_dev(sc.h, C.byref(cam), la, len(lights), C.byref(plans1[r].P_local), C.c_void_p(gathered[r].data_ptr()), None) == 0
+    frame_px = torch.full((480, 720), -1, dtype=torch.int32, device=dev)
+    assert sc.lib.glome_tiles_blit_all_packed_dev(gpu_ctx.h, C.byref(P), 3, C.c_void_p(gathered.data_ptr()), plans1[0].maxp, C.c_void_p(frame_px.data_ptr())) == 0
+    gpu_ctx.synchronize()
+    assert torch.equal(only_px, whole_px) and torch.equal(frame_px, whole_px)
     sc.release()
 
 
