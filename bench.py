@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--mode", type=int, default=0, help="0 = renderTile (1 ray/pixel), 1 = renderTileSubsample (adaptive)")
     ap.add_argument("--lanes", type=int, default=4, help="launches kept in flight per GPU (HIP streams / context slots)")
     ap.add_argument("--time-every", type=int, default=4, help="HIP-event pair on every k-th launch of the timed region (roofline kernel time)")
-    ap.add_argument("--group", type=int, default=0, help="frames per launch (and per RCCL gather); default 2 on one GPU, 4 on 2-4, 8 on 8")
+    ap.add_argument("--group", type=int, default=0, help="frames per launch (and per RCCL gather); default 4, 8 on 8 GPUs")
     ap.add_argument("--product", default="packed", choices=["packed", "rgbad"],
                     help="what a frame is: GlomeView's framebuffer of packed 0x00RRGGBB pixels (blitTile; 4 B/pixel cross xGMI) "
                          "or the float (r,g,b,a,depth) tuples (20 B/pixel)")
@@ -81,7 +81,7 @@ def main():
     P = api.render_params(width=W, height=H, maxdepth=maxdepth, mode=args.mode)
 
     if args.group <= 0:
-        args.group = 1 if (args.mode != 0 or args.product != "packed") else (2 if world == 1 else (8 if world >= 8 else 4))
+        args.group = 1 if (args.mode != 0 or args.product != "packed") else (8 if world >= 8 else 4)
     sf = dist.ShardedFrame(scene, P, rank, world, device, lanes=args.lanes, product=args.product, group=args.group)
 
     def barrier():
