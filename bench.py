@@ -154,7 +154,8 @@ def main():
     pmc = os.path.join(HERE, "profiles", "pmc_traffic.json")  # written from a separate rocprofv3 --pmc run (profiles/README.md)
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get(args.scene, {}).get("hbm_bytes_per_launch")
+            per_frame = json.load(open(pmc)).get(args.scene, {}).get("hbm_bytes_per_frame")
+            traffic = int(per_frame * sf.G) if per_frame else None  # per launch, like `achieved`
         except Exception:
             traffic = None
     roofline = {

@@ -1,4 +1,4 @@
-"""Minimal workload for rocprofv3 --pmc passes: the launches bench.py times (default: the flagship frame, two frames per
+"""Minimal workload for rocprofv3 --pmc passes: the launches bench.py times (default: the flagship frame, four frames per
 launch, packed framebuffer product), one after the other on one stream (no CPU leg, no torch.distributed)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,7 +10,7 @@ sd = cfg["make"]()
 b = api.Builder(); nm, _ = sd.replay(b); ctx = api.Context(0); sc = ctx.commit(b, nm[sd.root])
 cam = api.camera(*sd.cam); lights = [api.light(p, c, r, s) for (p, c, r, s) in sd.lights]
 P = api.render_params(width=cfg["width"], height=cfg["height"], maxdepth=cfg["maxdepth"])
-G = int(os.environ.get("GROUP", "2"))
+G = int(os.environ.get("GROUP", "4"))
 sf = dist.ShardedFrame(sc, P, 0, 1, torch.device("cuda:0"), lanes=1, product="packed", group=G)
 for i in range(int(os.environ.get("LAUNCHES", "12")) * G):
     sf.step(cam, lights)
