@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--mode", type=int, default=0, help="0 = renderTile (1 ray/pixel), 1 = renderTileSubsample (adaptive)")
     ap.add_argument("--lanes", type=int, default=4, help="launches kept in flight per GPU (HIP streams / context slots)")
-    ap.add_argument("--time-every", type=int, default=4, help="HIP-event pair on every k-th launch of the timed region (roofline kernel time)")
+    ap.add_argument("--time-every", type=int, default=1, help="HIP-event pair on every k-th launch of the timed region (roofline kernel time)")
     ap.add_argument("--group", type=int, default=0, help="frames per launch (and per RCCL gather); default 4, 8 on 8 GPUs")
     ap.add_argument("--product", default="packed", choices=["packed", "rgbad"],
                     help="what a frame is: GlomeView's framebuffer of packed 0x00RRGGBB pixels (blitTile; 4 B/pixel cross xGMI) "
@@ -81,7 +81,9 @@ def main():
     P = api.render_params(width=W, height=H, maxdepth=maxdepth, mode=args.mode)
 
     if args.group <= 0:
-        args.group = 1 if (args.mode != 0 or args.product != "packed") else (8 if world >= 8 else 4)
+        # frames per launch: deep batches pay a fill / drain of about one launch per run, so short runs get shallow ones
+        gmax = 8 if world >= 8 else 4
+        args.group = 1 if (args.mode != 0 or args.product != "packed") else max(1, min(gmax, args.steps // 24))
     sf = dist.ShardedFrame(scene, P, rank, world, device, lanes=args.lanes, product=args.product, group=args.group)
 
     def barrier():
@@ -103,8 +105,7 @@ def main():
         sf.step(cam, lights)
     sf.flush()
     barrier()
-    # every 4th launch carries a HIP-event pair (the event records are packets on the launch stream: timing every launch
-    # costs ~15 % of the frame rate at 0.4 ms per frame)
+    # every --time-every-th launch of the timed region carries a HIP-event pair on its launch stream (default: every launch)
     ctx.lib.glome_ctx_timing_begin_sampled(ctx.h, args.steps, max(1, args.time_every))
     t_start = time.perf_counter()
     for _ in range(args.steps):
