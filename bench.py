@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--mode", type=int, default=0, help="0 = renderTile (1 ray/pixel), 1 = renderTileSubsample (adaptive)")
     ap.add_argument("--lanes", type=int, default=4, help="launches kept in flight per GPU (HIP streams / context slots)")
     ap.add_argument("--time-every", type=int, default=1, help="HIP-event pair on every k-th launch of the timed region (roofline kernel time)")
+    ap.add_argument("--force-dist", action="store_true", help="one GPU, but through the multi-GPU pipeline with a one-rank RCCL group (rehearsal)")
     ap.add_argument("--group", type=int, default=0, help="frames per launch (and per RCCL gather); default 4, 8 on 8 GPUs")
     ap.add_argument("--product", default="packed", choices=["packed", "rgbad"],
                     help="what a frame is: GlomeView's framebuffer of packed 0x00RRGGBB pixels (blitTile; 4 B/pixel cross xGMI) "
@@ -61,9 +62,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible (there is no CPU path to time)")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         import torch.distributed as tdist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.force_dist and world == 1:
+            os.environ.setdefault("MASTER_PORT", "29533"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         tdist.init_process_group("nccl", device_id=device)
 
     cfg = scenes.CONFIGS[args.scene]
@@ -84,17 +88,17 @@ def main():
         # frames per launch: deep batches pay a fill / drain of about one launch per run, so short runs get shallow ones
         gmax = 8 if world >= 8 else 4
         args.group = 1 if (args.mode != 0 or args.product != "packed") else max(1, min(gmax, args.steps // 24))
-    sf = dist.ShardedFrame(scene, P, rank, world, device, lanes=args.lanes, product=args.product, group=args.group)
+    sf = dist.ShardedFrame(scene, P, rank, world, device, lanes=args.lanes, product=args.product, group=args.group, force_pipeline=args.force_dist)
 
     def barrier():
-        if world > 1:
+        if dist_on:
             tdist.barrier()
         torch.cuda.synchronize(device)
 
     # ray count of one frame (identical every step: the scene and camera are fixed)
     st = sf.step(cam, lights, stats=True)
-    rays_local = torch.tensor([st["rays_primary"], st["rays_shadow"], st["rays_secondary"]], dtype=torch.float64, device=device) if world > 1 else None
-    if world > 1:
+    rays_local = torch.tensor([st["rays_primary"], st["rays_shadow"], st["rays_secondary"]], dtype=torch.float64, device=device) if dist_on else None
+    if dist_on:
         tdist.all_reduce(rays_local)
         rays = [int(x) for x in rays_local.tolist()]
     else:
@@ -115,13 +119,13 @@ def main():
     elapsed = time.perf_counter() - t_start
     kms = np.zeros(args.steps, np.float32)
     nk = ctx.lib.glome_ctx_timing_end(ctx.h, kms.ctypes.data_as(L.c_fp), args.steps)
-    if world > 1:
+    if dist_on:
         e = torch.tensor([elapsed], dtype=torch.float64, device=device)
         tdist.all_reduce(e, op=tdist.ReduceOp.MAX)
         elapsed = float(e.item())
 
     if rank != 0:
-        if world > 1:
+        if dist_on:
             tdist.barrier()
             tdist.destroy_process_group()
         return
@@ -220,7 +224,7 @@ def main():
         "roofline": roofline, "cpu_baseline": cpu,
     }
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         tdist.barrier()
         tdist.destroy_process_group()
 

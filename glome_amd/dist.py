@@ -143,7 +143,7 @@ class ShardedFrame:
     blitTile are fused and 4 bytes per pixel cross xGMI.  "rgbad" -- the float (r, g, b, a, depth) tuples ([h, w, 5]),
     20 bytes per pixel (one frame per launch)."""
 
-    def __init__(self, scene, params, rank, world, device, lanes=4, product="rgbad", group=1):
+    def __init__(self, scene, params, rank, world, device, lanes=4, product="rgbad", group=1, force_pipeline=False):
         import torch
         self.torch = torch
         self.scene, self.ctx, self.lib = scene, scene.ctx, scene.lib
@@ -152,6 +152,9 @@ class ShardedFrame:
         self.packed = product == "packed"
         self.plan = ShardPlan(params, rank, world, unit=1 if self.packed else 5)
         self.rank, self.world, self.device = rank, world, device
+        # force_pipeline: run the payload / gather / blit pipeline even with one rank (a one-rank collective) -- a rehearsal of
+        # the multi-GPU path on a single GPU, never the default
+        self.piped = world > 1 or bool(force_pipeline)
         self.P, self.P_local = self.plan.P, self.plan.P_local
         self.h, self.w = params.height, params.width
         self.n = max(1, min(int(lanes), 8))  # the context has 8 launch slots
@@ -164,7 +167,7 @@ class ShardedFrame:
         self.k = 0
         self.batch = []
         self.lights = self.la = None
-        if world > 1:
+        if self.piped:
             payloads = [torch.zeros(self.G * self.plan.maxp, dtype=dt, device=device) for _ in range(self.n)]
             gathereds = [torch.zeros((world, self.G * self.plan.maxp), dtype=dt, device=device) if rank == 0 else None for _ in range(self.n)]
             self.pipe = FramePipeline(self.plan, payloads, gathereds, self._render_group, self._blit, self._lane, group=self.G)
@@ -239,7 +242,7 @@ class ShardedFrame:
             self.torch.cuda.synchronize(self.device)
             st = L.Stats()
             with self._lane(0):
-                if self.world == 1:
+                if not self.piped:
                     fp = self.frames[0].data_ptr()
                     rc = self.lib.glome_render_dev(self.scene.h, C.byref(cam), self.la, len(self.lights), C.byref(self.P), None if self.packed else C.c_void_p(fp),
                                                    C.c_void_p(fp) if self.packed else None, C.byref(st))
@@ -252,7 +255,7 @@ class ShardedFrame:
                         self._blit(0, 0, self.pipe.gathereds[0])
             self.last = (0, 0)
             return api._stats_dict(st)
-        if self.world == 1:
+        if not self.piped:
             self.batch.append(cam)
             if len(self.batch) == self.G:
                 self._launch_local()
@@ -261,7 +264,7 @@ class ShardedFrame:
         return None
 
     def flush(self):
-        if self.world > 1:
+        if self.piped:
             self.pipe.flush()
         elif self.batch:
             self._launch_local()

@@ -1,6 +1,7 @@
 """GPU suite (-m gpu): the HIP path through the C ABI (include/glome_hip.h) against the oracle on seeded inputs, the
 committed golden vectors, and -- at BASELINE.json's full sizes -- size-independent properties."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -225,6 +226,19 @@ def test_sharded_frame_pipeline_rehearsal_on_one_gpu(gpu_ctx):
         assert torch.equal(sf1.frames[lane][g], single(k)), k
     gpu_ctx.lib.glome_ctx_use_slot(gpu_ctx.h, None, 0)
     ranks[1][1].release(); ranks[0][1].release()
+
+
+def test_pipeline_through_a_one_rank_rccl_group(gpu_ctx):
+    """The frame pipeline with the REAL collective: a child process opens a one-rank RCCL group (backend nccl) and runs
+    dist.ShardedFrame's payload -> gather -> blit path through it; every frame equals the direct render."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_one_rank.py"), str(port)], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and "rccl one-rank pipeline ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
 
 def test_full_size_csg_generic_tier_vs_oracle_tile_sample(gpu_ctx):
