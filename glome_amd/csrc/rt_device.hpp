@@ -799,6 +799,7 @@ GPK PacketResult bih_tri_packet(const F4* nodes, const F4* tris, uint32_t ref, u
   int sp = 0;
   LaneMask occm = 0;  // MODE 2: lanes that found an occluder
   uint32_t exp_twait = 0, exp_nstep = 0;  // GLOME_EXP_ASM_TIMING only
+  (void)exp_twait; (void)exp_nstep;
   for (;;) {
     // ---- branch steps: walk down while the reference is a branch
     while (!(ref & BREF_LEAF)) {
