@@ -102,21 +102,24 @@ struct GenericTier {
   __device__ __forceinline__ bool occluded_wave(const Ray& r, float d, bool valid) { return valid && occluded(r, d); }
 };
 
-// LDS carve per wave: three stack columns of cap * 64 words
+// LDS carve per wave: three stack rows of cap * 64 words (reference, near, far -- the per-lane traversal's entries), or
+// two (near, far) in kernels whose lanes never push on their own: the packet walk keeps its references in registers
+template <bool TWO_ROWS = false>
 __device__ __forceinline__ LaneStack lane_stack(uint32_t* lds, int cap, uint32_t* ovf_base, int ovf_cap) {
   int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t* base = lds + (size_t)wave * cap * 64 * 3;
+  uint32_t* base = lds + (size_t)wave * cap * 64 * (TWO_ROWS ? 2 : 3);
   LaneStack s;
-  s.node = base + lane;
-  s.nearv = (float*)(base + cap * 64) + lane;
-  s.farv = (float*)(base + 2 * cap * 64) + lane;
+  s.node = base + lane;  // with two rows this aliases the near row and is never written (no per-lane pushes in that kernel)
+  s.nearv = (float*)(base + (TWO_ROWS ? 0 : cap * 64)) + lane;
+  s.farv = s.nearv + cap * 64;
   s.cap = cap;
+  s.ur = 0; s.ulo = 0; s.uhi = 0;
   // overflow: one [entry*3][64] block per wave slot (blockIdx.x * waves_per_block + wave)
   s.ovf_cap = ovf_base ? ovf_cap : 0;
   s.ovf = ovf_base ? ovf_base + ((size_t)(blockIdx.x * (blockDim.x >> 6) + wave) * ovf_cap * 3) * 64 + lane : nullptr;
   return s;
 }
-static size_t flat_lds_bytes(int cap) { return (size_t)cap * 64 * 12; }
+static size_t flat_lds_bytes(int cap, bool two_rows = false) { return (size_t)cap * 64 * (two_rows ? 8 : 12); }
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned int v) {
   unsigned long long s = v;
@@ -211,10 +214,14 @@ __device__ __forceinline__ void render_loop(const DRenderArgs& A, TIER& T) {
   }
 }
 
-template <bool FAITHFUL, bool COUNT, bool FULL, int CLS, int LB = 1>
+// TWO_ROWS: the wave's LDS holds two stack rows per entry instead of three (lane_stack); legal when no lane ever pushes on
+// its own -- a lean kernel of a triangle / sphere class over a scene whose materials are all Surface, where every ray of
+// the frame goes through the packet walk.  With LB waves per SIMD asked of the register allocator that is 24 waves per
+// CU instead of 16.
+template <bool FAITHFUL, bool COUNT, bool FULL, int CLS, int LB = 1, bool TWO_ROWS = false>
 __global__ void __launch_bounds__(64, LB) k_render_flat(DRenderArgs A, int stack_cap, uint32_t* ovf, int ovf_cap) {
   extern __shared__ uint32_t lds[];
-  FlatTier<FAITHFUL, COUNT, FULL, CLS> T{A.S, A.lights, A.nlights, lane_stack(lds, stack_cap, ovf, ovf_cap), Cnt()};
+  FlatTier<FAITHFUL, COUNT, FULL, CLS> T{A.S, A.lights, A.nlights, lane_stack<TWO_ROWS>(lds, stack_cap, ovf, ovf_cap), Cnt()};
   render_loop(A, T);
   flush_counters(A.counters, T.cnt, 0);
 }
@@ -673,9 +680,9 @@ int glome_scene_get_info(const glome_scene* s, glome_scene_info* out) {
 }
 
 // ---- launch helpers ----
-static int persistent_grid(glome_ctx* ctx, size_t lds_per_block, uint32_t total_work) {
+static int persistent_grid(glome_ctx* ctx, size_t lds_per_block, uint32_t total_work, int max_per_cu = 32) {
   int cus = ctx->prop.multiProcessorCount;
-  int per_cu = 32;  // wave slots per CU
+  int per_cu = max_per_cu;  // wave slots per CU the kernel's register budget allows
   if (lds_per_block) per_cu = std::min<int>(per_cu, (int)(160 * 1024 / lds_per_block));
   per_cu = std::max(per_cu, 1);
   long g = (long)cus * per_cu;
@@ -711,6 +718,18 @@ static int reset_counters(glome_ctx* ctx) {
   return 0;
 }
 
+static int scene_class(const glome_scene* s) {  // scene class -> the smallest kernel instance that covers it (SPECIALIZE analogue, Bih.hs:370-374)
+  int m = s->cls_mask;
+  return (m & ~CLS_BIH_TRI) == 0 ? CLS_BIH_TRI : ((m & ~(CLS_BIH_SPHERE | CLS_PRIMS)) == 0 ? (CLS_BIH_SPHERE | CLS_PRIMS) : ((m & ~CLS_MESH) == 0 ? CLS_MESH : CLS_ALL));
+}
+// every ray of the frame is walked as a packet (see k_render_flat): two stack rows per entry, six waves per SIMD
+static bool use_two_rows(const glome_scene* s, const glome_render_params* P) {
+  if (s->dev.tier != 0 || P->faithful || P->count_work || P->mode != GLOME_MODE_TILE) return false;
+  if (s->has_secondary_mats || s->has_nested_mats || s->stack_cap != kAsmLdsCap || getenv("GLOME_DEBUG_LB")) return false;
+  int cls = scene_class(s);
+  return cls == CLS_BIH_TRI || cls == (CLS_BIH_SPHERE | CLS_PRIMS);
+}
+
 static void launch_render(glome_scene* s, const DRenderArgs& A, const glome_render_params* P, int grid, size_t lds) {
   hipStream_t st = s->ctx->stream;
   bool faithful = P->faithful != 0, count = P->count_work != 0 || faithful;
@@ -718,9 +737,7 @@ static void launch_render(glome_scene* s, const DRenderArgs& A, const glome_rend
     // lean kernel: legal when no secondary trace can do work and no material nests (Blend / AdditiveLayers)
     bool full = s->has_nested_mats || (s->has_secondary_mats && P->maxdepth > 1);
     dim3 g(grid), blk(64);
-    // scene class -> the smallest kernel instance that covers it (SPECIALIZE analogue, Bih.hs:370-374)
-    int m = s->cls_mask;
-    int cls = (m & ~CLS_BIH_TRI) == 0 ? CLS_BIH_TRI : ((m & ~(CLS_BIH_SPHERE | CLS_PRIMS)) == 0 ? (CLS_BIH_SPHERE | CLS_PRIMS) : ((m & ~CLS_MESH) == 0 ? CLS_MESH : CLS_ALL));
+    int cls = scene_class(s);
     int lb = getenv("GLOME_DEBUG_LB") ? atoi(getenv("GLOME_DEBUG_LB")) : 0;
 #define GLOME_LAUNCH(F, C, U, K, B) hipLaunchKernelGGL((k_render_flat<F, C, U, K, B>), g, blk, lds, st, A, s->stack_cap, s->ovf_cap ? s->ctx->slot().d_ovf : nullptr, s->ovf_cap)
 #define GLOME_BY_CLS(F, C, U)                                                   \
@@ -730,12 +747,19 @@ static void launch_render(glome_scene* s, const DRenderArgs& A, const glome_rend
       else if (cls == CLS_MESH) GLOME_LAUNCH(F, C, U, CLS_MESH, 1);               \
       else GLOME_LAUNCH(F, C, U, CLS_ALL, 1);                                     \
     } while (0)
+    if (use_two_rows(s, P)) {
+      size_t lds2 = lds;  // sized by the caller for two rows
+      uint32_t* ov = s->ovf_cap ? s->ctx->slot().d_ovf : nullptr;
+      if (cls == CLS_BIH_TRI) hipLaunchKernelGGL((k_render_flat<false, false, false, CLS_BIH_TRI, 6, true>), g, blk, lds2, st, A, s->stack_cap, ov, s->ovf_cap);
+      else hipLaunchKernelGGL((k_render_flat<false, false, false, (CLS_BIH_SPHERE | CLS_PRIMS), 6, true>), g, blk, lds2, st, A, s->stack_cap, ov, s->ovf_cap);
+    } else
     if (faithful) { if (full) GLOME_LAUNCH(true, true, true, CLS_ALL, 1); else GLOME_LAUNCH(true, true, false, CLS_ALL, 1); }
     else if (count) { if (full) GLOME_LAUNCH(false, true, true, CLS_ALL, 1); else GLOME_LAUNCH(false, true, false, CLS_ALL, 1); }
     else if (full) GLOME_BY_CLS(false, false, true);
     else if (cls == CLS_BIH_TRI && lb == 2) GLOME_LAUNCH(false, false, false, CLS_BIH_TRI, 2);
     else if (cls == CLS_BIH_TRI && lb == 3) GLOME_LAUNCH(false, false, false, CLS_BIH_TRI, 3);
     else if (cls == CLS_BIH_TRI && lb == 4) GLOME_LAUNCH(false, false, false, CLS_BIH_TRI, 4);
+    else if (cls == CLS_BIH_TRI && lb == 5) GLOME_LAUNCH(false, false, false, CLS_BIH_TRI, 5);
     else if (cls == CLS_BIH_TRI && lb == 6) GLOME_LAUNCH(false, false, false, CLS_BIH_TRI, 6);
     else if (cls == CLS_BIH_TRI && lb == 8) GLOME_LAUNCH(false, false, false, CLS_BIH_TRI, 8);
     else GLOME_BY_CLS(false, false, false);
@@ -815,8 +839,9 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
   } else if (A.ntiles > 0) {
-    size_t lds = s->dev.tier == 0 ? flat_lds_bytes(s->stack_cap) : 0;
-    int grid = persistent_grid(ctx, lds, A.total_waves * (uint32_t)nframes);
+    const bool two_rows = use_two_rows(s, P);
+    size_t lds = s->dev.tier == 0 ? flat_lds_bytes(s->stack_cap, two_rows) : 0;
+    int grid = persistent_grid(ctx, lds, A.total_waves * (uint32_t)nframes, two_rows ? 24 : 32);
     if (s->dev.tier == 0 && s->ovf_cap && (rc = ensure_overflow(ctx, grid, 1, s->ovf_cap))) return rc;
     bool pooled = ctx->timing && (ctx->timing_seen++ % ctx->timing_stride) == 0 && ctx->pool_used + 2 <= (int)ctx->pool.size();
     hipEvent_t e0 = pooled ? ctx->pool[ctx->pool_used] : ctx->ev0, e1 = pooled ? ctx->pool[ctx->pool_used + 1] : ctx->ev1;

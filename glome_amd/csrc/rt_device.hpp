@@ -424,21 +424,35 @@ struct LaneStack {
   static constexpr int STRIDE = 1;
 #endif
   GD int total_cap() const { return cap + ovf_cap; }
-  // Packet entries (bih_tri_wave): the node reference and the mask of lanes that want the entry are wave-uniform; they
-  // ride in the `node` row -- lane 0's word is the reference, lanes 1 and 2 hold the mask -- next to every lane's own
-  // (near, far).  On the host a wave is one lane and the mask is one bit, kept in bit 31 of the reference.
+  // Packet entries (bih_tri_wave): the node reference and the mask of lanes that want the entry are wave-uniform.  On the
+  // device they live in three vector registers, entry k in lane k of each (a 64-entry scalar stack that costs no LDS:
+  // v_writelane / v_readlane with the stack pointer as the lane); only every lane's own (near, far) goes to the LDS rows.
+  // A kernel whose lanes never push on their own therefore needs two LDS rows per entry instead of three, which is what
+  // bounds its waves per CU.  On the host a wave is one lane and the mask is one bit, kept in bit 31 of the reference.
 #if defined(__HIPCC__)
+  uint32_t ur, ulo, uhi;
+  GD void push2(int sp, float a, float b) {
+    if (__builtin_expect(sp < cap, 1)) { nearv[sp * STRIDE] = a; farv[sp * STRIDE] = b; }
+    else { uint32_t* o = ovf + (size_t)(sp - cap) * 3 * STRIDE; __builtin_nontemporal_store(as_u(a), o + STRIDE); __builtin_nontemporal_store(as_u(b), o + 2 * STRIDE); }
+  }
+  GD void pop2(int sp, float& a, float& b) const {
+    if (__builtin_expect(sp < cap, 1)) { a = nearv[sp * STRIDE]; b = farv[sp * STRIDE]; }
+    else {
+      const uint32_t* o = ovf + (size_t)(sp - cap) * 3 * STRIDE;
+      a = as_f(__builtin_nontemporal_load(o + STRIDE)); b = as_f(__builtin_nontemporal_load(o + 2 * STRIDE));
+      asm volatile("" : "+v"(a), "+v"(b));
+    }
+  }
   GD void push_wave(int sp, uint32_t ref, LaneMask m, float a, float b) {
-    uint32_t w = ref;
-    asm("v_writelane_b32 %0, %1, 1" : "+v"(w) : "s"((uint32_t)m));
-    asm("v_writelane_b32 %0, %1, 2" : "+v"(w) : "s"((uint32_t)(m >> 32)));
-    push(sp, w, a, b);
+    uint32_t keep;  // m0 is saved and restored: the compiler does not track it through an asm statement
+    asm("s_mov_b32 %3, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tv_writelane_b32 %0, %5, m0\n\tv_writelane_b32 %1, %6, m0\n\tv_writelane_b32 %2, %7, m0\n\ts_mov_b32 m0, %3"
+        : "+v"(ur), "+v"(ulo), "+v"(uhi), "=&s"(keep) : "s"(sp), "s"(ref), "s"((uint32_t)m), "s"((uint32_t)(m >> 32)));
+    push2(sp, a, b);
   }
   GD void pop_wave(int sp, uint32_t& ref, LaneMask& m, float& a, float& b) const {
-    uint32_t w;
-    pop(sp, w, a, b);
-    ref = (uint32_t)__builtin_amdgcn_readlane((int)w, 0);
-    m = (LaneMask)(uint32_t)__builtin_amdgcn_readlane((int)w, 1) | ((LaneMask)(uint32_t)__builtin_amdgcn_readlane((int)w, 2) << 32);
+    pop2(sp, a, b);
+    ref = (uint32_t)__builtin_amdgcn_readlane((int)ur, sp);
+    m = (LaneMask)(uint32_t)__builtin_amdgcn_readlane((int)ulo, sp) | ((LaneMask)(uint32_t)__builtin_amdgcn_readlane((int)uhi, sp) << 32);
   }
 #else
   GD void push_wave(int sp, uint32_t ref, LaneMask m, float a, float b) { push(sp, ref | ((uint32_t)(m & 1ull) << 31), a, b); }
@@ -666,14 +680,14 @@ GD bool bih_tri(const DScene& S, uint32_t hdr, const Ray& r, float d, STK& stk, 
 // compile, the counting variants and every case this routine declines go through it).
 //   walks down from `ref` while it is a branch; returns 0 when it stands on a leaf (am != 0) or nothing is left
 //   (am == 0); returns 1 -- with the state untouched at that node -- when a push would not fit the LDS part of the stack.
-// Registers s[60:69] and vcc are scratch (named in the clobber list); the LDS rows are `cap_lds` entries apart.
+// Registers s[60:69] and vcc are scratch (m0 is used and restored) (named in the clobber list); the far row is `cap_lds` entries after the near row.
 #if defined(__HIPCC__)
 constexpr int kAsmLdsCap = 12;  // the LDS part of the stack the row offsets below are written for
 GD int bih_descend_asm(const F4* nodes, uint32_t& ref, LaneMask& am, int& sp, float& nearv, float& farv, uint32_t fwdbits, int cap_lds,
-                       V3 o, V3 rcp, uint32_t lds_row, uint32_t& g_asm_twait, uint32_t& g_asm_nstep) {
+                       V3 o, V3 rcp, uint32_t lds_row, uint32_t& g_asm_twait, uint32_t& g_asm_nstep, uint32_t& ur, uint32_t& ulo, uint32_t& uhi) {
   int status;
   float dl, dr, tv;
-  uint32_t wv, av;
+  uint32_t av;
   asm volatile(
       "L_node_%=:\n"
       "  s_bitcmp1_b32 %[ref], 29\n"
@@ -736,14 +750,16 @@ GD int bih_descend_asm(const F4* nodes, uint32_t& ref, LaneMask& am, int& sp, fl
       "  s_cmp_ge_i32 %[sp], %[cap]\n"
       "  s_cbranch_scc1 L_slow_%=\n"
       "  v_max_f32 %[tv], %[dr], %[near]\n"
-      "  v_mov_b32 %[wv], s63\n"
+      "  s_mov_b32 s69, m0\n"            // (m0 is restored below: the compiler does not track it through asm)
+      "  s_mov_b32 m0, %[sp]\n"          // the uniform part of the entry: lane `sp` of ur / ulo / uhi
       "  s_lshl_b32 s68, %[sp], 8\n"
-      "  v_writelane_b32 %[wv], s66, 1\n"
-      "  v_writelane_b32 %[wv], s67, 2\n"
       "  v_add_u32 %[av], s68, %[lds]\n"
-      "  ds_write_b32 %[av], %[wv]\n"
-      "  ds_write_b32 %[av], %[tv] offset:%[row1]\n"
-      "  ds_write_b32 %[av], %[far] offset:%[row2]\n"
+      "  v_writelane_b32 %[ur], s63, m0\n"
+      "  v_writelane_b32 %[ulo], s66, m0\n"
+      "  v_writelane_b32 %[uhi], s67, m0\n"
+      "  s_mov_b32 m0, s69\n"
+      "  ds_write_b32 %[av], %[tv]\n"    // this lane's (near, far) of the far child
+      "  ds_write_b32 %[av], %[far] offset:%[row1]\n"
       "  s_add_i32 %[sp], %[sp], 1\n"
       "L_nopush_%=:\n"
       "  v_min_f32 %[far], %[dl], %[far]\n"
@@ -766,12 +782,12 @@ GD int bih_descend_asm(const F4* nodes, uint32_t& ref, LaneMask& am, int& sp, fl
       "  s_mov_b32 %[status], 1\n"
       "L_end_%=:\n"
       : [ref] "+s"(ref), [am] "+s"(am), [sp] "+s"(sp), [near] "+v"(nearv), [far] "+v"(farv), [status] "=s"(status),
-        [dl] "=&v"(dl), [dr] "=&v"(dr), [tv] "=&v"(tv), [wv] "=&v"(wv), [av] "=&v"(av)
+        [dl] "=&v"(dl), [dr] "=&v"(dr), [tv] "=&v"(tv), [av] "=&v"(av), [ur] "+v"(ur), [ulo] "+v"(ulo), [uhi] "+v"(uhi)
 #if defined(GLOME_EXP_ASM_TIMING)
         , [twait] "+s"(g_asm_twait), [nstep] "+s"(g_asm_nstep)
 #endif
       : [fwd] "s"(fwdbits), [nodes] "s"(nodes), [cap] "s"(cap_lds), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [rx] "v"(rcp.x), [ry] "v"(rcp.y),
-        [rz] "v"(rcp.z), [lds] "v"(lds_row), [row1] "n"(kAsmLdsCap * 256), [row2] "n"(2 * kAsmLdsCap * 256)
+        [rz] "v"(rcp.z), [lds] "v"(lds_row), [row1] "n"(kAsmLdsCap * 256)
       : "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69",
 #if defined(GLOME_EXP_ASM_TIMING)
         "s70", "s71", "s72", "s73",
@@ -807,7 +823,8 @@ GPK PacketResult bih_tri_packet(const F4* nodes, const F4* tris, uint32_t ref, u
 #if defined(__HIPCC__) && !defined(GLOME_EXP_NO_ASM)
       if constexpr (!COUNT && std::is_same<STK, LaneStack>::value) {
         if (stk.cap == kAsmLdsCap) {  // the hand-scheduled branch steps; returns 1 where a push has to go to the overflow columns
-          if (bih_descend_asm(nodes, ref, am, sp, nearv, farv, fwdbits, stk.cap, r.o, rcp, (uint32_t)(uintptr_t)stk.node, exp_twait, exp_nstep) == 0) break;
+          if (bih_descend_asm(nodes, ref, am, sp, nearv, farv, fwdbits, stk.cap, r.o, rcp, (uint32_t)(uintptr_t)stk.nearv, exp_twait, exp_nstep, stk.ur, stk.ulo,
+                              stk.uhi) == 0) break;
         }
       }
 #endif
