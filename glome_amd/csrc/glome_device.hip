@@ -331,10 +331,10 @@ __device__ __forceinline__ void ss_pass_loop(const DRenderArgs& A, TIER& T, int 
     __syncthreads();  // the list is reused by the next region
   }
 }
-template <bool FULL, int CLS>
-__global__ void __launch_bounds__(64) k_ss_pass_flat(DRenderArgs A, int pass, int stack_cap, uint32_t* ovf, int ovf_cap) {
+template <bool FULL, int CLS, int LB = 1, bool TWO_ROWS = false>
+__global__ void __launch_bounds__(64, LB) k_ss_pass_flat(DRenderArgs A, int pass, int stack_cap, uint32_t* ovf, int ovf_cap) {
   extern __shared__ uint32_t lds[];
-  FlatTier<false, false, FULL, CLS> T{A.S, A.lights, A.nlights, lane_stack(lds, stack_cap, ovf, ovf_cap), Cnt()};
+  FlatTier<false, false, FULL, CLS> T{A.S, A.lights, A.nlights, lane_stack<TWO_ROWS>(lds, stack_cap, ovf, ovf_cap), Cnt()};
   ss_pass_loop(A, T, pass);
   flush_counters(A.counters, T.cnt, 0);
 }
@@ -724,7 +724,7 @@ static int scene_class(const glome_scene* s) {  // scene class -> the smallest k
 }
 // every ray of the frame is walked as a packet (see k_render_flat): two stack rows per entry, six waves per SIMD
 static bool use_two_rows(const glome_scene* s, const glome_render_params* P) {
-  if (s->dev.tier != 0 || P->faithful || P->count_work || P->mode != GLOME_MODE_TILE) return false;
+  if (s->dev.tier != 0 || P->faithful || P->count_work) return false;
   if (s->has_secondary_mats || s->has_nested_mats || s->stack_cap != kAsmLdsCap || getenv("GLOME_DEBUG_LB")) return false;
   int cls = scene_class(s);
   return cls == CLS_BIH_TRI || cls == (CLS_BIH_SPHERE | CLS_PRIMS);
@@ -819,18 +819,20 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
     if (pooled) ctx->pool_used += 2;
     ev_start = e0; ev_stop = e1;
     HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
-    size_t lds = s->dev.tier == 0 ? flat_lds_bytes(s->stack_cap) : 0;
+    const bool two_rows = use_two_rows(s, P) && scene_class(s) == CLS_BIH_TRI;  // (the sample passes have a triangle-class instance only)
+    size_t lds = s->dev.tier == 0 ? flat_lds_bytes(s->stack_cap, two_rows) : 0;
     bool full = s->has_nested_mats || (s->has_secondary_mats && P->maxdepth > 1);
     bool tri = s->dev.tier == 0 && (s->cls_mask & ~CLS_BIH_TRI) == 0;
     uint32_t* ov = s->ovf_cap ? ctx->slot().d_ovf : nullptr;
     for (int pass = 1; pass <= 5; pass++) {
       int nbx;
       uint32_t items = (uint32_t)ss_regions_per_tile(pass, P->blocksize, nbx) * (uint32_t)A.ntiles;
-      int tgrid = persistent_grid(ctx, lds, items);
+      int tgrid = persistent_grid(ctx, lds, items, two_rows ? 24 : 32);
       if (s->dev.tier == 0 && s->ovf_cap && (rc = ensure_overflow(ctx, tgrid, 1, s->ovf_cap))) return rc;
       ov = s->ovf_cap ? ctx->slot().d_ovf : nullptr;
       dim3 g(tgrid), blk(64);
       if (s->dev.tier != 0) hipLaunchKernelGGL(k_ss_pass_generic, g, blk, 0, ctx->stream, A, pass);
+      else if (two_rows) hipLaunchKernelGGL((k_ss_pass_flat<false, CLS_BIH_TRI, 6, true>), g, blk, lds, ctx->stream, A, pass, s->stack_cap, ov, s->ovf_cap);
       else if (tri && !full) hipLaunchKernelGGL((k_ss_pass_flat<false, CLS_BIH_TRI>), g, blk, lds, ctx->stream, A, pass, s->stack_cap, ov, s->ovf_cap);
       else if (tri) hipLaunchKernelGGL((k_ss_pass_flat<true, CLS_BIH_TRI>), g, blk, lds, ctx->stream, A, pass, s->stack_cap, ov, s->ovf_cap);
       else if (!full) hipLaunchKernelGGL((k_ss_pass_flat<false, CLS_ALL>), g, blk, lds, ctx->stream, A, pass, s->stack_cap, ov, s->ovf_cap);
