@@ -725,6 +725,9 @@ static int scene_class(const glome_scene* s) {  // scene class -> the smallest k
 // every ray of the frame is walked as a packet (see k_render_flat): two stack rows per entry, six waves per SIMD
 static bool use_two_rows(const glome_scene* s, const glome_render_params* P) {
   if (s->dev.tier != 0 || P->faithful || P->count_work) return false;
+  // a rank's shard of a frame shares the GPU with the collective's and the blit's kernels: the 16-wave instance leaves them
+  // room (measured: rank-side frame period 0.047 ms against 0.072 ms at 8 ranks), the 24-wave one is for whole frames
+  if (P->tile_stride != 1) return false;
   if (s->has_secondary_mats || s->has_nested_mats || s->stack_cap != kAsmLdsCap || getenv("GLOME_DEBUG_LB")) return false;
   int cls = scene_class(s);
   return cls == CLS_BIH_TRI || cls == (CLS_BIH_SPHERE | CLS_PRIMS);
