@@ -119,6 +119,7 @@ SYMBOLS = [
     ("glome_tiles_blit_all_dev", C.c_int, [vp, C.POINTER(RenderParams), C.c_int, vp, C.c_int64, vp, vp]),
     ("glome_render_tiles_packed_dev", C.c_int, [vp, C.POINTER(Camera), C.POINTER(Light), C.c_int, C.POINTER(RenderParams), vp, C.POINTER(Stats)]),
     ("glome_tiles_blit_all_packed_dev", C.c_int, [vp, C.POINTER(RenderParams), C.c_int, vp, C.c_int64, vp]),
+    ("glome_tiles_blit_all_packed_batch_dev", C.c_int, [vp, C.POINTER(RenderParams), C.c_int, vp, C.c_int64, C.c_int, C.c_int64, vp, C.c_int64]),
     ("glome_render_tiles_packed_batch_dev", C.c_int, [vp, C.POINTER(Camera), C.c_int, C.POINTER(Light), C.c_int, C.POINTER(RenderParams), vp, C.c_int64, C.POINTER(Stats)]),
     ("glome_render_packed_batch_dev", C.c_int, [vp, C.POINTER(Camera), C.c_int, C.POINTER(Light), C.c_int, C.POINTER(RenderParams), vp, C.c_int64, C.POINTER(Stats)]),
 ]

@@ -424,7 +424,11 @@ __global__ void k_tiles_blit(const DTile* tiles, int ntiles, int width, const fl
     }
   }
 }
-__global__ void k_tiles_blit_packed(const DTile* tiles, int ntiles, int width, const uint32_t* payload, uint32_t* packed) {
+// blockIdx.z = frame of a group: frame f's payload sits f * payload_frame_stride words into every rank's slab, its
+// framebuffer f * out_frame_stride words after the first
+__global__ void k_tiles_blit_packed(const DTile* tiles, int ntiles, int width, const uint32_t* payload, uint32_t* packed, size_t payload_frame_stride, size_t out_frame_stride) {
+  payload += (size_t)blockIdx.z * payload_frame_stride;
+  packed += (size_t)blockIdx.z * out_frame_stride;
   for (int t = blockIdx.y; t < ntiles; t += gridDim.y) {
     DTile T = tiles[t];
     int np = T.w * T.h;
@@ -1106,15 +1110,22 @@ int glome_tiles_blit_all_dev(glome_ctx* ctx, const glome_render_params* P, int w
 }
 int glome_tiles_blit_all_packed_dev(glome_ctx* ctx, const glome_render_params* P, int world, const uint32_t* gathered_dev, int64_t stride_pixels,
                                     uint32_t* packed_dev) {
+  return glome_tiles_blit_all_packed_batch_dev(ctx, P, world, gathered_dev, stride_pixels, 1, 0, packed_dev, 0);
+}
+int glome_tiles_blit_all_packed_batch_dev(glome_ctx* ctx, const glome_render_params* P, int world, const uint32_t* gathered_dev, int64_t stride_pixels,
+                                          int nframes, int64_t payload_frame_stride, uint32_t* packed_dev, int64_t out_frame_stride) {
   if (!ctx) return GLOME_E_INVALID;
   int rc = check_params(ctx, P);
   if (rc) return rc;
-  if (world <= 0 || stride_pixels < 0 || !gathered_dev || !packed_dev) { ctx->err = "bad world / stride / buffer"; return GLOME_E_INVALID; }
+  if (world <= 0 || stride_pixels < 0 || !gathered_dev || !packed_dev || nframes < 1 || nframes > kMaxBatchFrames || payload_frame_stride < 0 || out_frame_stride < 0) {
+    ctx->err = "bad world / stride / buffer / frame count"; return GLOME_E_INVALID;
+  }
   HIPCHK(ctx, hipSetDevice(ctx->device));
   glome_ctx::TileTable* tt;
   if ((rc = gathered_table(ctx, P, world, stride_pixels, &tt))) return rc;
   if (tt->host.empty()) return 0;
-  hipLaunchKernelGGL(k_tiles_blit_packed, dim3(17, std::min<int>((int)tt->host.size(), 1024)), dim3(256), 0, ctx->stream, tt->dev, (int)tt->host.size(), P->width, gathered_dev, packed_dev);
+  hipLaunchKernelGGL(k_tiles_blit_packed, dim3(17, std::min<int>((int)tt->host.size(), 1024), nframes), dim3(256), 0, ctx->stream, tt->dev, (int)tt->host.size(), P->width, gathered_dev,
+                     packed_dev, (size_t)payload_frame_stride, (size_t)out_frame_stride);
   HIPCHK(ctx, hipGetLastError());
   return 0;
 }

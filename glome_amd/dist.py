@@ -91,9 +91,10 @@ class FramePipeline:
     lane(slot) (a context manager) are callables, so the same control flow is exercised on CPU tensors with gloo
     (tests/test_dist_gloo.py)."""
 
-    def __init__(self, plan, payloads, gathereds, render_group, blit, lane=None, group=1):
+    def __init__(self, plan, payloads, gathereds, render_group, blit, lane=None, group=1, blit_group=None):
         import contextlib
         self.plan, self.payloads, self.gathereds, self.render_group, self.blit = plan, payloads, gathereds, render_group, blit
+        self.blit_group = blit_group  # optional: blit(slot, nrows, gathered) for a whole group at once instead of row by row
         self.lane = lane if lane is not None else (lambda slot: contextlib.nullcontext())
         self.G = int(group)
         self.n = len(payloads)  # lanes = groups in flight
@@ -123,8 +124,11 @@ class FramePipeline:
         with self.lane(slot):
             work.wait()  # RCCL: this lane's stream waits for the collective; gloo: the host does
             if self.plan.rank == 0:
-                for g in range(nrows):
-                    self.blit(slot, g, self.gathereds[slot])
+                if self.blit_group is not None:
+                    self.blit_group(slot, nrows, self.gathereds[slot])
+                else:
+                    for g in range(nrows):
+                        self.blit(slot, g, self.gathereds[slot])
         self.done += nrows
 
     def flush(self):
@@ -170,7 +174,8 @@ class ShardedFrame:
         if self.piped:
             payloads = [torch.zeros(self.G * self.plan.maxp, dtype=dt, device=device) for _ in range(self.n)]
             gathereds = [torch.zeros((world, self.G * self.plan.maxp), dtype=dt, device=device) if rank == 0 else None for _ in range(self.n)]
-            self.pipe = FramePipeline(self.plan, payloads, gathereds, self._render_group, self._blit, self._lane, group=self.G)
+            self.pipe = FramePipeline(self.plan, payloads, gathereds, self._render_group, self._blit, self._lane, group=self.G,
+                                      blit_group=self._blit_group if self.packed else None)
         torch.cuda.synchronize(device)
 
     @property
@@ -210,6 +215,14 @@ class ShardedFrame:
         if rc != 0:
             raise api.GlomeError("blit: " + self.ctx.err())
         self.last = (slot, g)
+
+    def _blit_group(self, slot, nrows, gathered):
+        # one launch for the group's frames: frame g is g * maxp words into every rank's slab and lands in frames[slot][g]
+        rc = self.lib.glome_tiles_blit_all_packed_batch_dev(self.ctx.h, C.byref(self.P), self.world, C.c_void_p(gathered.data_ptr()), self.G * self.plan.maxp,
+                                                            nrows, self.plan.maxp, C.c_void_p(self.frames[slot].data_ptr()), self.h * self.w)
+        if rc != 0:
+            raise api.GlomeError("blit: " + self.ctx.err())
+        self.last = (slot, nrows - 1)
 
     def set_lights(self, lights):
         self.lights = lights

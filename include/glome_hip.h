@@ -236,6 +236,10 @@ int glome_tiles_blit_all_dev(glome_ctx*, const glome_render_params*, int world, 
  * payloads); one launch writes every rank's tiles into the packed framebuffer (width*height words). */
 int glome_tiles_blit_all_packed_dev(glome_ctx*, const glome_render_params*, int world, const uint32_t* gathered_dev, int64_t stride_pixels,
                                     uint32_t* packed_dev);
+/* The same for the nframes frames of a batch in one launch: frame f's payload starts f * payload_frame_stride words into
+ * every rank's slab, its framebuffer f * out_frame_stride words after packed_dev. */
+int glome_tiles_blit_all_packed_batch_dev(glome_ctx*, const glome_render_params*, int world, const uint32_t* gathered_dev, int64_t stride_pixels,
+                                          int nframes, int64_t payload_frame_stride, uint32_t* packed_dev, int64_t out_frame_stride);
 
 #ifdef __cplusplus
 }
