@@ -2,13 +2,16 @@
 // context, scene commit/upload, the per-ray batch seams and the whole-frame render.
 //
 // Kernel catalogue
-//   k_render_flat<MAXD,FAITHFUL,COUNT>  persistent: one wave pulls 64-pixel work items (8x8 blocks of a 65x65
-//                                       reference tile, Glome.hs:371-386) from an atomic queue; per lane:
-//                                       primary ray -> BIH/Mesh closest hit (LDS stack) -> shadow rays ->
-//                                       shade -> secondary rays.  No ray streams in HBM at all.
-//   k_render_generic<MAXD,COUNT>        same loop over the generic interpreter (rt_generic.hpp)
+//   k_render_flat<FAITHFUL,COUNT,FULL,CLS,LB,TWO_ROWS>
+//                                       persistent: one wave pulls 64-pixel work items (8x8 blocks of a 65x65
+//                                       reference tile, Glome.hs:371-386; up to 8 frames per launch) from a ticket
+//                                       queue; the wave walks a triangle / sphere BIH once for its 64 rays (packet:
+//                                       rt_device.hpp bih_tri_wave) -> shadow rays -> shade -> secondary rays (per lane).
+//                                       No ray streams in HBM at all.
+//   k_render_generic                    same loop over the generic interpreter (rt_generic.hpp)
+//   k_ss_pass_flat / k_ss_pass_generic  one pass of the adaptive sampler (renderTileSubsample, Glome.hs:226-323)
 //   k_rayint_batch / k_shadow_batch / k_inside_batch   the `Solid` method seams on SoA ray streams
-//   k_tiles_pack / k_tiles_blit         Tile payload <-> frame (blitTile, Glome.hs:353-358)
+//   k_tiles_pack / k_tiles_blit / k_tiles_blit_packed  Tile payload <-> frame (blitTile, Glome.hs:353-358)
 #include <hip/hip_runtime.h>
 
 #include <cstdio>

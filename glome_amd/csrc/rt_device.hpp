@@ -4,8 +4,11 @@
 // of the reference are kept, because they decide NaN / +-0 behaviour (Q1, Q2).
 //
 // Two tiers share the primitive and shading code:
-//   flat tier    -- root = list of simple primitives / homogeneous BIHs / meshes.  Fully inlined,
-//                   traversal stack in LDS (one column per lane, conflict-free), deferred normals.
+//   flat tier    -- root = list of simple primitives / homogeneous BIHs / meshes.  Fully inlined, deferred
+//                   normals.  A wave walks a triangle / sphere BIH once for its 64 rays (bih_tri_wave:
+//                   wave-uniform node reference, scalar loads, per-lane intervals; the branch steps are
+//                   hand-scheduled, bih_descend_asm); everything else traverses per lane with its stack in
+//                   LDS (one column per lane, conflict-free).
 //   generic tier -- arbitrary nesting (Instance, CSG, Bound, nested BIH): an interpreter whose
 //                   recursion is unrolled at compile time (rayint_g<D> calls rayint_g<D-1>), so
 //                   the call graph is static and the stacks are fixed-size scratch.
