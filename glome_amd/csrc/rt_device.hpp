@@ -685,7 +685,8 @@ GD bool bih_tri(const DScene& S, uint32_t hdr, const Ray& r, float d, STK& stk, 
 //   (am == 0); returns 1 -- with the state untouched at that node -- when a push would not fit the LDS part of the stack.
 // Registers s[60:69] and vcc are scratch (m0 is used and restored) (named in the clobber list); the far row is `cap_lds` entries after the near row.
 #if defined(__HIPCC__)
-constexpr int kAsmLdsCap = 12;  // the LDS part of the stack the row offsets below are written for
+constexpr int kAsmLdsCap = 12;  // the default LDS part of the stack; the routine is instantiated for the caps the launches use
+template <int CAP>
 GD int bih_descend_asm(const F4* nodes, uint32_t& ref, LaneMask& am, int& sp, float& nearv, float& farv, uint32_t fwdbits, int cap_lds,
                        V3 o, V3 rcp, uint32_t lds_row, uint32_t& g_asm_twait, uint32_t& g_asm_nstep, uint32_t& ur, uint32_t& ulo, uint32_t& uhi) {
   int status;
@@ -790,7 +791,7 @@ GD int bih_descend_asm(const F4* nodes, uint32_t& ref, LaneMask& am, int& sp, fl
         , [twait] "+s"(g_asm_twait), [nstep] "+s"(g_asm_nstep)
 #endif
       : [fwd] "s"(fwdbits), [nodes] "s"(nodes), [cap] "s"(cap_lds), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [rx] "v"(rcp.x), [ry] "v"(rcp.y),
-        [rz] "v"(rcp.z), [lds] "v"(lds_row), [row1] "n"(kAsmLdsCap * 256)
+        [rz] "v"(rcp.z), [lds] "v"(lds_row), [row1] "n"(CAP * 256)
       : "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69",
 #if defined(GLOME_EXP_ASM_TIMING)
         "s70", "s71", "s72", "s73",
@@ -825,9 +826,13 @@ GPK PacketResult bih_tri_packet(const F4* nodes, const F4* tris, uint32_t ref, u
       ref = uni(ref); am = uni(am); sp = (int)uni((uint32_t)sp);  // wave-uniform by construction: keep them in SGPRs
 #if defined(__HIPCC__) && !defined(GLOME_EXP_NO_ASM)
       if constexpr (!COUNT && std::is_same<STK, LaneStack>::value) {
-        if (stk.cap == kAsmLdsCap) {  // the hand-scheduled branch steps; returns 1 where a push has to go to the overflow columns
-          if (bih_descend_asm(nodes, ref, am, sp, nearv, farv, fwdbits, stk.cap, r.o, rcp, (uint32_t)(uintptr_t)stk.nearv, exp_twait, exp_nstep, stk.ur, stk.ulo,
-                              stk.uhi) == 0) break;
+        // the hand-scheduled branch steps; they return 1 where a push has to go to the overflow columns
+        if (stk.cap == 12) {
+          if (bih_descend_asm<12>(nodes, ref, am, sp, nearv, farv, fwdbits, stk.cap, r.o, rcp, (uint32_t)(uintptr_t)stk.nearv, exp_twait, exp_nstep, stk.ur, stk.ulo,
+                                  stk.uhi) == 0) break;
+        } else if (stk.cap == 10) {
+          if (bih_descend_asm<10>(nodes, ref, am, sp, nearv, farv, fwdbits, stk.cap, r.o, rcp, (uint32_t)(uintptr_t)stk.nearv, exp_twait, exp_nstep, stk.ur, stk.ulo,
+                                  stk.uhi) == 0) break;
         }
       }
 #endif
