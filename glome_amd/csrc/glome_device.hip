@@ -738,11 +738,11 @@ static int scene_class(const glome_scene* s) {  // scene class -> the smallest k
   return (m & ~CLS_BIH_TRI) == 0 ? CLS_BIH_TRI : ((m & ~(CLS_BIH_SPHERE | CLS_PRIMS)) == 0 ? (CLS_BIH_SPHERE | CLS_PRIMS) : ((m & ~CLS_MESH) == 0 ? CLS_MESH : CLS_ALL));
 }
 // every ray of the frame is walked as a packet (see k_render_flat): two stack rows per entry, six waves per SIMD
-static bool use_two_rows(const glome_scene* s, const glome_render_params* P) {
+static bool use_two_rows(const glome_scene* s, const glome_render_params* P, uint32_t items = 0xffffffffu) {
+  // a small launch of a rank's shard shares the GPU with the collective's and the blit's kernels and is better off with the
+  // 16-wave instance (measured at 8 ranks: 0.040 against 0.047 ms per frame); from ~48k work items on the 24-wave one wins
+  if (P->tile_stride != 1 && items < 48000u) return false;
   if (s->dev.tier != 0 || P->faithful || P->count_work) return false;
-  // a rank's shard of a frame shares the GPU with the collective's and the blit's kernels: the 16-wave instance leaves them
-  // room (measured: rank-side frame period 0.047 ms against 0.072 ms at 8 ranks), the 24-wave one is for whole frames
-  if (P->tile_stride != 1) return false;
   if (s->has_secondary_mats || s->has_nested_mats || s->stack_cap != kAsmLdsCap || getenv("GLOME_DEBUG_LB")) return false;
   int cls = scene_class(s);
   return cls == CLS_BIH_TRI || cls == (CLS_BIH_SPHERE | CLS_PRIMS);
@@ -765,7 +765,7 @@ static void launch_render(glome_scene* s, const DRenderArgs& A, const glome_rend
       else if (cls == CLS_MESH) GLOME_LAUNCH(F, C, U, CLS_MESH, 1);               \
       else GLOME_LAUNCH(F, C, U, CLS_ALL, 1);                                     \
     } while (0)
-    if (use_two_rows(s, P)) {
+    if (use_two_rows(s, P, A.total_waves * (uint32_t)A.nframes)) {
       size_t lds2 = lds;  // sized by the caller for two rows
       uint32_t* ov = s->ovf_cap ? s->ctx->slot().d_ovf : nullptr;
       if (cls == CLS_BIH_TRI) hipLaunchKernelGGL((k_render_flat<false, false, false, CLS_BIH_TRI, 6, true>), g, blk, lds2, st, A, s->stack_cap, ov, s->ovf_cap);
@@ -859,7 +859,7 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
   } else if (A.ntiles > 0) {
-    const bool two_rows = use_two_rows(s, P);
+    const bool two_rows = use_two_rows(s, P, A.total_waves * (uint32_t)nframes);
     size_t lds = s->dev.tier == 0 ? flat_lds_bytes(s->stack_cap, two_rows) : 0;
     int grid = persistent_grid(ctx, lds, A.total_waves * (uint32_t)nframes, two_rows ? 24 : 32, true);
     if (s->dev.tier == 0 && s->ovf_cap && (rc = ensure_overflow(ctx, grid, 1, s->ovf_cap))) return rc;
