@@ -845,7 +845,7 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
     for (int pass = 1; pass <= 5; pass++) {
       int nbx;
       uint32_t items = (uint32_t)ss_regions_per_tile(pass, P->blocksize, nbx) * (uint32_t)A.ntiles;
-      int tgrid = persistent_grid(ctx, lds, items, two_rows ? 24 : 32);
+      int tgrid = persistent_grid(ctx, lds, items, two_rows ? 24 : 32, true);
       if (s->dev.tier == 0 && s->ovf_cap && (rc = ensure_overflow(ctx, tgrid, 1, s->ovf_cap))) return rc;
       ov = s->ovf_cap ? ctx->slot().d_ovf : nullptr;
       dim3 g(tgrid), blk(64);
