@@ -691,18 +691,23 @@ int glome_scene_get_info(const glome_scene* s, glome_scene_info* out) {
 // should get ~64 work items, so that its fixed costs (set-up, the counter flush) amortise and several launches in flight
 // share the CUs side by side instead of one after the other (measured on the flagship frame, 4 launches of 4 frames in
 // flight: 24 waves per CU 0.272 ms, 16: 0.249, 8: 0.239; the 4K / 1M-triangle frame, 4x the items, is best at 24).
-static int persistent_grid(glome_ctx* ctx, size_t lds_per_block, uint32_t total_work, int max_per_cu = 32, bool sized_by_work = false) {
+static int persistent_grid(glome_ctx* ctx, size_t lds_per_block, uint32_t total_work, int max_per_cu = 32, int min_per_cu = 0) {
   int cus = ctx->prop.multiProcessorCount;
   int per_cu = max_per_cu;  // wave slots per CU the kernel's register budget allows
   if (lds_per_block) per_cu = std::min<int>(per_cu, (int)(160 * 1024 / lds_per_block));
   per_cu = std::max(per_cu, 1);
-  if (sized_by_work) {
+  if (min_per_cu > 0) {  // sized by work: ~64 items per wave, not below min_per_cu waves per CU
     long want = ((long)total_work + 64L * cus - 1) / (64L * cus);
-    per_cu = (int)std::min<long>(per_cu, std::max<long>(8, want));
+    per_cu = (int)std::min<long>(per_cu, std::max<long>(min_per_cu, want));
   }
   long g = (long)cus * per_cu;
   return (int)std::max<long>(1, std::min<long>(g, total_work));
 }
+// The floor of a work-sized grid: a scene with a small tree has cheap work items (tens of traversal steps), and a wave's
+// fixed costs then dominate a short launch -- 3 waves per CU (S2, four 720x480 frames per launch: 0.024 ms per frame
+// against 0.036 with 8); items of a large scene keep a wave busy for ~0.1 ms each and a short launch wants 8 (a rank's
+// shard of the flagship frame: 0.039 ms per frame with 8, 0.048 with 4).
+static int grid_floor(const glome_scene* s) { return s->info.n_bih_nodes + s->info.n_mesh_nodes < 4096 ? 3 : 8; }
 static int ensure_overflow(glome_ctx* ctx, int grid, int waves_per_block, int ovf_cap) {
   size_t need = (size_t)grid * waves_per_block * ovf_cap * 3 * 64 * sizeof(uint32_t);
   glome_ctx::Slot& sl = ctx->slot();
@@ -845,7 +850,7 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
     for (int pass = 1; pass <= 5; pass++) {
       int nbx;
       uint32_t items = (uint32_t)ss_regions_per_tile(pass, P->blocksize, nbx) * (uint32_t)A.ntiles;
-      int tgrid = persistent_grid(ctx, lds, items, two_rows ? 24 : 32, true);
+      int tgrid = persistent_grid(ctx, lds, items, two_rows ? 24 : 32, grid_floor(s));
       if (s->dev.tier == 0 && s->ovf_cap && (rc = ensure_overflow(ctx, tgrid, 1, s->ovf_cap))) return rc;
       ov = s->ovf_cap ? ctx->slot().d_ovf : nullptr;
       dim3 g(tgrid), blk(64);
@@ -861,7 +866,7 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
   } else if (A.ntiles > 0) {
     const bool two_rows = use_two_rows(s, P, A.total_waves * (uint32_t)nframes);
     size_t lds = s->dev.tier == 0 ? flat_lds_bytes(s->stack_cap, two_rows) : 0;
-    int grid = persistent_grid(ctx, lds, A.total_waves * (uint32_t)nframes, two_rows ? 24 : 32, true);
+    int grid = persistent_grid(ctx, lds, A.total_waves * (uint32_t)nframes, two_rows ? 24 : 32, grid_floor(s));
     if (s->dev.tier == 0 && s->ovf_cap && (rc = ensure_overflow(ctx, grid, 1, s->ovf_cap))) return rc;
     bool pooled = ctx->timing && (ctx->timing_seen++ % ctx->timing_stride) == 0 && ctx->pool_used + 2 <= (int)ctx->pool.size();
     hipEvent_t e0 = pooled ? ctx->pool[ctx->pool_used] : ctx->ev0, e1 = pooled ? ctx->pool[ctx->pool_used + 1] : ctx->ev1;
