@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=4, help="launches kept in flight per GPU (HIP streams / context slots)")
     ap.add_argument("--time-every", type=int, default=1, help="HIP-event pair on every k-th launch of the timed region (roofline kernel time)")
     ap.add_argument("--force-dist", action="store_true", help="one GPU, but through the multi-GPU pipeline with a one-rank RCCL group (rehearsal)")
-    ap.add_argument("--group", type=int, default=0, help="frames per launch (and per RCCL gather); default 4 on one GPU, 8 on several")
+    ap.add_argument("--group", type=int, default=0, help="frames per launch (and per RCCL gather); default 4 on one or two GPUs, 8 on more")
     ap.add_argument("--product", default="packed", choices=["packed", "rgbad"],
                     help="what a frame is: GlomeView's framebuffer of packed 0x00RRGGBB pixels (blitTile; 4 B/pixel cross xGMI) "
                          "or the float (r,g,b,a,depth) tuples (20 B/pixel)")
@@ -86,7 +86,7 @@ def main():
 
     if args.group <= 0:
         # frames per launch: deep batches pay a fill / drain of about one launch per run, so short runs get shallow ones
-        gmax = 8 if world > 1 else 4
+        gmax = 8 if world > 2 else 4
         args.group = 1 if (args.mode != 0 or args.product != "packed") else max(1, min(gmax, args.steps // 24))
     sf = dist.ShardedFrame(scene, P, rank, world, device, lanes=args.lanes, product=args.product, group=args.group, force_pipeline=args.force_dist)
 

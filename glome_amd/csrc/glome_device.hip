@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(64, LB) k_render_flat(DRenderArgs A, int stack
   extern __shared__ uint32_t lds[];
   FlatTier<FAITHFUL, COUNT, FULL, CLS> T{A.S, A.lights, A.nlights, lane_stack<TWO_ROWS>(lds, stack_cap, ovf, ovf_cap), Cnt()};
   render_loop(A, T);
-  flush_counters(A.counters, T.cnt, 0);
+  if (A.want_counters) flush_counters(A.counters, T.cnt, 0);
 }
 __global__ void __launch_bounds__(64) k_render_generic(DRenderArgs A) {
   GenericTier T{A.S, A.lights, A.nlights, Cnt()};
@@ -828,6 +828,7 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
   const bool bare = !stats && P->mode == GLOME_MODE_TILE && !P->faithful && !P->count_work && ctx->slot().work_base < 0x70000000u;
   if (!bare && (rc = reset_counters(ctx))) return rc;
   A.work_base = ctx->slot().work_base;
+  A.want_counters = bare ? 0 : 1;
   hipEvent_t ev_start = ctx->ev0, ev_stop = ctx->ev1;
   if (A.ntiles > 0 && P->mode == GLOME_MODE_SUBSAMPLE) {
     // scratch: v (5 floats per owned pixel) | 16 counters (per-pass queue heads)

@@ -118,6 +118,7 @@ struct DRenderArgs {
   // frame f-1's in the queue, its pixels go frame_stride pixels further into out5 / packed
   int32_t nframes;
   uint32_t frame_stride;
+  int32_t want_counters;  // 0: nobody will read the ray / work counters of this launch -- the waves skip the flush
   DCamera more_cams[kMaxBatchFrames - 1];
 };
 
