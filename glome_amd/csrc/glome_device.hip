@@ -147,11 +147,8 @@ __device__ __forceinline__ void flush_counters(DCounters* c, const Cnt& cnt, uns
 // work item w -> tile + 64 pixels.  A tile is cut into 8x8 blocks (coherent rays per wave); the pixels left over on
 // the right and bottom edges (65 = 8*8 + 1) are packed 64 at a time, so lanes are not wasted on partial blocks.
 __device__ __forceinline__ bool work_to_pixel(const DRenderArgs& A, uint32_t w, int lane, int& px, int& py, size_t& dense_off) {
-  int lo = 0, hi = A.ntiles - 1;
-  while (lo < hi) {
-    int mid = (lo + hi + 1) >> 1;
-    if (A.tiles[mid].wave_base <= w) lo = mid; else hi = mid - 1;
-  }
+  int lo = (int)A.tile_lut[w >> 6];  // the tile of item (w & ~63); w's own is that one or one of the next few
+  while (lo + 1 < A.ntiles && A.tiles[lo + 1].wave_base <= w) lo++;
   DTile t = A.tiles[lo];
   uint32_t j = w - t.wave_base;
   uint32_t nbx = t.w >> 3, nby = t.h >> 3, nblk = nbx * nby;
@@ -470,7 +467,8 @@ struct glome_ctx {
   Slot& slot() { return slots[cur]; }
   std::string err;
   // tile tables cached per (w, h, blocksize, first, stride)
-  struct TileTable { std::vector<DTile> host; DTile* dev = nullptr; uint32_t total_waves = 0; int64_t pixels = 0; };
+  // lut[w >> 6] = the tile that holds work item (w & ~63): the kernel's item -> tile lookup is one table read and a step or two
+  struct TileTable { std::vector<DTile> host; DTile* dev = nullptr; uint32_t* lut = nullptr; uint32_t total_waves = 0; int64_t pixels = 0; };
   std::map<std::vector<int>, TileTable> tile_cache;
 };
 struct glome_scene {
@@ -509,6 +507,13 @@ static int get_tiles(glome_ctx* ctx, const glome_render_params* P, int first, in
     size_t bytes = std::max<size_t>(1, tt.host.size()) * sizeof(DTile);
     HIPCHK(ctx, hipMalloc((void**)&tt.dev, bytes));
     if (!tt.host.empty()) HIPCHK(ctx, hipMemcpy(tt.dev, tt.host.data(), tt.host.size() * sizeof(DTile), hipMemcpyHostToDevice));
+    std::vector<uint32_t> lut((tt.total_waves >> 6) + 1, 0);
+    for (size_t k = 0, t = 0; k < lut.size(); k++) {
+      while (t + 1 < tt.host.size() && tt.host[t + 1].wave_base <= (uint32_t)(k << 6)) t++;
+      lut[k] = (uint32_t)t;
+    }
+    HIPCHK(ctx, hipMalloc((void**)&tt.lut, lut.size() * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMemcpy(tt.lut, lut.data(), lut.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     it = ctx->tile_cache.emplace(key, std::move(tt)).first;
   }
   *out = &it->second;
@@ -555,7 +560,7 @@ glome_ctx* glome_ctx_create(int device_ordinal) {
 void glome_ctx_destroy(glome_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  for (auto& kv : c->tile_cache) if (kv.second.dev) (void)hipFree(kv.second.dev);
+  for (auto& kv : c->tile_cache) { if (kv.second.dev) (void)hipFree(kv.second.dev); if (kv.second.lut) (void)hipFree(kv.second.lut); }
   for (auto& sl : c->slots) {
     if (sl.d_counters) (void)hipFree(sl.d_counters);
     if (sl.d_ovf) (void)hipFree(sl.d_ovf);
@@ -820,7 +825,7 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
   }
   A.nlights = nlights; A.width = P->width; A.height = P->height; A.fog = P->fog; A.maxdepth = P->maxdepth;
   memcpy(A.thresholds, P->thresholds, 16);
-  A.tiles = tt->dev; A.ntiles = (int)tt->host.size(); A.total_waves = tt->total_waves;
+  A.tiles = tt->dev; A.tile_lut = tt->lut; A.ntiles = (int)tt->host.size(); A.total_waves = tt->total_waves;
   // dense 0: full frame (rgbad and / or packed); 1: dense rgbad tile payload; 2: dense packed-pixel tile payload only
   A.out5 = dense == 2 ? nullptr : rgbad_dev; A.packed = dense == 1 ? nullptr : packed_dev; A.counters = ctx->slot().d_counters; A.dense = dense != 0;
   // a plain frame (no statistics wanted, renderTile mode) does not reset the counters: its work queue starts at the

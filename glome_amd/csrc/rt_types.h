@@ -104,6 +104,7 @@ struct DRenderArgs {
   int32_t maxdepth;
   float thresholds[4];
   const DTile* tiles;  // owned tiles
+  const uint32_t* tile_lut;  // tile of every 64th work item
   int32_t ntiles;
   uint32_t total_waves;
   uint32_t work_base;   // value of counters->next_work when this launch starts (0 after a counter reset)
