@@ -498,12 +498,13 @@ static int check_params(glome_ctx* ctx, const glome_render_params* P) {
   if (P->maxdepth < 1 || P->maxdepth > kMaxTraceDepth) { ctx->err = "maxdepth must be in 1.." + std::to_string(kMaxTraceDepth); return GLOME_E_LIMIT; }
   return 0;
 }
-static int get_tiles(glome_ctx* ctx, const glome_render_params* P, int first, int stride, glome_ctx::TileTable** out) {
-  std::vector<int> key{P->width, P->height, P->blocksize, first, stride};
+static int get_tiles(glome_ctx* ctx, const glome_render_params* P, int first, int stride, glome_ctx::TileTable** out, int blocksize = 0) {
+  if (!blocksize) blocksize = P->blocksize;
+  std::vector<int> key{P->width, P->height, blocksize, first, stride};
   auto it = ctx->tile_cache.find(key);
   if (it == ctx->tile_cache.end()) {
     glome_ctx::TileTable tt;
-    owned_tiles(P->width, P->height, P->blocksize, first, stride, tt.host, tt.total_waves, tt.pixels);
+    owned_tiles(P->width, P->height, blocksize, first, stride, tt.host, tt.total_waves, tt.pixels);
     size_t bytes = std::max<size_t>(1, tt.host.size()) * sizeof(DTile);
     HIPCHK(ctx, hipMalloc((void**)&tt.dev, bytes));
     if (!tt.host.empty()) HIPCHK(ctx, hipMemcpy(tt.dev, tt.host.data(), tt.host.size() * sizeof(DTile), hipMemcpyHostToDevice));
@@ -810,7 +811,11 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
   if (P->mode == GLOME_MODE_SUBSAMPLE && P->blocksize > 65) { ctx->err = "GLOME_MODE_SUBSAMPLE supports tiles up to 65x65"; return GLOME_E_LIMIT; }
   HIPCHK(ctx, hipSetDevice(ctx->device));
   glome_ctx::TileTable* tt;
-  if ((rc = get_tiles(ctx, P, P->tile_first, P->tile_stride, &tt))) return rc;
+  // a whole renderTile frame in image layout: the pixels are independent and every tile is owned, so the tile size only
+  // decides how the work is cut.  64x64 tiles are all 8x8 blocks -- no thin leftover strips (a 65x65 tile has 129
+  // pixels in a column and a row, whose 64-pixel items are the least coherent and slowest of the frame)
+  const bool whole = P->mode == GLOME_MODE_TILE && dense == 0 && P->tile_first == 0 && P->tile_stride == 1 && !getenv("GLOME_NO_RETILE");
+  if ((rc = get_tiles(ctx, P, P->tile_first, P->tile_stride, &tt, whole ? 64 : 0))) return rc;
   DRenderArgs A;
   memset(&A, 0, sizeof(A));
   A.S = s->dev;
