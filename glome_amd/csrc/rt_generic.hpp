@@ -46,9 +46,43 @@ GD V3 mat_tvec(const F4& r0, const F4& r1, const F4& r2, V3 v) {  // invxfm_norm
 
 template <int D, bool C> struct G;  // the four class methods at nesting budget D
 
-template <int D, bool C> GD HitG rayint_g(GCtx<C>& g, U4 rec, const Ray& r, float d, TexStack tex) { return G<D, C>::rayint(g, rec, r, d, tex); }
-template <int D, bool C> GD bool shadow_g(GCtx<C>& g, U4 rec, const Ray& r, float d) { return G<D, C>::shadow(g, rec, r, d); }
-template <int D, bool C> GD bool inside_g(GCtx<C>& g, U4 rec, V3 p) { return G<D, C>::inside(g, rec, p); }
+// The class-method calls.  A child that is a primitive (under any Tex wrappers) is answered here, inline at the call
+// site: most calls of a CSG scene are such leaves, and an out-of-line call costs a frame of spills each.
+template <int D, bool C> GD HitG rayint_g(GCtx<C>& g, U4 rec, const Ray& r, float d, TexStack tex) {
+  for (;;) {  // Tex s tex: rayint s r d (tex:texs) tags, Tex.hs:66
+    if (rec.x & RF_NOVIS) return hit_miss();
+    if ((rec.x & RF_KINDMASK) != R_TEX) break;
+    tex = tex_push(tex, rec.z);
+    rec = ldu4(g.S.recs, rec.y);
+  }
+  const uint32_t kind = rec.x & RF_KINDMASK;
+  if (kind >= R_SPHERE && kind <= R_CONE) {
+    HitG h = hit_miss();
+    if (C) g.cnt.prim++;
+    float t; V3 n;
+    if (!prim_test<true>(g.S, kind, rec.y, r, d, t, n)) return h;
+    h.hit = true; h.t = t; h.n = n; h.p = vscaleadd(r.o, r.d, t);
+    h.tex = tex_cat(own_stack_rayint(rec.z), tex); h.uid = rec.w;
+    return h;
+  }
+  return G<D, C>::rayint(g, rec, r, d, tex);
+}
+template <int D, bool C> GD bool shadow_g(GCtx<C>& g, U4 rec, const Ray& r, float d) {
+  for (;;) {  // shadow (Tex s _) = shadow s; NoShadow -> False (Tex.hs:69, 81)
+    if (rec.x & RF_NOSHADOW) return false;
+    if ((rec.x & RF_KINDMASK) != R_TEX) break;
+    rec = ldu4(g.S.recs, rec.y);
+  }
+  const uint32_t kind = rec.x & RF_KINDMASK;
+  if (kind >= R_SPHERE && kind <= R_CONE) { if (C) g.cnt.prim++; return prim_shadow(g.S, kind, rec.y, r, d); }
+  return G<D, C>::shadow(g, rec, r, d);
+}
+template <int D, bool C> GD bool inside_g(GCtx<C>& g, U4 rec, V3 p) {
+  while ((rec.x & RF_KINDMASK) == R_TEX) rec = ldu4(g.S.recs, rec.y);
+  const uint32_t kind = rec.x & RF_KINDMASK;
+  if (kind >= R_SPHERE && kind <= R_CONE) return prim_inside(g.S, kind, rec.y, p);
+  return G<D, C>::inside(g, rec, p);
+}
 template <int D, bool C> GD TexStack meta_g(GCtx<C>& g, U4 rec, V3 p) { return G<D, C>::meta(g, rec, p); }
 
 // strip Tex records (and stop at the first non-Tex record)
@@ -121,7 +155,7 @@ template <int D, bool C> struct G {
   }
 
   // rayint_difference, Csg.hs:33-54 (Q13); the self-recursion through rayint_advance (Solid.hs:85-91) is a loop
-  static GDN HitG diff_rayint(Ctx& g, U4 rec, const Ray& r0, float d0, TexStack tex) {
+  static GD HitG diff_rayint(Ctx& g, U4 rec, const Ray& r0, float d0, TexStack tex) {
     const DScene& S = g.S;
     U4 ra = ldu4(S.recs, rec.y), rb = ldu4(S.recs, rec.z);
     float adds[kCsgMaxAdvance];
@@ -167,7 +201,7 @@ template <int D, bool C> struct G {
     for (uint32_t k = from; k < rec.z; k++) acc = acc && inside_g<D - 1>(g, ldu4(g.S.recs, rec.y + k), p);
     return acc;
   }
-  static GDN HitG isect_rayint(Ctx& g, U4 rec, const Ray& r0, float d0, TexStack tex) {
+  static GD HitG isect_rayint(Ctx& g, U4 rec, const Ray& r0, float d0, TexStack tex) {
     const DScene& S = g.S;
     uint32_t n = rec.z;
     IFrame fr[kIsectFrames];
@@ -221,7 +255,7 @@ template <int D, bool C> struct G {
   }
 
   // rayint_bih, Bih.hs:332-368, over records (any leaf class); ordered early-out (see rt_device.hpp)
-  static GDN HitG bih_rayint(Ctx& g, U4 rec, const Ray& r, float d, TexStack tex) {
+  static GD HitG bih_rayint(Ctx& g, U4 rec, const Ray& r, float d, TexStack tex) {
     const DScene& S = g.S;
     PrivStack stk;
     HitG best = hit_miss();
@@ -238,7 +272,7 @@ template <int D, bool C> struct G {
     return best;
   }
   // rayint_mesh, Mesh.hs:136-198
-  static GDN HitG mesh_rayint(Ctx& g, U4 rec, const Ray& r, float d, TexStack tex) {
+  static GD HitG mesh_rayint(Ctx& g, U4 rec, const Ray& r, float d, TexStack tex) {
     const DScene& S = g.S;
     PrivStack stk;
     float mt; uint32_t ti;
@@ -301,7 +335,7 @@ template <int D, bool C> struct G {
       return false;
     }
   }
-  static GDN bool bih_shadow(Ctx& g, U4 rec, const Ray& r, float d) {  // shadow_bih, Bih.hs:510-544
+  static GD bool bih_shadow(Ctx& g, U4 rec, const Ray& r, float d) {  // shadow_bih, Bih.hs:510-544
     const DScene& S = g.S;
     PrivStack stk;
     bool occ = false;
