@@ -87,14 +87,15 @@ struct GenericTier {
   int nlights;
   Cnt cnt;
   unsigned int err = 0;
+  GPool pool;  // the interpreter's frame / advance pools: one per lane for the whole kernel
   __device__ __forceinline__ HitG closest(const Ray& r, float tmax) {
-    GCtx<true> g{S, cnt, err};
+    GCtx<true> g{S, cnt, err, pool};
     HitG h = rayint_g<kGenericDepth>(g, ldu4(S.recs, S.root_rec), r, tmax, (TexStack)0);
     err = g.err;
     return h;
   }
   __device__ __forceinline__ bool occluded(const Ray& r, float d) {
-    GCtx<true> g{S, cnt, err};
+    GCtx<true> g{S, cnt, err, pool};
     bool o = shadow_g<kGenericDepth>(g, ldu4(S.recs, S.root_rec), r, d);
     err = g.err;
     return o;
@@ -392,7 +393,8 @@ __global__ void __launch_bounds__(64) k_shadow_batch_generic(DScene S, size_t n,
 }
 __global__ void __launch_bounds__(64) k_inside_batch(DScene S, size_t n, const float* px, const float* py, const float* pz, uint8_t* in, DCounters* c) {
   Cnt cnt; unsigned int err = 0;
-  GCtx<true> g{S, cnt, err};
+  GPool pool;
+  GCtx<true> g{S, cnt, err, pool};
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     in[i] = inside_g<kGenericDepth>(g, ldu4(S.recs, S.root_rec), v3(px[i], py[i], pz[i])) ? 1 : 0;
   if (g.err) atomicOr(&c->error, 1u);

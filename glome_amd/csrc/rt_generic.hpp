@@ -10,10 +10,24 @@
 
 namespace glome {
 
+// One explicit frame of rayint_intersection's list recursion (isect_rayint).  `from` holds the list position and, in
+// its top two bits, the frame's state; `aux` is the state's one live distance (state 1: the inside hit's depth, state 2:
+// the advance added back on return).
+struct IFrame { uint32_t from; float ox, oy, oz, d, aux; };
+// The interpreter's variable-length scratch lives in ONE pool per ray instead of one worst-case array per nesting level:
+// nested invocations stack their frames / advances on the same arrays (fr_top, adv_top), so the kernel's scratch frame
+// is sized by what a ray can have live at once, not by depth x worst case.  The pools are bounded (kIsectFrames,
+// kCsgMaxAdvance per ray); running out raises the context's error flag like every other device limit.
+struct GPool {
+  IFrame fr[kIsectFrames];
+  float adv[kCsgMaxAdvance];
+};
 template <bool COUNT> struct GCtx {
   const DScene& S;
   Cnt& cnt;
   unsigned int err;
+  GPool& pool;
+  int fr_top = 0, adv_top = 0;
 };
 
 GD HitG nearest_hit(const HitG& a, const HitG& b) {  // nearest, Solid.hs:37-44: ties -> b
@@ -158,7 +172,8 @@ template <int D, bool C> struct G {
   static GD HitG diff_rayint(Ctx& g, U4 rec, const Ray& r0, float d0, TexStack tex) {
     const DScene& S = g.S;
     U4 ra = ldu4(S.recs, rec.y), rb = ldu4(S.recs, rec.z);
-    float adds[kCsgMaxAdvance];
+    float* adds = g.pool.adv + g.adv_top;  // this invocation's advances; nested invocations stack above them
+    const int adv_base = g.adv_top;
     int na = 0;
     Ray r = r0;
     float d = d0;
@@ -183,19 +198,21 @@ template <int D, bool C> struct G {
         if (ha.t < hb.t) { res = ha; break; }
         adv = hb.t;
       }
-      if (na >= kCsgMaxAdvance) { g.err = 1; break; }
+      if (adv_base + na >= kCsgMaxAdvance) { g.err = 1; break; }
       float a = adv + kDel;
       adds[na++] = a;
+      g.adv_top = adv_base + na;
       r.o = vscaleadd(r.o, r.d, a);  // ray_move
       d = d - a;
     }
     if (res.hit) for (int k = na - 1; k >= 0; k--) res.t = res.t + adds[k];  // RayHit (depth+a) ..., innermost first
+    g.adv_top = adv_base;
     return res;
   }
 
   // rayint_intersection, Csg.hs:68-90 (Q14).  The reference recurses on the list tail (non-tail position) and on
   // itself with an advanced ray; both become explicit frames.
-  struct IFrame { uint32_t from; float ox, oy, oz, d, sd, add; uint32_t state; };
+  static constexpr uint32_t kFrState1 = 1u << 30, kFrState2 = 2u << 30, kFrFrom = (1u << 30) - 1u;
   static GD bool inside_rest(Ctx& g, U4 rec, uint32_t from, V3 p) {  // inside (Intersection ss) sp: foldl' (&&) True
     bool acc = true;
     for (uint32_t k = from; k < rec.z; k++) acc = acc && inside_g<D - 1>(g, ldu4(g.S.recs, rec.y + k), p);
@@ -204,11 +221,15 @@ template <int D, bool C> struct G {
   static GD HitG isect_rayint(Ctx& g, U4 rec, const Ray& r0, float d0, TexStack tex) {
     const DScene& S = g.S;
     uint32_t n = rec.z;
-    IFrame fr[kIsectFrames];
+    const int base = g.fr_top;  // this invocation's frames start here; nested invocations stack above fr[sp]
+    IFrame* fr = g.pool.fr + base;
+    const int room = kIsectFrames - base;
+    if (room < 1) { g.err = 1; return hit_miss(); }
     int sp = 0;
     auto push = [&](uint32_t from, V3 o, float d) {
       IFrame& c = fr[sp];
-      c.from = from; c.ox = o.x; c.oy = o.y; c.oz = o.z; c.d = d; c.sd = 0; c.add = 0; c.state = 0;
+      c.from = from; c.ox = o.x; c.oy = o.y; c.oz = o.z; c.d = d; c.aux = 0;
+      g.fr_top = base + sp + 1;
     };
     push(0, r0.o, d0);
     HitG ret = hit_miss();
@@ -216,41 +237,44 @@ template <int D, bool C> struct G {
     for (;;) {
       if (!returning) {
         IFrame& f = fr[sp];
+        const uint32_t from = f.from & kFrFrom;
         Ray r; r.o = v3(f.ox, f.oy, f.oz); r.d = r0.d;
-        if (f.from >= n || f.d < 0) { ret = hit_miss(); returning = true; continue; }  // null slds || d < 0
-        U4 s = ldu4(S.recs, rec.y + f.from);
+        if (from >= n || f.d < 0) { ret = hit_miss(); returning = true; continue; }  // null slds || d < 0
+        U4 s = ldu4(S.recs, rec.y + from);
         HitG hs = rayint_g<D - 1>(g, s, r, f.d, tex);
-        if (f.from + 1 == n) { ret = hs; returning = true; continue; }  // [] -> rayint s r d t tags
+        if (from + 1 == n) { ret = hs; returning = true; continue; }  // [] -> rayint s r d t tags
         if (inside_g<D - 1>(g, s, r.o)) {
-          if (!hs.hit) { f.from += 1; continue; }  // RayMiss -> rayint (Intersection ss) r d: a tail call
-          if (sp + 1 >= kIsectFrames) { g.err = 1; return hit_miss(); }
-          f.sd = hs.t; f.state = 1;                // rest = rayint (Intersection ss) r sd
-          sp++; push(f.from + 1, r.o, hs.t);
+          if (!hs.hit) { f.from = from + 1; continue; }  // RayMiss -> rayint (Intersection ss) r d: a tail call
+          if (sp + 1 >= room) { g.err = 1; g.fr_top = base; return hit_miss(); }
+          f.aux = hs.t; f.from = from | kFrState1;  // rest = rayint (Intersection ss) r sd
+          sp++; push(from + 1, r.o, hs.t);
           continue;
         }
         if (!hs.hit) { ret = hit_miss(); returning = true; continue; }
-        if (inside_rest(g, rec, f.from + 1, hs.p)) { ret = hs; returning = true; continue; }  // RayHit sd sp sn r vzero st stags
-        if (sp + 1 >= kIsectFrames) { g.err = 1; return hit_miss(); }
+        if (inside_rest(g, rec, from + 1, hs.p)) { ret = hs; returning = true; continue; }  // RayHit sd sp sn r vzero st stags
+        if (sp + 1 >= room) { g.err = 1; g.fr_top = base; return hit_miss(); }
         float a = hs.t + kDel;  // rayint_advance (Intersection slds) r d t tags sd
-        f.state = 2; f.add = a;
-        sp++; push(f.from, vscaleadd(r.o, r.d, a), f.d - a);
+        f.from = from | kFrState2; f.aux = a;
+        sp++; push(from, vscaleadd(r.o, r.d, a), f.d - a);
         continue;
       }
-      if (sp == 0) return ret;
+      if (sp == 0) { g.fr_top = base; return ret; }
       sp--;
+      g.fr_top = base + sp + 1;
       IFrame& p = fr[sp];
-      if (p.state == 1) {
+      if ((p.from & ~kFrFrom) == kFrState1) {
         if (ret.hit) continue;  // hit -> hit
-        if (sp + 1 >= kIsectFrames) { g.err = 1; return hit_miss(); }
-        float a = p.sd + kDel;
-        p.state = 2; p.add = a;
+        if (sp + 1 >= room) { g.err = 1; g.fr_top = base; return hit_miss(); }
+        float a = p.aux + kDel;
+        const uint32_t pf = p.from & kFrFrom;
+        p.from = pf | kFrState2; p.aux = a;
         V3 po = v3(p.ox, p.oy, p.oz);
-        float pd = p.d; uint32_t pf = p.from;
+        float pd = p.d;
         sp++; push(pf, vscaleadd(po, r0.d, a), pd - a);
         returning = false;
         continue;
       }
-      if (ret.hit) ret.t = ret.t + p.add;  // state 2: RayHit (depth+a) ...
+      if (ret.hit) ret.t = ret.t + p.aux;  // state 2: RayHit (depth+a) ...
     }
   }
 

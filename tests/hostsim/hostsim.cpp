@@ -41,8 +41,8 @@ struct HostGenericTier {
   int nlights;
   Cnt cnt;
   unsigned int err = 0;
-  HitG closest(const Ray& r, float tmax) { GCtx<true> g{S, cnt, err}; HitG h = rayint_g<kGenericDepth>(g, S.recs[S.root_rec], r, tmax, (TexStack)0); err = g.err; return h; }
-  bool occluded(const Ray& r, float d) { GCtx<true> g{S, cnt, err}; bool o = shadow_g<kGenericDepth>(g, S.recs[S.root_rec], r, d); err = g.err; return o; }
+  HitG closest(const Ray& r, float tmax) { GPool pool; GCtx<true> g{S, cnt, err, pool}; HitG h = rayint_g<kGenericDepth>(g, S.recs[S.root_rec], r, tmax, (TexStack)0); err = g.err; return h; }
+  bool occluded(const Ray& r, float d) { GPool pool; GCtx<true> g{S, cnt, err, pool}; bool o = shadow_g<kGenericDepth>(g, S.recs[S.root_rec], r, d); err = g.err; return o; }
   HitG closest_ni(const Ray& r, float tmax) { return closest(r, tmax); }
   bool occluded_ni(const Ray& r, float d) { return occluded(r, d); }
   HitG closest_wave(const Ray& r, float tmax, bool valid) { return valid ? closest(r, tmax) : hit_miss(); }
@@ -129,7 +129,7 @@ int hostsim_shadow(void* sv, int tier, size_t n, const float* ox, const float* o
 int hostsim_inside(void* sv, size_t n, const float* px, const float* py, const float* pz, unsigned char* in) {
   SimScene* s = (SimScene*)sv;
   Cnt cnt; unsigned int err = 0;
-  GCtx<true> g{s->D, cnt, err};
+  GPool pool; GCtx<true> g{s->D, cnt, err, pool};
   for (size_t i = 0; i < n; i++) in[i] = inside_g<kGenericDepth>(g, s->D.recs[s->D.root_rec], v3(px[i], py[i], pz[i]));
   return g.err ? -2 : 0;
 }
