@@ -210,6 +210,31 @@ class Builder:
         lights = [(tuple(lp[6 * k:6 * k + 3]), tuple(lp[6 * k + 3:6 * k + 6])) for k in range(min(nl.value, max_lights))]
         return root, (tuple(c[0:3]), tuple(c[3:6]), tuple(c[6:9]), c[9]), lights, tuple(bg)
 
+    def show(self, node):
+        """Node `node` as the text GlomeView's `show geom` prints (Glome.hs:431; derived Show + Solid.hs:277, Tex.hs:50, Mesh.hs:44)."""
+        n = self.lib.glome_sb_show(self.h, int(node), None, 0)
+        self._chk(int(n), "glome_sb_show")
+        buf = C.create_string_buffer(n + 1)
+        self._chk(int(self.lib.glome_sb_show(self.h, int(node), buf, n + 1)), "glome_sb_show")
+        return buf.value.decode()
+
+    def show_tex_materials(self, node):
+        """Material ids of the Tex constructors of show(node), in reading order (the part the text cannot carry)."""
+        n = int(self.lib.glome_sb_show_tex_materials(self.h, int(node), None, 0))
+        self._chk(n, "glome_sb_show_tex_materials")
+        out = (C.c_int32 * max(1, n))()
+        self._chk(int(self.lib.glome_sb_show_tex_materials(self.h, int(node), out, n)), "glome_sb_show_tex_materials")
+        return list(out)[:n]
+
+    def load_show(self, text, tex_materials=(), default_material=-1):
+        """Read a `show geom` text: returns (root node, number of Tex constructors).  The k-th Tex gets tex_materials[k],
+        later ones default_material (textures are closures in the reference and print as "Texture")."""
+        mats = (C.c_int32 * max(1, len(tex_materials)))(*[int(m) for m in tex_materials])
+        nt = C.c_int32(0)
+        root = self._chk(self.lib.glome_sb_load_show(self.h, text.encode() if isinstance(text, str) else text, mats, len(tex_materials), int(default_material), C.byref(nt)),
+                         "glome_sb_load_show")
+        return root, nt.value
+
     def material_blend_fn(self, a, b, fn, params):
         """Blend a b (f pos): fn = WEIGHT_PERLIN (params = [scale]) or WEIGHT_STRIPE_* (params = axis), TestScene.hs:214-234."""
         wp = (C.c_double * 4)(*([float(x) for x in params] + [0.0] * (4 - len(params))))

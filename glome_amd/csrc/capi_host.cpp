@@ -8,6 +8,7 @@
 
 #include "../../include/glome_hip.h"
 #include "capi_shared.hpp"
+#include "show_format.hpp"
 #include "tiles.hpp"
 
 using namespace glome;
@@ -181,6 +182,40 @@ struct NffLex {
   bool keyword(const char* k) { std::string w; if (word(w) && w == k) { take(w); return true; } return false; }
 };
 }  // namespace
+
+// `show geom` text (show_format.hpp)
+long glome_sb_show(glome_sb* sb, int32_t id, char* buf, long cap) {
+  if (!sb) return GLOME_E_INVALID;
+  try {
+    std::string o;
+    ShowWriter W{sb->graph, o};
+    W.item(id);
+    if (buf && cap > 0) { size_t n = std::min<size_t>(o.size(), (size_t)cap - 1); memcpy(buf, o.data(), n); buf[n] = 0; }
+    return (long)o.size();
+  } catch (const std::exception& e) { sb->err = e.what(); return GLOME_E_INVALID; }
+}
+long glome_sb_show_tex_materials(glome_sb* sb, int32_t id, int32_t* mats, long cap) {
+  if (!sb) return GLOME_E_INVALID;
+  try {
+    std::string o;
+    std::vector<int> m;
+    ShowWriter W{sb->graph, o, &m};
+    W.item(id);
+    for (long k = 0; mats && k < cap && k < (long)m.size(); k++) mats[k] = m[(size_t)k];
+    return (long)m.size();
+  } catch (const std::exception& e) { sb->err = e.what(); return GLOME_E_INVALID; }
+}
+int32_t glome_sb_load_show(glome_sb* sb, const char* text, const int32_t* tex_materials, int32_t n_tex_materials, int32_t default_material, int32_t* n_tex) {
+  return guard(sb, [&] {
+    if (!text) throw std::invalid_argument("null show text");
+    if (n_tex_materials < 0 || (n_tex_materials > 0 && !tex_materials)) throw std::invalid_argument("bad material list");
+    std::vector<int> mats(tex_materials, tex_materials + n_tex_materials);
+    int nt = 0;
+    int root = load_show(sb->graph, text, strlen(text), mats.data(), (int)mats.size(), default_material, &nt);
+    if (n_tex) *n_tex = nt;
+    return root;
+  });
+}
 
 int32_t glome_sb_load_nff(glome_sb* sb, const char* text, double cam_from_at_up_angle[10], double* light_pos_rgb, int32_t max_lights, int32_t* n_lights,
                           double bg_rgb[3]) {

@@ -109,6 +109,22 @@ int32_t glome_sb_tolist(glome_sb*, int32_t id);             /* `tolist`, Solid.h
 int32_t glome_sb_load_nff(glome_sb*, const char* text, double cam_from_at_up_angle[10], double* light_pos_rgb, int32_t max_lights, int32_t* n_lights,
                           double bg_rgb[3]);
 
+/* The text GlomeView prints for a scene (`show geom`, SDLK_s, Glome.hs:431) as an interchange format: derived `Show` of
+ * the solids' constructors (Sphere.hs:11, Triangle.hs:13-14, Box.hs:10, Cone.hs:21-23, Plane.hs:11, Csg.hs:14-15,
+ * Bound.hs:20,95, Tex.hs:27-29, Solid.hs:386, Bih.hs:51-57, Vec.hs:105,407-414,646) with the hand-written instances for
+ * SolidItem ("SI ...", Solid.hs:277), Texture ("Texture", Solid.hs:101), Tag (Tex.hs:50) and Mesh (Mesh.hs:44).
+ * glome_sb_show writes node `id` in that text (returns its length; at most cap-1 characters + NUL go to buf, buf may
+ * be NULL to ask for the length).  glome_sb_load_show reads such a text -- e.g. the dump of a real GHC build of
+ * TestScene.hs -- into the builder, Bih and Mesh trees exactly as printed, and returns the root.  Materials are closures
+ * on the Haskell side and print as "Texture": the k-th `Tex` of the text (reading order) gets tex_materials[k], the
+ * rest default_material (-1: fail); *n_tex = how many the text holds.  Tags and mesh vertex normals are not printed by
+ * the reference and do not survive (a mesh with normals is refused); `Difference _ _ False` is refused. */
+long glome_sb_show(glome_sb*, int32_t id, char* buf, long cap);
+/* the material ids of the `Tex` constructors of that text, in reading order (what the text itself cannot carry): returns
+ * their number, writes at most cap of them */
+long glome_sb_show_tex_materials(glome_sb*, int32_t id, int32_t* mats, long cap);
+int32_t glome_sb_load_show(glome_sb*, const char* text, const int32_t* tex_materials, int32_t n_tex_materials, int32_t default_material, int32_t* n_tex);
+
 /* materials (the defunctionalised `Material`, Shader.hs:43-52; a texture is a material id = t_uniform, Shader.hs:55-56) */
 int32_t glome_sb_material_surface(glome_sb*, const double color[3], double alpha, double amb, double kd, double ks, double shine);
 int32_t glome_sb_material_reflect(glome_sb*, double refl);

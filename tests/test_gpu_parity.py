@@ -387,6 +387,26 @@ def test_nff_scene_renders_like_the_oracle(gpu_ctx):
     sc.release()
 
 
+@pytest.mark.parametrize("name", ["csg", "materials", "soup"])
+def test_scene_read_back_from_show_text_renders_the_same_frame(gpu_ctx, name):
+    """N4: a scene written as `show geom` text and read back (trees as printed, materials from the side list) is the same
+    scene on the device: the frame is bit-identical, generic and flat tiers."""
+    sd = zoo.soup(2500, 5) if name == "soup" else getattr(zoo, name)()
+    b, nm, sc = commit(gpu_ctx, sd)
+    root = nm[sd.root]
+    root2, ntex = b.load_show(b.show(root), b.show_tex_materials(root))
+    sc2 = gpu_ctx.commit(b, root2)
+    assert sc2.info()["tier"] == sc.info()["tier"]
+    cam, lights = product_camera_lights(sd)
+    P = api.render_params(width=200, height=144, maxdepth=3)
+    img, packed, st = sc.render(cam, lights, P)
+    img2, packed2, st2 = sc2.render(cam, lights, P)
+    assert np.array_equal(img, img2) and np.array_equal(packed, packed2)
+    assert (st["rays_primary"], st["rays_shadow"], st["rays_secondary"]) == (st2["rays_primary"], st2["rays_shadow"], st2["rays_secondary"])
+    parity.check_image(img2, (st2["rays_primary"], st2["rays_shadow"], st2["rays_secondary"]), sd, 200, 144, 3)
+    sc.release(); sc2.release()
+
+
 @pytest.mark.parametrize("kind", ["tri_floor", "tri_only", "sphere_floor"])
 def test_random_soup_renders_like_the_oracle(gpu_ctx, kind):
     """The packet walk on irregular trees (overlapping items, leaves of more than six, mixed entry lists)."""
