@@ -147,9 +147,15 @@ class ShardedFrame:
     blitTile are fused and 4 bytes per pixel cross xGMI.  "rgbad" -- the float (r, g, b, a, depth) tuples ([h, w, 5]),
     20 bytes per pixel (one frame per launch)."""
 
-    def __init__(self, scene, params, rank, world, device, lanes=4, product="rgbad", group=1, force_pipeline=False):
+    def __init__(self, scene, params, rank, world, device, lanes=4, product="rgbad", group=1, force_pipeline=False, work_tiles=64):
         import torch
         self.torch = torch
+        # renderTile's pixels do not depend on the tile map (the adaptive sampler's do, Q21): the shard unit is then a 64x64
+        # *work* tile
+        # (64: all 8x8 blocks, no thin leftover strips; tools/shard_balance.py: 32 and 16 lose cache locality between a rank's
+        # neighbouring work items, 128 and 256 lose balance at 8 ranks) -- whatever tile size the caller's display loop uses
+        if work_tiles and params.mode == 0 and params.blocksize != int(work_tiles):
+            params = _clone_params(params, blocksize=int(work_tiles))
         self.scene, self.ctx, self.lib = scene, scene.ctx, scene.lib
         if product not in ("packed", "rgbad"):
             raise ValueError("product must be 'packed' or 'rgbad'")

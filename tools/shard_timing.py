@@ -1,6 +1,6 @@
 """Single-GPU rehearsal of the multi-GPU step: per-rank render time of each tile shard (load balance) and rank 0's
 per-step cost without the collective.  Not a test."""
-import ctypes as C, json, sys, time
+import ctypes as C, json, os, sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import torch, numpy as np
 from glome_amd import api, scenes, dist, _lib as L
@@ -12,7 +12,7 @@ dev = torch.device("cuda:0")
 P = api.render_params(width=1920, height=1080, maxdepth=1)
 la = (L.Light * len(lights))(*lights)
 frame = torch.zeros((1080, 1920, 5), dtype=torch.float32, device=dev)
-for world in (1, 2, 4, 8):
+for world in (() if os.environ.get("SHARD_PIPE_ONLY") else (1, 2, 4, 8)):
     plans = [dist.ShardPlan(P, r, world) for r in range(world)]
     gathered = torch.zeros((world, plans[0].maxp), dtype=torch.float32, device=dev)
     per_rank = []
