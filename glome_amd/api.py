@@ -290,6 +290,16 @@ class Context:
         self.lib.glome_ctx_device_info(self.h, name, 256, C.byref(cu), C.byref(ws))
         return name.value.decode(), cu.value, ws.value
 
+    def bih(self, builder, ids):
+        """`bih ids` built on this context's GPU (glome_sb_bih_dev): the node glome_sb_bih makes, tree bit for bit.
+        Returns (node, device milliseconds)."""
+        arr = (C.c_int32 * max(1, len(ids)))(*[int(i) for i in ids])
+        ms = C.c_float(0)
+        rc = self.lib.glome_sb_bih_dev(self.h, builder.h, arr, len(ids), C.byref(ms))
+        if rc < 0:
+            raise GlomeError(f"glome_sb_bih_dev: {self.err()} (status {rc})")
+        return rc, ms.value
+
     def commit(self, builder, root):
         s = self.lib.glome_scene_commit(self.h, builder.h, int(root))
         if not s:

@@ -27,6 +27,7 @@
 #include "tiles.hpp"
 #include "rt_device.hpp"
 #include "rt_generic.hpp"
+#include "bih_build_device.hpp"
 
 using namespace glome;
 
@@ -625,6 +626,31 @@ int glome_ctx_device_info(glome_ctx* c, char* name, int cap, int* cu_count, int*
   if (cu_count) *cu_count = c->prop.multiProcessorCount;
   if (warp_size) *warp_size = c->prop.warpSize;
   return 0;
+}
+
+// ---- bih, built on the device (bih_build_device.hpp) ----
+int32_t glome_sb_bih_dev(glome_ctx* ctx, glome_sb* sb, const int32_t* ids, int32_t n, float* gpu_ms) {
+  if (!ctx || !sb) { g_global_error = "null ctx or builder"; return GLOME_E_INVALID; }
+  if (gpu_ms) *gpu_ms = 0;
+  try {
+    if (n < 0 || (n > 0 && !ids)) throw std::invalid_argument("bad id list");
+    Graph& G = sb->graph;
+    std::vector<int> v(ids, ids + n);
+    if (v.empty()) return G.bih(v);  // bih [] = Void, Bih.hs:309-311
+    std::vector<Box3> boxes;
+    Box3 bb = box_empty();
+    for (int i : v) boxes.push_back(G.bound(i));
+    for (auto& b : boxes) bb = box_join(bb, b);
+    if (bb.lo.x == -kInfinity || bb.lo.y == -kInfinity || bb.lo.z == -kInfinity || bb.hi.x == kInfinity || bb.hi.y == kInfinity || bb.hi.z == kInfinity)
+      throw scene_error("bih: infinite bounding box");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    auto T = std::make_shared<BihTree>();
+    std::string err;
+    if (!bihdev::build(boxes, v, bb, *T, ctx->stream, err, gpu_ms)) { ctx->err = sb->err = err; return GLOME_E_LIMIT; }
+    Node nd; nd.kind = K_BIH; nd.bih = T;
+    return G.add(nd);
+  } catch (const scene_error& e) { ctx->err = sb->err = e.what(); return GLOME_E_SCENE; }
+  catch (const std::exception& e) { ctx->err = sb->err = e.what(); return GLOME_E_INVALID; }
 }
 
 // ---- commit ----

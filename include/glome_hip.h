@@ -148,6 +148,12 @@ int glome_sb_bound(glome_sb*, int32_t id, double out6[6]);    /* bound, Solid.hs
 long glome_sb_bih_dump(glome_sb*, int32_t id, long cap, double* lsplit, double* rsplit, int* axis, int* nleaf,
                        int32_t* leaf_prims, long cap_prims);
 
+/* `bih` (Bih.hs:309-324) built on the GPU of `ctx`: the same node as glome_sb_bih over the same ids -- the tree of the
+ * reference's build_rec (Bih.hs:211-285), node for node and bit for bit -- made level by level by four kernels per tree
+ * level instead of by recursion on the host (100k triangles: see DESIGN.md).  *gpu_ms (may be NULL) = device time of the
+ * build.  Needs the HIP half of the library (a context); the host builder stays the default and the checker. */
+int32_t glome_sb_bih_dev(glome_ctx*, glome_sb*, const int32_t* ids, int32_t n, float* gpu_ms);
+
 /* ---- commit: validate + flatten to packed SoA pools + upload to HBM ---- */
 glome_scene* glome_scene_commit(glome_ctx*, glome_sb*, int32_t root);
 void glome_scene_release(glome_scene*);

@@ -387,6 +387,59 @@ def test_nff_scene_renders_like_the_oracle(gpu_ctx):
     sc.release()
 
 
+def _same_tree(b, a_node, d_node):
+    da, dd = b.bih_dump(a_node), b.bih_dump(d_node)
+    for k in range(5):  # split planes, axes, leaf sizes, leaf items in order: bit for bit
+        assert np.array_equal(da[k], dd[k]), k
+    assert np.array_equal(b.bound(a_node), b.bound(d_node))
+
+
+@pytest.mark.parametrize("kind", ["spheres", "mixed", "duplicates", "tiny"])
+def test_device_built_bih_is_the_host_builders_tree(gpu_ctx, kind):
+    """N4: glome_sb_bih_dev (four kernels per tree level) against glome_sb_bih (the recursion of Bih.hs:211-285): same
+    candidates, same costs, same comparison chain, same stable partitions -- the same tree, leaf order included."""
+    rng = np.random.default_rng(17)
+    b = api.Builder()
+    if kind == "spheres":
+        ids = [b.sphere(tuple(rng.uniform(-30, 30, size=3)), float(rng.uniform(0.1, 4))) for _ in range(3000)]
+    elif kind == "mixed":  # big and small objects (the fourth candidate: area > 0.4 of the node's), boxes, triangles
+        ids = [b.sphere(tuple(rng.uniform(-10, 10, size=3)), float(rng.uniform(0.05, 0.5))) for _ in range(800)]
+        ids += [b.box(tuple(rng.uniform(-10, 0, size=3)), tuple(rng.uniform(0, 10, size=3))) for _ in range(6)]
+        ids += [b.triangle(*[tuple(rng.uniform(-10, 10, size=3)) for _ in range(3)]) for _ in range(700)]
+        ids = [ids[i] for i in rng.permutation(len(ids))]
+    elif kind == "duplicates":  # identical boxes: partitions that do not separate, ties everywhere, empty leaves
+        ids = [b.sphere((float(i % 5), 0.0, float(i % 3)), 1.0) for i in range(600)]
+    else:
+        ids = [b.sphere((float(i), 0.0, 0.0), 0.4) for i in range(3)]
+    host = b.bih(ids)
+    dev, ms = gpu_ctx.bih(b, ids)
+    _same_tree(b, host, dev)
+    if kind != "tiny":
+        assert ms > 0
+
+
+def test_device_built_bih_of_the_flagship_terrain(gpu_ctx):
+    """100,352 triangles (S3's heightfield): the device build gives the host builder's tree and the frame it renders."""
+    import time
+    sd = scenes.s3(224)
+    b = api.Builder()
+    nm, _ = sd.replay(b)
+    nid, host, ids = 0, None, None  # SceneDesc node ids run over the node ops in order (a bulk op makes many)
+    for kind, name, args in sd.ops:
+        if kind == "N":
+            nid += args[0].shape[0]
+        elif kind == "n":
+            if name == "bih":
+                host, ids = nm[nid], [nm[i] for i in args[0]]
+            nid += 1
+    assert host is not None and len(ids) == 100352
+    t0 = time.perf_counter()
+    dev, ms = gpu_ctx.bih(b, ids)
+    wall = time.perf_counter() - t0
+    _same_tree(b, host, dev)
+    print(f"device bih of {len(ids)} triangles: {ms:.2f} ms on the GPU, {wall * 1e3:.0f} ms wall incl. bounds, upload and tree read-back")
+
+
 @pytest.mark.parametrize("name", ["csg", "materials", "soup"])
 def test_scene_read_back_from_show_text_renders_the_same_frame(gpu_ctx, name):
     """N4: a scene written as `show geom` text and read back (trees as printed, materials from the side list) is the same
