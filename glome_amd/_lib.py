@@ -97,6 +97,7 @@ SYMBOLS = [
     ("glome_sb_material_blend_fn", C.c_int32, [vp, C.c_int32, C.c_int32, C.c_int32, c_dp]),
     ("glome_sb_load_nff", C.c_int32, [vp, C.c_char_p, c_dp, c_dp, C.c_int32, c_ip, c_dp]),
     ("glome_sb_bih_dev", C.c_int32, [vp, vp, c_ip, C.c_int32, C.POINTER(C.c_float)]),
+    ("glome_sb_mesh_dev", C.c_int32, [vp, vp, c_dp, C.c_int, c_dp, C.c_int, c_ip, C.c_int, c_ip, C.c_int, C.POINTER(C.c_float)]),
     ("glome_sb_show", C.c_long, [vp, C.c_int32, C.c_char_p, C.c_long]),
     ("glome_sb_show_tex_materials", C.c_long, [vp, C.c_int32, c_ip, C.c_long]),
     ("glome_sb_load_show", C.c_int32, [vp, C.c_char_p, c_ip, C.c_int32, C.c_int32, c_ip]),

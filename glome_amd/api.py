@@ -300,6 +300,19 @@ class Context:
             raise GlomeError(f"glome_sb_bih_dev: {self.err()} (status {rc})")
         return rc, ms.value
 
+    def mesh(self, builder, verts, norms, tris, mats):
+        """`mesh` with its BVH built on this context's GPU (glome_sb_mesh_dev).  Returns (node, device milliseconds)."""
+        v = np.ascontiguousarray(np.asarray(verts, dtype=np.float64).reshape(-1, 3))
+        n = np.ascontiguousarray(np.asarray(norms, dtype=np.float64).reshape(-1, 3))
+        t = np.ascontiguousarray(np.asarray(tris, dtype=np.int32).reshape(-1, 8))
+        m = np.ascontiguousarray(np.asarray(mats, dtype=np.int32).ravel())
+        ms = C.c_float(0)
+        rc = self.lib.glome_sb_mesh_dev(self.h, builder.h, v.ctypes.data_as(L.c_dp), v.shape[0], n.ctypes.data_as(L.c_dp), n.shape[0],
+                                        t.ctypes.data_as(L.c_ip), t.shape[0], m.ctypes.data_as(L.c_ip), m.shape[0], C.byref(ms))
+        if rc < 0:
+            raise GlomeError(f"glome_sb_mesh_dev: {self.err()} (status {rc})")
+        return rc, ms.value
+
     def commit(self, builder, root):
         s = self.lib.glome_scene_commit(self.h, builder.h, int(root))
         if not s:

@@ -653,6 +653,30 @@ int32_t glome_sb_bih_dev(glome_ctx* ctx, glome_sb* sb, const int32_t* ids, int32
   catch (const std::exception& e) { ctx->err = sb->err = e.what(); return GLOME_E_INVALID; }
 }
 
+int32_t glome_sb_mesh_dev(glome_ctx* ctx, glome_sb* sb, const double* verts, int nv, const double* norms, int nn, const int32_t* tris, int nt, const int32_t* mats, int nm,
+                          float* gpu_ms) {
+  if (!ctx || !sb) { g_global_error = "null ctx or builder"; return GLOME_E_INVALID; }
+  if (gpu_ms) *gpu_ms = 0;
+  try {
+    if (nv < 0 || nn < 0 || nt < 0 || nm < 0 || (nv && !verts) || (nn && !norms) || (nt && !tris) || (nm && !mats)) throw std::invalid_argument("bad mesh arrays");
+    Graph& G = sb->graph;
+    std::vector<D3> V, N;
+    for (int k = 0; k < nv; k++) V.push_back(D3{verts[3 * k], verts[3 * k + 1], verts[3 * k + 2]});
+    for (int k = 0; k < nn; k++) N.push_back(D3{norms[3 * k], norms[3 * k + 1], norms[3 * k + 2]});
+    std::vector<MeshTri> T;
+    for (int k = 0; k < nt; k++) { const int32_t* t = tris + 8 * k; T.push_back(MeshTri{t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]}); }
+    std::vector<int> M(mats, mats + nm);
+    if (nt < 3) return G.mesh(std::move(V), std::move(N), std::move(T), std::move(M));  // a single leaf (Mesh.hs:70)
+    std::vector<Box3> tbb;
+    auto D = G.mesh_data(std::move(V), std::move(N), std::move(T), std::move(M), tbb);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::string err;
+    if (!bihdev::build_mesh(tbb, *D, ctx->stream, err, gpu_ms)) { ctx->err = sb->err = err; return GLOME_E_LIMIT; }
+    return G.mesh_node(D);
+  } catch (const scene_error& e) { ctx->err = sb->err = e.what(); return GLOME_E_SCENE; }
+  catch (const std::exception& e) { ctx->err = sb->err = e.what(); return GLOME_E_INVALID; }
+}
+
 // ---- commit ----
 glome_scene* glome_scene_commit(glome_ctx* ctx, glome_sb* sb, int32_t root) {
   if (!ctx || !sb) { g_global_error = "null ctx or builder"; return nullptr; }

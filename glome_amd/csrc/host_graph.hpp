@@ -517,7 +517,8 @@ struct Graph {
       return me;
     }
   };
-  int mesh(std::vector<D3> verts, std::vector<D3> norms, std::vector<MeshTri> tris, std::vector<int> mesh_mats) {
+  // the validated arrays, the mesh's box and the triangles' boxes -- everything of `mesh` but the tree
+  std::shared_ptr<MeshData> mesh_data(std::vector<D3> verts, std::vector<D3> norms, std::vector<MeshTri> tris, std::vector<int> mesh_mats, std::vector<Box3>& tbb) const {
     auto M = std::make_shared<MeshData>();
     int nv = (int)verts.size(), nn = (int)norms.size(), nm = (int)mesh_mats.size();
     for (auto& t : tris) {
@@ -529,13 +530,19 @@ struct Graph {
     for (int m : mesh_mats) if (m < 0 || m >= (int)mats.size()) throw std::invalid_argument("mesh: bad material id");
     M->verts = std::move(verts); M->norms = std::move(norms); M->tris = std::move(tris); M->mats = std::move(mesh_mats);
     M->bb = box_of_points(M->verts.data(), M->verts.size());  // Mesh.hs:55
-    MeshBuild B{*M, {}};
-    for (auto& t : M->tris) { D3 pts[3] = {M->verts[t.a], M->verts[t.b], M->verts[t.c]}; B.tbb.push_back(box_of_points(pts, 3)); }  // Mesh.hs:119-121
+    tbb.clear();
+    for (auto& t : M->tris) { D3 pts[3] = {M->verts[t.a], M->verts[t.b], M->verts[t.c]}; tbb.push_back(box_of_points(pts, 3)); }  // Mesh.hs:119-121
+    return M;
+  }
+  int mesh_node(std::shared_ptr<MeshData> M) { Node n; n.kind = K_MESH; n.mesh = std::move(M); return add(n); }
+  int mesh(std::vector<D3> verts, std::vector<D3> norms, std::vector<MeshTri> tris, std::vector<int> mesh_mats) {
+    std::vector<Box3> tbb;
+    auto M = mesh_data(std::move(verts), std::move(norms), std::move(tris), std::move(mesh_mats), tbb);
+    MeshBuild B2{*M, std::move(tbb)};
     std::vector<int> all(M->tris.size());
     for (size_t k = 0; k < all.size(); k++) all[k] = (int)k;
-    B.rec(all, M->bb, 0);
-    Node n; n.kind = K_MESH; n.mesh = M;
-    return add(n);
+    B2.rec(all, M->bb, 0);
+    return mesh_node(M);
   }
 
   // ---------------- materials ----------------

@@ -154,6 +154,11 @@ long glome_sb_bih_dump(glome_sb*, int32_t id, long cap, double* lsplit, double* 
  * build.  Needs the HIP half of the library (a context); the host builder stays the default and the checker. */
 int32_t glome_sb_bih_dev(glome_ctx*, glome_sb*, const int32_t* ids, int32_t n, float* gpu_ms);
 
+/* `mesh` (Mesh.hs:50-134) with its two-box BVH (build_tree, Mesh.hs:69-113) built on the GPU of `ctx`: arguments and
+ * result as glome_sb_mesh, the tree the host builder makes (boxes, leaf order). */
+int32_t glome_sb_mesh_dev(glome_ctx*, glome_sb*, const double* verts, int nv, const double* norms, int nn, const int32_t* tris, int nt, const int32_t* mats, int nm,
+                          float* gpu_ms);
+
 /* ---- commit: validate + flatten to packed SoA pools + upload to HBM ---- */
 glome_scene* glome_scene_commit(glome_ctx*, glome_sb*, int32_t root);
 void glome_scene_release(glome_scene*);

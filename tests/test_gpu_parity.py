@@ -440,6 +440,23 @@ def test_device_built_bih_of_the_flagship_terrain(gpu_ctx):
     print(f"device bih of {len(ids)} triangles: {ms:.2f} ms on the GPU, {wall * 1e3:.0f} ms wall incl. bounds, upload and tree read-back")
 
 
+@pytest.mark.parametrize("n", [12, 96])
+def test_device_built_mesh_bvh_is_the_host_builders_tree(gpu_ctx, n):
+    """N4: glome_sb_mesh_dev against glome_sb_mesh (build_tree, Mesh.hs:69-113): the `show` text spells out every box of
+    the BVH and every leaf's triangle list -- identical -- and so is the rendered frame."""
+    V = scenes.heightfield_vertices(n).reshape(-1, 3) * np.array([0.5, 1.0, 0.5])
+    idx = np.arange((n + 1) * (n + 1)).reshape(n + 1, n + 1)
+    a, b_, c, d = idx[:-1, :-1], idx[:-1, 1:], idx[1:, :-1], idx[1:, 1:]
+    tri = np.stack([np.stack([a, b_, c], -1), np.stack([c, b_, d], -1)], axis=2).reshape(-1, 3)
+    T = np.full((len(tri), 8), -1, np.int32)
+    T[:, :3] = tri
+    b = api.Builder()
+    host = b.mesh(V, np.zeros((0, 3)), T, [])
+    dev, ms = gpu_ctx.mesh(b, V, np.zeros((0, 3)), T, [])
+    assert b.show(host) == b.show(dev) and ms > 0
+    assert b.primcount(host) == b.primcount(dev) and np.array_equal(b.bound(host), b.bound(dev))
+
+
 @pytest.mark.parametrize("name", ["csg", "materials", "soup"])
 def test_scene_read_back_from_show_text_renders_the_same_frame(gpu_ctx, name):
     """N4: a scene written as `show geom` text and read back (trees as printed, materials from the side list) is the same
