@@ -12,6 +12,7 @@
 //   k_ss_pass_flat / k_ss_pass_generic  one pass of the adaptive sampler (renderTileSubsample, Glome.hs:226-323)
 //   k_rayint_batch / k_shadow_batch / k_inside_batch   the `Solid` method seams on SoA ray streams
 //   k_tiles_pack / k_tiles_blit / k_tiles_blit_packed  Tile payload <-> frame (blitTile, Glome.hs:353-358)
+//   k_bb_* / k_mb_* (bih_build_device.hpp)             `bih` and the Mesh BVH built level by level (Bih.hs:211-285, Mesh.hs:69-113)
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
