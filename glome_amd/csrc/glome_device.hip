@@ -246,9 +246,12 @@ __global__ void __launch_bounds__(64) k_render_generic(DRenderArgs A) {
 // The working buffer `v` is a dense per-tile array in global memory (tile order, row major inside a tile), so all
 // neighbour reads stay inside the tile like the reference's getc (Glome.hs:233-235); `v2` is the output.  A pass reads
 // what the previous passes wrote anywhere in the tile, hence one launch per pass.
-__device__ __forceinline__ TC ss_load(const float* v, size_t i) { const float* p = v + i * 5; return tc(p[0], p[1], p[2], p[3], p[4]); }
-__device__ __forceinline__ void ss_store(float* v, size_t i, const TC& c) { float* p = v + i * 5; p[0] = c.r; p[1] = c.g; p[2] = c.b; p[3] = c.a; p[4] = c.d; }
-__device__ __forceinline__ TC ss_getc(const float* v, const DTile& t, int dx, int dy) {  // getc: outside the tile reads blank
+// channel planes, not 5-float structs: the lanes of a block read neighbouring pixels, so a plane read is (nearly) contiguous
+struct SSBuf { float* v; size_t plane; };
+__device__ __forceinline__ TC ss_load(const SSBuf& b, size_t i) { const float* p = b.v + i; return tc(p[0], p[b.plane], p[2 * b.plane], p[3 * b.plane], p[4 * b.plane]); }
+__device__ __forceinline__ void ss_store(const SSBuf& b, size_t i, const TC& c) { float* p = b.v + i; p[0] = c.r; p[b.plane] = c.g; p[2 * b.plane] = c.b; p[3 * b.plane] = c.a; p[4 * b.plane] = c.d; }
+__device__ __forceinline__ void out5_store(float* v, size_t i, const TC& c) { float* p = v + i * 5; p[0] = c.r; p[1] = c.g; p[2] = c.b; p[3] = c.a; p[4] = c.d; }
+__device__ __forceinline__ TC ss_getc(const SSBuf& v, const DTile& t, int dx, int dy) {  // getc: outside the tile reads blank
   if (dx >= 0 && dx < t.w && dy >= 0 && dy < t.h) return ss_load(v, (size_t)t.pix_base + (size_t)dy * t.w + dx);
   return tc_blank();
 }
@@ -257,14 +260,14 @@ __device__ __forceinline__ size_t ss_out_index(const DRenderArgs& A, const DTile
 }
 __device__ __forceinline__ void ss_write_out(const DRenderArgs& A, const DTile& t, int dx, int dy, const TC& c) {
   size_t o = ss_out_index(A, t, dx, dy);
-  if (A.out5) ss_store(A.out5, o, c);
+  if (A.out5) out5_store(A.out5, o, c);
   if (A.packed) A.packed[o] = rgbf(c.r * c.a, c.g * c.a, c.b * c.a);
 }
 
 template <class TIER>
 __device__ __forceinline__ void ss_pass_loop(const DRenderArgs& A, TIER& T, int pass) {
   __shared__ uint32_t need_list[256];  // candidates of the region that need a sample: dx | dy << 8 (one wave per block)
-  float* v = A.scratch;
+  const SSBuf v{A.scratch, (size_t)A.ss_plane};
   const int lane = threadIdx.x & 63;
   const float thr = pass >= 2 ? A.thresholds[pass - 2] : 0.0f;
   int ox[4], oy[4];
@@ -899,6 +902,7 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
     if ((rc = ensure_scratch(ctx, npx * 5 * sizeof(float) + 16 * sizeof(unsigned int)))) return rc;
     A.scratch = ctx->slot().d_scratch;
     A.ss_cnt = (unsigned int*)(A.scratch + npx * 5);
+    A.ss_plane = (uint32_t)npx;
     A.blocksize = P->blocksize;
     HIPCHK(ctx, hipMemsetAsync(A.ss_cnt, 0, 16 * sizeof(unsigned int), ctx->stream));
     bool pooled = ctx->timing && (ctx->timing_seen++ % ctx->timing_stride) == 0 && ctx->pool_used + 2 <= (int)ctx->pool.size();

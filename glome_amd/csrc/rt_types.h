@@ -111,6 +111,7 @@ struct DRenderArgs {
   int32_t dense;       // 1: out5 is a dense tile payload (tile order, row major inside a tile) instead of a frame
   float* scratch;      // adaptive sampler: dense per-tile working buffer `v` (owned pixels * 5 floats)
   unsigned int* ss_cnt;  // adaptive sampler: [8 + pass] work-queue head of the pass
+  uint32_t ss_plane;     // adaptive sampler: pixels per channel plane of the working buffer `scratch` (r | g | b | a | depth planes)
   int32_t blocksize;     // adaptive sampler: tile edge (<= 65); work items are laid out for full-size tiles
   float* out5;         // width*height*5
   uint32_t* packed;    // width*height or null
