@@ -10,6 +10,8 @@ timeout -k 10 300 python bench.py > $out/bench_S3.json 2> $out/bench_S3.err || e
 tools/pmc_pass.sh $out/pmc "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVES" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum" "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES" || exit 1
 python tools/pmc_summary.py $out/pmc > $out/pmc_summary.json
 GPU_MAX_HW_QUEUES=8 timeout -k 10 600 python tools/shard_timing.py > $out/shard_timing.log 2>&1
+GPU_MAX_HW_QUEUES=8 WORK_TILES=64,64 timeout -k 10 600 python tools/shard_balance.py > $out/shard_balance.log 2>&1
+timeout -k 10 300 python tools/bih_build_timing.py > $out/bih_build.log 2>&1
 root=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $root/$out/prof --output-format csv -- python3 $root/bench.py --steps 200 --warmup 20 --no-cpu > $root/$out/prof.log 2>&1
