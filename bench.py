@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--time-every", type=int, default=1, help="HIP-event pair on every k-th launch of the timed region (roofline kernel time)")
     ap.add_argument("--host-build", action="store_true", help="build the BIH with the host builder (glome_sb_bih) instead of on the GPU")
     ap.add_argument("--force-dist", action="store_true", help="one GPU, but through the multi-GPU pipeline with a one-rank RCCL group (rehearsal)")
-    ap.add_argument("--group", type=int, default=0, help="frames per launch (and per RCCL gather); default 4 on one or two GPUs, 8 on more")
+    ap.add_argument("--group", type=int, default=0, help="frames per launch (and per RCCL gather); default by rank count and run length (up to 4 on one or two GPUs, 8 on more)")
     ap.add_argument("--product", default="packed", choices=["packed", "rgbad"],
                     help="what a frame is: GlomeView's framebuffer of packed 0x00RRGGBB pixels (blitTile; 4 B/pixel cross xGMI) "
                          "or the float (r,g,b,a,depth) tuples (20 B/pixel)")
@@ -96,9 +96,19 @@ def main():
     P = api.render_params(width=W, height=H, maxdepth=maxdepth, mode=args.mode)
 
     if args.group <= 0:
-        # frames per launch: deep batches pay a fill / drain of about one launch per run, so short runs get shallow ones
-        gmax = 8 if world > 2 else 4
-        args.group = 1 if (args.mode != 0 or args.product != "packed") else max(1, min(gmax, args.steps // 24))
+        # frames per launch (and per gather).  Deep batches pay a fill / drain of about one launch per run, so short runs get
+        # shallower ones; the break-even points are measured (tools/short_run_groups.py, profiles/r01_l_short_run_groups.log):
+        # at 8 ranks a 20-step run takes 0.091 ms per step with one frame per launch and 0.052 with four.
+        if args.mode != 0 or args.product != "packed":
+            args.group = 1
+        elif world == 1:
+            args.group = max(1, min(4, args.steps // 24))
+        elif world == 2:
+            args.group = 1 if args.steps < 8 else 4
+        elif world <= 4:
+            args.group = 2 if args.steps < 16 else 8
+        else:
+            args.group = 4 if args.steps < 40 else 8
     sf = dist.ShardedFrame(scene, P, rank, world, device, lanes=args.lanes, product=args.product, group=args.group, force_pipeline=args.force_dist)
 
     def barrier():
