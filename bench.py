@@ -104,7 +104,7 @@ def main():
         elif world == 1:
             args.group = max(1, min(4, args.steps // 24))
         elif world == 2:
-            args.group = 1 if args.steps < 8 else 4
+            args.group = 1 if args.steps < 8 else (4 if args.steps < 64 else 8)
         elif world <= 4:
             args.group = 2 if args.steps < 16 else 8
         else:
@@ -126,6 +126,7 @@ def main():
         rays = [st["rays_primary"], st["rays_shadow"], st["rays_secondary"]]
     rays_per_step = sum(rays)
 
+    sf.prime(cam, lights)  # every lane's slot / stream / kernel instance exists before the warm-up (initialisation, not steps)
     for _ in range(args.warmup):
         sf.step(cam, lights)
     sf.flush()

@@ -250,6 +250,15 @@ class ShardedFrame:
                 raise api.GlomeError("render: " + self.ctx.err())
         self.last = (slot, len(views) - 1)
 
+    def prime(self, cam, lights):
+        """Initialisation, not work: one full group through every lane, so that each lane's context slot (counters, queue,
+        overflow and tile tables), stream and kernel instances exist before anything is timed.  Without it a run shorter
+        than lanes x group frames pays those first uses inside its timed steps."""
+        for _ in range(self.n * self.G):
+            self.step(cam, lights)
+        self.flush()
+        self.torch.cuda.synchronize(self.device)
+
     def step(self, cam, lights, stats=False):
         """One frame (the view `cam`; the lights are shared by the frames of a group).  stats=True renders it alone (no
         overlap) and returns this rank's stats dict (it synchronises)."""

@@ -28,6 +28,7 @@ for world in (8, 4, 2):
                     gathered[0].copy_(payload)
                     return _Done()
                 sf.plan.gather = fake
+                sf.prime(cam, lights)
                 for i in range(W):
                     sf.step(cam, lights)
                 sf.flush(); torch.cuda.synchronize()
