@@ -6,8 +6,8 @@ for spec in "S1 0" "S2 0" "S2 1" "S3 0" "S3mesh 0" "S4 0" "S3 1"; do
   timeout -k 10 300 python bench.py --scene $1 --mode $2 --steps 400 --warmup 40 > gpurun_out/configs/$1_mode$2.json 2> gpurun_out/configs/$1_mode$2.err || echo "FAILED $1 $2"
   tail -c 400 gpurun_out/configs/$1_mode$2.err | grep -v amdgpu.ids | tail -2
 done
-timeout -k 10 500 python bench.py --scene S5 --mode 1 --steps 30 --warmup 5 --no-cpu > gpurun_out/configs/S5_mode1.json 2> gpurun_out/configs/S5_mode1.err || echo "FAILED S5"
-timeout -k 10 300 python bench.py --scene S5 --mode 0 --steps 30 --warmup 5 --no-cpu > gpurun_out/configs/S5_mode0.json 2> gpurun_out/configs/S5_mode0.err || echo "FAILED S5 tile"
+timeout -k 10 500 python bench.py --scene S5 --mode 1 --steps 100 --warmup 10 --no-cpu > gpurun_out/configs/S5_mode1.json 2> gpurun_out/configs/S5_mode1.err || echo "FAILED S5"
+timeout -k 10 300 python bench.py --scene S5 --mode 0 --steps 200 --warmup 20 --no-cpu > gpurun_out/configs/S5_mode0.json 2> gpurun_out/configs/S5_mode0.err || echo "FAILED S5 tile"
 python - <<'PY'
 import json, glob
 for f in sorted(glob.glob("gpurun_out/configs/*.json")):
