@@ -342,12 +342,12 @@ __global__ void __launch_bounds__(64, LB) k_ss_pass_flat(DRenderArgs A, int pass
   extern __shared__ uint32_t lds[];
   FlatTier<false, false, FULL, CLS> T{A.S, A.lights, A.nlights, lane_stack<TWO_ROWS>(lds, stack_cap, ovf, ovf_cap), Cnt()};
   ss_pass_loop(A, T, pass);
-  flush_counters(A.counters, T.cnt, 0);
+  if (A.want_counters) flush_counters(A.counters, T.cnt, 0);
 }
 __global__ void __launch_bounds__(64) k_ss_pass_generic(DRenderArgs A, int pass) {
   GenericTier T{A.S, A.lights, A.nlights, Cnt()};
   ss_pass_loop(A, T, pass);
-  flush_counters(A.counters, T.cnt, T.err);
+  if (A.want_counters) flush_counters(A.counters, T.cnt, T.err);
 }
 
 // ------------------------------------------------------------------------------------------------ batch seams
@@ -894,7 +894,7 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
   const bool bare = !stats && P->mode == GLOME_MODE_TILE && !P->faithful && !P->count_work && ctx->slot().work_base < 0x70000000u;
   if (!bare && (rc = reset_counters(ctx))) return rc;
   A.work_base = ctx->slot().work_base;
-  A.want_counters = bare ? 0 : 1;
+  A.want_counters = (bare || (P->mode == GLOME_MODE_SUBSAMPLE && !stats)) ? 0 : 1;  // nobody reads them without `stats`
   hipEvent_t ev_start = ctx->ev0, ev_stop = ctx->ev1;
   if (A.ntiles > 0 && P->mode == GLOME_MODE_SUBSAMPLE) {
     // scratch: v (5 floats per owned pixel) | 16 counters (per-pass queue heads)
