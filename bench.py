@@ -8,14 +8,26 @@ A step = one frame: every pixel's primary ray + its shadow rays through the hot 
 shadow any-hit -> shade), scene resident in HBM.  With N GPUs the frame's 65x65 reference tiles are sharded round-robin
 and gathered to rank 0 with one RCCL gather (strong scaling: the frame is fixed).  Rank 0 prints ONE JSON line.
 
-The line carries `roofline` (dominant kernel vs the 8 TB/s HBM roofline, algorithmic bytes per SURVEY.md 8(d), kernel
-time from HIP events recorded on the launch stream over the timed region) and `cpu_baseline` (the CPU oracle -- a C++
-restatement of the reference algorithm, kind "port" -- timed on this box's host cores on a bounded tile sample).
+The line carries `roofline` and `cpu_baseline`.
+
+roofline: the dominant kernel is a cache-resident tree walk, not a stream, so one number against HBM peak says little.  The
+line therefore reports one fraction PER CEILING -- HBM / fabric bytes, L2 requests, scalar-unit issue, vector issue -- from
+the counters of a committed `rocprofv3 --pmc` pass over the SAME launch shape (profiles/<round>_pmc_<scene>.json, made by
+tools/pmc_roofline.py) and the duration of that launch measured live here with HIP events on the launch stream, launches
+NOT overlapped (one in flight, 8 frames each: enough work to fill the GPU).  `bound` names the highest ceiling; `frac` is
+its fraction (<= 1).  SURVEY.md 8(d)'s algorithmic byte model stays as a labelled side figure (`model`): it charges every
+ray for every node a CPU would fetch, while a wave fetches a node once for its 64 rays.
+
+cpu_baseline: the CPU oracle -- a C++ restatement of the reference algorithm, kind "port" -- timed on this box's host
+cores on the same frame.
 """
 import argparse
 import ctypes as C
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -45,6 +57,17 @@ def main():
                          "or the float (r,g,b,a,depth) tuples (20 B/pixel)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: start the N ranks ourselves, as fresh child processes, BEFORE this process makes any GPU
+        # call (it never does: it only waits and passes the children's output and exit code on)
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), GLOME_BENCH_SELF_LAUNCHED="1")
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
     # the frames in flight run on separate HIP streams; give them separate hardware queues (the runtime's default is 4,
     # which makes the frame period depend on how the streams happen to share queues)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
@@ -57,8 +80,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible (there is no CPU path to time)")
     torch.cuda.set_device(local)
@@ -155,48 +177,105 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = rays_per_step / (elapsed / args.steps) / 1e6
 
-    # ---- roofline of the dominant kernel (rank 0's render launch) ----
-    # algorithmic bytes: 32 B ray in + 32 B hit out per closest-hit ray, 32 + 4 per shadow ray,
-    # 16 B per BIH node visited, S_prim per primitive tested (48 B triangle, 16 B sphere); node / primitive visits are
-    # the reference algorithm's (no early-out, rayint_debug convention, Bih.hs:378-412), counted by the faithful kernel
-    # on this very frame (tests pin those counts to the CPU oracle's).
-    Pl = dist._clone_params(P, tile_first=(rank if world > 1 else 0), tile_stride=world)
+    # ---- the dominant kernel alone: launch duration and single-frame latency (HIP events on the launch stream) ----
+    # One launch in flight at a time (the timed region above overlaps several, so a launch's own duration there is longer
+    # than its share of the GPU).  G_lone frames per launch: enough work items to fill every CU many times over.
+    la = (L.Light * max(1, len(lights)))(*lights)
     ctx.lib.glome_ctx_use_slot(ctx.h, None, 0)
+    torch.cuda.synchronize(device)
+
+    def lone_launches(nframes, reps):
+        """ms per launch of `reps` launches carrying `nframes` frames of this rank's tiles each, never overlapped"""
+        cams = (L.Camera * nframes)(*([cam] * nframes))
+        if args.mode != 0:  # the adaptive sampler renders one frame per call: float tuples, five pass kernels
+            buf = torch.zeros((H, W, 5), dtype=torch.float32, device=device)
+            call = lambda: ctx.lib.glome_render_dev(scene.h, C.byref(cam), la, len(lights), C.byref(sf.P_local), C.c_void_p(buf.data_ptr()), None, None)
+        elif world == 1:
+            buf = torch.zeros((nframes, H, W), dtype=torch.int32, device=device)
+            call = lambda: ctx.lib.glome_render_packed_batch_dev(scene.h, cams, nframes, la, len(lights), C.byref(sf.P), C.c_void_p(buf.data_ptr()), H * W, None)
+        else:
+            buf = torch.zeros(nframes * sf.plan.maxp, dtype=torch.int32, device=device)
+            call = lambda: ctx.lib.glome_render_tiles_packed_batch_dev(scene.h, cams, nframes, la, len(lights), C.byref(sf.P_local), C.c_void_p(buf.data_ptr()), sf.plan.maxp, None)
+        for _ in range(2):
+            if call() != 0:
+                raise SystemExit("lone launch: " + ctx.err())
+            ctx.synchronize()
+        ctx.lib.glome_ctx_timing_begin(ctx.h, reps)
+        for _ in range(reps):
+            if call() != 0:
+                raise SystemExit("lone launch: " + ctx.err())
+            ctx.synchronize()
+        out = np.zeros(reps, np.float32)
+        n = ctx.lib.glome_ctx_timing_end(ctx.h, out.ctypes.data_as(L.c_fp), reps)
+        return [float(x) for x in out[:n]]
+
+    G_lone = 8 if args.mode == 0 else 1
+    ctx.lib.glome_ctx_set_grid_per_cu(ctx.h, 32)  # a launch on its own takes every wave slot its registers / LDS allow
+    lone_ms = lone_launches(G_lone, 12)
+    one_ms = lone_launches(1, 12) if G_lone != 1 else lone_ms
+    ctx.lib.glome_ctx_set_grid_per_cu(ctx.h, 0)
+    kernel_ms = float(np.median(lone_ms))
+    kernel_s = kernel_ms * 1e-3
+    latency = {"single_frame_ms": round(float(np.median(one_ms)), 4), "lone_launch_ms": round(kernel_ms, 4), "lone_launch_frames": G_lone,
+               "ms_per_frame_in_a_lone_launch": round(kernel_ms / G_lone, 4), "pipelined_ms_per_frame": round(ms_per_step, 4),
+               "note": "value / ms_per_step are pipelined throughput (launches_in_flight x frames_per_launch independent frames in flight); single_frame_ms is one frame alone on an idle GPU"}
+
+    # ---- SURVEY.md 8(d)'s byte model, kept as a labelled side figure ----
+    # 32 B ray in + 32 B hit out per closest-hit ray, 32 + 4 per shadow ray, 16 B per BIH node visited (64 B per Mesh
+    # node), S_prim per primitive tested (48 B triangle, 16 B sphere); visits as the reference algorithm makes them per
+    # ray (no early-out, rayint_debug convention, Bih.hs:378-412), counted by the faithful kernel on this very frame and
+    # these very tiles (sf.P_local; tests pin the counts to the CPU oracle's).
     tmp = torch.zeros((H, W, 5), dtype=torch.float32, device=device)
     torch.cuda.synchronize(device)
-    Pf = dist._clone_params(Pl, faithful=1, count_work=1)
-    stf = scene.render_dev(cam, lights, Pf, tmp.data_ptr())
-    Pc = dist._clone_params(Pl, faithful=0, count_work=1)
-    stc = scene.render_dev(cam, lights, Pc, tmp.data_ptr())
+    stf = scene.render_dev(cam, lights, dist._clone_params(sf.P_local, faithful=1, count_work=1), tmp.data_ptr())
+    stc = scene.render_dev(cam, lights, dist._clone_params(sf.P_local, faithful=0, count_work=1), tmp.data_ptr())
+    del tmp
     s_prim = 48 if info["n_triangles"] >= info["n_spheres"] else 16
-    node_b = 64 if info["n_mesh_nodes"] > info["n_bih_nodes"] else 16
 
-    def algo_bytes(s):
-        return (s["rays_primary"] + s["rays_secondary"]) * 64 + s["rays_shadow"] * 36 + (s["bih_nodes"] * 16 + s["mesh_nodes"] * 64) + s["prim_tests"] * s_prim
+    def algo_bytes(s_):
+        return (s_["rays_primary"] + s_["rays_secondary"]) * 64 + s_["rays_shadow"] * 36 + (s_["bih_nodes"] * 16 + s_["mesh_nodes"] * 64) + s_["prim_tests"] * s_prim
 
-    kavg_ms = float(np.mean(kms[:nk])) if nk > 0 else float("nan")
-    bytes_ref = algo_bytes(stf) * sf.G  # a launch carries sf.G frames of this rank's tiles
-    achieved = bytes_ref / (kavg_ms * 1e-3) / 1e9
-    traffic = None
-    pmc = os.path.join(HERE, "profiles", "pmc_traffic.json")  # written from a separate rocprofv3 --pmc run (profiles/README.md)
-    if os.path.exists(pmc):
+    rays_local_n = max(1, stf["rays_primary"] + stf["rays_shadow"] + stf["rays_secondary"])
+    model = {"what": "SURVEY.md 8(d) algorithmic bytes: every ray charged for every node / primitive the reference's per-ray traversal fetches; NOT bytes this kernel moves (a wave fetches a node once for its 64 rays, from L2)",
+             "bytes_per_launch": int(algo_bytes(stf)) * G_lone, "bytes_per_frame": int(algo_bytes(stf)),
+             "per_ray": {"nodes": round((stf["bih_nodes"] + stf["mesh_nodes"]) / rays_local_n, 2), "prims": round(stf["prim_tests"] / rays_local_n, 2)},
+             "bytes_per_frame_early_out_visits": int(algo_bytes(stc)),
+             "GBs_over_lone_launch": round(algo_bytes(stf) * G_lone / kernel_s / 1e9, 1)}
+
+    # ---- per-ceiling fractions from the committed counter pass of this launch shape ----
+    _, cus, _ = ctx.device_info()
+    kname = ("k_ss_pass_*" if args.mode != 0 else "k_render_flat") if info["tier"] == 0 else ("k_ss_pass_generic" if args.mode != 0 else "k_render_generic")
+    roofline = {"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None, "kernel": kname, "kernel_ms": round(kernel_ms, 4),
+                "kernel_ms_all": [round(x, 4) for x in lone_ms], "launch_shape": f"1 launch in flight, {G_lone} frame(s) per launch, rank 0's tiles", "ceilings": None,
+                "pmc_source": None, "model": model}
+    cands = sorted(glob.glob(os.path.join(HERE, "profiles", f"r*_pmc_{args.scene}_mode{args.mode}.json")))
+    if cands and world == 1:
         try:
-            per_frame = json.load(open(pmc)).get(args.scene, {}).get("hbm_bytes_per_frame")
-            traffic = int(per_frame * sf.G) if per_frame else None  # per launch, like `achieved`
-        except Exception:
-            traffic = None
-    roofline = {
-        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-        "traffic": traffic,
-        "kernel": "k_render_flat" if info["tier"] == 0 else "k_render_generic", "kernel_ms_avg": round(kavg_ms, 4), "launches_timed": int(nk),
-        "algorithmic_bytes_per_launch": int(bytes_ref),
-        "per_ray": {"nodes": round((stf["bih_nodes"] + stf["mesh_nodes"]) / max(1, sum(rays) // world), 2), "prims": round(stf["prim_tests"] / max(1, sum(rays) // world), 2)},
-        "visited_bytes_per_launch_early_out": int(algo_bytes(stc)) * sf.G, "frames_per_launch": sf.G, "timed": f"every {max(1, args.time_every)}th launch of the timed region",
-        "frac_of_measured_copy_ceiling_6290GBs": round(achieved / 6290.0, 4),
-        # with several frames in flight the launches overlap, so each launch's own duration (above) is longer than the
-        # frame period; the same bytes over the measured frame period:
-        "effective_GBs_over_frame_period": round(bytes_ref / sf.G / (ms_per_step * 1e-3) / 1e9, 1),
-    }
+            pm = json.load(open(cands[-1]))
+            cn = pm["counters"]
+            sc_ = G_lone / float(pm["frames_per_launch"])  # counts are proportional to the frames a launch carries
+            clock_hz = float(pm["clock_ghz"]) * 1e9
+            cyc = kernel_s * clock_hz  # cycles of one CU over the launch
+            hbm_bytes = (cn["FETCH_SIZE"] * 2.0 + cn["WRITE_SIZE"]) * 1024.0 * sc_  # KiB; gfx950 FETCH_SIZE reads half (MI355X_MICROARCH.md, HBM)
+            l2_bytes = cn["TCC_REQ_sum"] * 128.0 * sc_                               # an upper bound: every request priced as a full 128-B line
+            sal = (cn["SQ_INSTS_SALU"] + cn["SQ_INSTS_SMEM"]) * sc_
+            ceil = {
+                "hbm": {"achieved": round(hbm_bytes / kernel_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_bytes / kernel_s / 1e9 / HBM_PEAK_GBS, 4),
+                        "note": "fabric-side bytes (FETCH_SIZE x 2 + WRITE_SIZE); Infinity-Cache hits included, so true HBM traffic is at most this"},
+                "l2": {"achieved": round(l2_bytes / kernel_s / 1e9, 1), "peak": 34500.0, "unit": "GB/s", "frac": round(l2_bytes / kernel_s / 1e9 / 34500.0, 4)},
+                "scalar_issue": {"achieved": round(sal / (cus * cyc), 4), "peak": 1.0, "unit": "scalar (SALU + SMEM) instructions per cycle per CU", "frac": round(sal / (cus * cyc), 4),
+                                 "branch_per_cycle_per_cu": round(cn["SQ_INSTS_BRANCH"] * sc_ / (cus * cyc), 4)},
+                "valu_issue": {"achieved": round(cn["SQ_INSTS_VALU"] * sc_ / (cus * cyc), 4), "peak": 2.0, "unit": "wave64 vector instructions per cycle per CU (4 SIMD-32, 2 cycles each)",
+                               "frac": round(cn["SQ_INSTS_VALU"] * sc_ / (cus * cyc) / 2.0, 4)},
+            }
+            top = max(ceil, key=lambda k: ceil[k]["frac"])
+            roofline.update({"bound": top, "achieved": ceil[top]["achieved"], "peak": ceil[top]["peak"], "unit": ceil[top]["unit"], "frac": ceil[top]["frac"],
+                             "traffic": int(hbm_bytes), "ceilings": ceil, "clock_ghz": pm["clock_ghz"],
+                             "wave_wait_frac": round(cn["SQ_WAIT_ANY"] / cn["SQ_WAVE_CYCLES"], 4) if cn.get("SQ_WAVE_CYCLES") else None,
+                             "pmc_source": os.path.relpath(cands[-1], HERE), "pmc_kernel_ms": pm.get("kernel_ms"),
+                             "note": "counters per launch from the committed rocprofv3 --pmc passes of this launch shape; duration measured live (HIP events); cycles = duration x the clock the counter passes measured"})
+        except Exception as e:  # a malformed profile must not void the bench line
+            roofline["pmc_error"] = repr(e)
 
     # ---- cpu_baseline: the oracle on a bounded sample of the same frame (every 4th tile), all host cores ----
     cpu = None
@@ -243,7 +322,7 @@ def main():
                    "width": W, "height": H, "rays_per_frame": {"primary": rays[0], "shadow": rays[1], "secondary": rays[2]},
                    "sampling": "renderTile, 1 primary ray/pixel" if args.mode == 0 else "renderTileSubsample (adaptive, 1/8..2 primary rays/pixel)", "launches_in_flight": sf.n, "frames_per_launch": sf.G, "frame_product": "packed 0x00RRGGBB framebuffer (trace + blitTile fused, 4 B/pixel)" if args.product == "packed" else "float (r,g,b,a,depth) per pixel, 20 B/pixel", "tiles": f"{'64x64 work' if args.mode == 0 else '65x65 reference'} tiles, round-robin over ranks; a launch renders a rank's tiles of {sf.G} frames, one RCCL gather to rank 0 per launch, overlapped with the next launch" if (world > 1 or args.force_dist) else ("65x65 reference tile map, one GPU; a whole renderTile frame is cut into 64x64 work tiles (same pixels, no leftover strips)" if args.mode == 0 else "65x65 reference tiles, one GPU"),
                    "scene_setup_s": round(setup_s, 2), "bih_build": "host" if args.host_build else "device (glome_sb_bih_dev / glome_sb_mesh_dev) for lists of 4096+ objects", "device_bytes": info["device_bytes"]},
-        "roofline": roofline, "cpu_baseline": cpu,
+        "roofline": roofline, "latency": latency, "cpu_baseline": cpu, "rccl_ranks": world if dist_on else 0,
     }
     print(json.dumps(out), flush=True)
     if dist_on:

@@ -52,6 +52,9 @@ class Flattener {
     if (F.tier == 0 && F.max_bih_depth > kFlatStack) { F.tier = 1; F.why_generic = "BIH deeper than the LDS stack"; }
     if (F.tier == 0 && F.max_mesh_depth > kFlatStack) { F.tier = 1; F.why_generic = "Mesh BVH deeper than the LDS stack"; }
     if (F.tier != 0) F.entries.clear();
+    // the generic tier walks BIHs / Mesh BVHs with a fixed scratch stack per level: a deeper tree is refused, not truncated
+    if (F.tier != 0 && std::max(F.max_bih_depth, F.max_mesh_depth) > kGenericStack)
+      throw limit_error("BIH / Mesh tree deeper than the device traversal stack (" + std::to_string(std::max(F.max_bih_depth, F.max_mesh_depth)) + " > " + std::to_string(kGenericStack) + ")");
     pad();
   }
 

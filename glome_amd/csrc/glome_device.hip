@@ -348,6 +348,7 @@ __global__ void __launch_bounds__(64) k_ss_pass_generic(DRenderArgs A, int pass)
   GenericTier T{A.S, A.lights, A.nlights, Cnt()};
   ss_pass_loop(A, T, pass);
   if (A.want_counters) flush_counters(A.counters, T.cnt, T.err);
+  else if (__builtin_amdgcn_ballot_w64(T.err != 0) && (threadIdx.x & 63) == 0) atomicOr(&A.counters->error, 1u);
 }
 
 // ------------------------------------------------------------------------------------------------ batch seams
@@ -467,12 +468,14 @@ struct glome_ctx {
     // value of d_counters->next_work once the launches queued on this slot have run: a render launch that needs no
     // statistics does not reset the counters, it takes its work items relative to this base (one stream packet per frame)
     uint32_t work_base = 0;
+    bool launched = false;  // a render launch went out on this slot since its error word was last polled
   };
   static constexpr int kSlots = 8;
   Slot slots[kSlots];
   int cur = 0;
   Slot& slot() { return slots[cur]; }
   std::string err;
+  int grid_per_cu = 0;  // 0: persistent grids sized by work (tuned for several launches in flight); > 0: this many waves per CU, resources permitting
   // tile tables cached per (w, h, blocksize, first, stride)
   // lut[w >> 6] = the tile that holds work item (w & ~63): the kernel's item -> tile lookup is one table read and a step or two
   struct TileTable { std::vector<DTile> host; DTile* dev = nullptr; uint32_t* lut = nullptr; uint32_t total_waves = 0; int64_t pixels = 0; };
@@ -593,6 +596,11 @@ int glome_ctx_use_slot(glome_ctx* c, void* stream, int slot) {
   c->cur = slot;
   return 0;
 }
+int glome_ctx_set_grid_per_cu(glome_ctx* c, int waves_per_cu) {
+  if (!c || waves_per_cu < 0 || waves_per_cu > 32) return GLOME_E_INVALID;
+  c->grid_per_cu = waves_per_cu;
+  return 0;
+}
 int glome_ctx_timing_begin(glome_ctx* c, int max_launches) {
   if (!c || max_launches <= 0) return GLOME_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
@@ -614,15 +622,24 @@ int glome_ctx_timing_begin_sampled(glome_ctx* c, int max_launches, int stride) {
 int glome_ctx_timing_end(glome_ctx* c, float* ms_out, int cap) {
   if (!c) return GLOME_E_INVALID;
   c->timing = false;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
   int n = c->pool_used / 2;
-  for (int i = 0; i < n && i < cap; i++) HIPCHK(c, hipEventElapsedTime(&ms_out[i], c->pool[2 * i], c->pool[2 * i + 1]));
+  // the pairs were recorded on whichever lane stream launched (up to kSlots of them): wait on each stop event itself
+  for (int i = 0; i < n && i < cap; i++) {
+    HIPCHK(c, hipEventSynchronize(c->pool[2 * i + 1]));
+    HIPCHK(c, hipEventElapsedTime(&ms_out[i], c->pool[2 * i], c->pool[2 * i + 1]));
+  }
   return n;
 }
+static int poll_device_error(glome_ctx* ctx, glome_ctx::Slot& sl);
 int glome_ctx_synchronize(glome_ctx* c) {
   if (!c) return GLOME_E_INVALID;
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  return 0;
+  // limits hit by launches nobody asked statistics of; lanes on the caller's own streams are the caller's to synchronise
+  // first (an error raised by a launch still in flight is reported by the next call)
+  int rc = 0;
+  for (auto& sl : c->slots)
+    if (sl.launched) { sl.launched = false; int r = poll_device_error(c, sl); if (r) rc = r; }
+  return rc;
 }
 int glome_ctx_device_info(glome_ctx* c, char* name, int cap, int* cu_count, int* warp_size) {
   if (!c) return GLOME_E_INVALID;
@@ -758,7 +775,8 @@ static int persistent_grid(glome_ctx* ctx, size_t lds_per_block, uint32_t total_
   int per_cu = max_per_cu;  // wave slots per CU the kernel's register budget allows
   if (lds_per_block) per_cu = std::min<int>(per_cu, (int)(160 * 1024 / lds_per_block));
   per_cu = std::max(per_cu, 1);
-  if (min_per_cu > 0) {  // sized by work: ~64 items per wave, not below min_per_cu waves per CU
+  if (ctx->grid_per_cu > 0) per_cu = std::min(per_cu, ctx->grid_per_cu);  // glome_ctx_set_grid_per_cu: the caller knows what else runs
+  else if (min_per_cu > 0) {  // sized by work: ~64 items per wave, not below min_per_cu waves per CU
     long want = ((long)total_work + 64L * cus - 1) / (64L * cus);
     per_cu = (int)std::min<long>(per_cu, std::max<long>(min_per_cu, want));
   }
@@ -787,15 +805,23 @@ static int ensure_scratch(glome_ctx* ctx, size_t need) {
   sl.scratch_bytes = need;
   return 0;
 }
-static int check_device_error(glome_ctx* ctx) {
-  DCounters c;
-  HIPCHK(ctx, hipMemcpy(&c, ctx->slot().d_counters, sizeof(c), hipMemcpyDeviceToHost));
-  if (c.error) { ctx->err = "device-side limit hit (traversal stack or CSG advance cap)"; return GLOME_E_LIMIT; }
-  return 0;
+// The device-side error word is sticky: kernels only ever OR into it, the counter reset leaves it alone, and it is read --
+// and cleared -- where the host waits anyway (statistics, the host-buffer seams, glome_ctx_synchronize).  So a launch
+// that nobody asked statistics of (the pipelined frame path) still reports a CSG-advance or frame-pool limit, at the
+// next synchronize.  The caller has synchronised the slot's stream.
+static int poll_device_error(glome_ctx* ctx, glome_ctx::Slot& sl) {
+  unsigned int e = 0;
+  unsigned int* d = &sl.d_counters->error;
+  HIPCHK(ctx, hipMemcpy(&e, d, sizeof(e), hipMemcpyDeviceToHost));
+  if (!e) return 0;
+  HIPCHK(ctx, hipMemset(d, 0, sizeof(e)));
+  ctx->err = "device-side limit hit (traversal stack or CSG advance cap)";
+  return GLOME_E_LIMIT;
 }
+static int check_device_error(glome_ctx* ctx) { return poll_device_error(ctx, ctx->slot()); }
 
 static int reset_counters(glome_ctx* ctx) {
-  HIPCHK(ctx, hipMemsetAsync(ctx->slot().d_counters, 0, sizeof(DCounters), ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->slot().d_counters, 0, offsetof(DCounters, error), ctx->stream));  // not the sticky error word
   ctx->slot().work_base = 0;
   return 0;
 }
@@ -956,8 +982,12 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
     stats->bih_nodes = c.bih_nodes; stats->mesh_nodes = c.mesh_nodes; stats->prim_tests = c.prim_tests;
     if (A.ntiles > 0) HIPCHK(ctx, hipEventElapsedTime(&stats->kernel_ms, ev_start, ev_stop));
     stats->n_tiles = A.ntiles; stats->n_pixels = (int32_t)tt->pixels;
-    if (c.error) { ctx->err = "device-side limit hit (traversal stack or CSG advance cap)"; return GLOME_E_LIMIT; }
-  }
+    ctx->slot().launched = false;
+    if (c.error) {
+      HIPCHK(ctx, hipMemset(&ctx->slot().d_counters->error, 0, sizeof(unsigned int)));
+      ctx->err = "device-side limit hit (traversal stack or CSG advance cap)"; return GLOME_E_LIMIT;
+    }
+  } else if (A.ntiles > 0) ctx->slot().launched = true;
   return 0;
 }
 

@@ -911,11 +911,27 @@ GD bool bih_tri_wave(const DScene& S, uint32_t hdr, const Ray& r, float d, bool 
   F4 h0 = ld4u(S.bihhdr, 3 * hdr), h1 = ld4u(S.bihhdr, 3 * hdr + 1);
   const uint32_t delta = uni(as_u(ld4u(S.bihhdr, 3 * hdr + 2).x));
   const uint32_t ref = uni(as_u(h0.w));
-  if (ref & BREF_LEAF) return valid ? bih_tri<MODE, COUNT, LEAFK>(S, hdr, r, d, stk, cnt, best_t, best_rec) : false;  // a one-leaf tree
   const V3 rcp = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
   float nearv, farv;
   bbclip_ub(r, v3(h0), v3(h1), nearv, farv);
   farv = gminf(d, farv);  // `traverse root near (fmin d far)`, Bih.hs:368
+  if (ref & BREF_LEAF) {
+    // A one-leaf tree: `rayint [s] r far` over its items (Bih.hs:339), per lane.  Nothing is pushed -- the kernels that
+    // keep only two stack rows per entry (lane_stack<TWO_ROWS>) rely on that; bih_tri's continuation entries for leaves
+    // of more than six items would land on a row they do not have.  The count is wave-uniform.
+    uint32_t count = (ref >> 26) & 7u, first = ref & BREF_FIRST;
+    if (count == 7u) { F4 ln = ld4u(S.bihnodes, first); count = uni(as_u(ln.z)); first = uni(as_u(ln.w)); }
+    if (!valid || (MODE != 0 && nearv > farv)) return false;  // a root leaf is tested regardless of its interval (Bih.hs:339), which only matters when nothing clips `far`
+    bool occ1 = false;
+    for (uint32_t k = 0; k < count; k++) {
+      float t;
+      if (COUNT) cnt.prim++;
+      bool hit = leaf_item_test(S, LEAFK, MODE == 2, first + delta + k, r, farv, t);
+      if (MODE == 2) { if (hit) { occ1 = true; break; } }
+      else if (hit && !(best_t < t)) { best_t = t; best_rec = first + k; if (MODE == 1) farv = gminf(farv, t); }
+    }
+    return occ1;
+  }
   if (COUNT) { if (valid && nearv > farv) cnt.bih++; }  // a root branch entered with an empty interval is counted and left (Bih.hs:343)
   // Children are taken near-first by the signs of the ray direction, so one packet needs one sign pattern.  Almost
   // every wave has a single pattern; a block straddling an axis plane through the eye has two or four, and is walked

@@ -63,6 +63,10 @@ int glome_ctx_timing_begin(glome_ctx*, int max_launches);
  * launch stream and cost frame rate when a frame is a fraction of a millisecond. */
 int glome_ctx_timing_begin_sampled(glome_ctx*, int max_launches, int stride);
 int glome_ctx_timing_end(glome_ctx*, float* ms_out, int cap);
+/* Waves per CU of the persistent render launches.  0 (default): sized by the launch's work, for several launches in flight
+ * on separate slots (each takes a share of the CUs' wave slots); n > 0: n per CU, resources permitting -- what a launch
+ * that runs ALONE wants (24 for the packet instances).  The reference has no such knob (GHC's +RTS -N is the nearest). */
+int glome_ctx_set_grid_per_cu(glome_ctx*, int waves_per_cu);
 int glome_ctx_device_info(glome_ctx*, char* name, int cap, int* cu_count, int* warp_size);
 
 /* ---- transforms: Xfm = forward 3x4 (12 doubles, row major) + inverse 3x4 (12 doubles) ---- */
@@ -201,7 +205,9 @@ typedef struct glome_render_params {
   int32_t mode;          /* GLOME_MODE_* */
   int32_t blocksize;     /* tile edge, Glome.hs:116 (65) */
   int32_t maxdepth;      /* Glome.hs:25 (3); 1..4 supported */
-  int32_t fog;           /* 1: TILE mode stores r + depth/400 like Glome.hs:174; 0: the get_color tuple */
+  int32_t fog;           /* 1: TILE mode stores (r + depth/400, g, b, a, depth) exactly as renderTile does (Glome.hs:174,
+                            Q20: a miss stores r = 2500); 0 -- the DEFAULT, a deliberate deviation from renderTile -- stores
+                            the tuple get_color returns (Glome.hs:53-55) before that debug term */
   float thresholds[4];   /* Glome.hs:221-224 */
   int32_t tile_first, tile_stride; /* shard: render tiles tile_first, tile_first+tile_stride, ... (x-major order) */
   int32_t faithful;      /* 1: BIH traversal without ordered early-out, exactly as Bih.hs:332-368 visits nodes */

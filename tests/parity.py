@@ -5,10 +5,23 @@ import numpy as np
 
 from helpers import compare_hits, compare_images, oracle_for, product_camera_lights, random_rays
 
+import json
+import os
+
 T_RTOL = 1e-4          # relative t tolerance (north star: 1e-4 relative fp32)
-MISMATCH_MAX = 1e-3    # fraction of rays allowed to flip hit/miss vs fp64
-OUTLIER_MAX = 2e-3     # fraction of hits allowed beyond T_RTOL (CSG boundaries under fp32)
-PIXEL_OUTLIER_MAX = 5e-3
+# The bounds below are the measured levels (profiles/r02_parity_levels.txt, written by these checks when
+# GLOME_PARITY_LOG is set) times a small margin, not round numbers: a regression of a few x trips them.
+MISMATCH_MAX = 3e-4    # fraction of rays allowed to flip hit/miss vs fp64 (grazing rays)
+OUTLIER_MAX = 5e-4     # fraction of hits allowed beyond T_RTOL (CSG boundaries under fp32)
+PIXEL_OUTLIER_MAX = 5e-4   # fraction of pixels beyond 1e-4 relative (silhouette pixels that flip hit/miss in fp32)
+SUBSAMPLE_OUTLIER_MAX = 2e-3  # adaptive mode: one flipped threshold decision moves a pixel and its blended neighbours
+
+
+def _log(kind, sd, levels):
+    path = os.environ.get("GLOME_PARITY_LOG")
+    if path:
+        with open(path, "a") as f:
+            f.write(json.dumps({"check": kind, "scene": getattr(sd, "name", None) or f"{sd.n_nodes} nodes", **levels}) + "\n")
 
 
 def id_maps(nm, om):
@@ -29,7 +42,7 @@ def check_rays(backend_rayint, backend_shadow, backend_inside, sd, nm, n=20000, 
     both = (got["t"] >= 0) & (ref["t"] >= 0)
     inv, invo = id_maps(nm, om)
     same_prim = inv[got["prim"][both]] == invo[ref["prim"][both]]
-    assert same_prim.mean() > 0.99, f"primitive agreement {same_prim.mean()}"  # coplanar faces tie differently in fp32
+    assert same_prim.mean() > 0.995, f"primitive agreement {same_prim.mean()}"  # coplanar faces tie differently in fp32
     tex_ok = np.all(got["tex"][both] == ref["tex"][both], axis=1)
     assert np.mean(tex_ok[same_prim]) > 0.999, "texture stacks differ on the same primitive"
     nerr = np.abs(got["n"][both] - ref["n"][both]).max(axis=1)
@@ -43,7 +56,10 @@ def check_rays(backend_rayint, backend_shadow, backend_inside, sd, nm, n=20000, 
     io = o.inside(om[sd.root], pts.astype(np.float64))
     ig = backend_inside(pts)
     assert np.mean(io != ig) <= MISMATCH_MAX, f"inside mismatch {np.mean(io != ig)}"
-    return {"mismatch": mism, "t_err_max": emax, "shadow_mismatch": float(np.mean(so != sg)), "hit_frac": float(np.mean(ref["t"] >= 0))}
+    lv = {"mismatch": mism, "t_err_max": emax, "t_outliers": float(np.mean(err > T_RTOL)) if err.size else 0.0, "same_prim": float(same_prim.mean()),
+          "shadow_mismatch": float(np.mean(so != sg)), "inside_mismatch": float(np.mean(io != ig)), "hit_frac": float(np.mean(ref["t"] >= 0))}
+    _log("rays", sd, lv)
+    return lv
 
 
 def check_image(img, counts, sd, w, h, maxdepth):
@@ -51,13 +67,15 @@ def check_image(img, counts, sd, w, h, maxdepth):
     o, om, _ = oracle_for(sd)
     ref, _, rc = o.render(w, h, maxdepth=maxdepth, want_packed=False)
     c = compare_images(img, ref)
-    assert c["frac_over"] <= PIXEL_OUTLIER_MAX, c
-    assert c["mean"] <= 3e-4, c
     hit_g, hit_r = img[..., 4] < 1e6, ref[..., 4] < 1e6
-    assert np.mean(hit_g != hit_r) <= 2e-3
     bothhit = hit_g & hit_r
     drel = np.abs(img[..., 4][bothhit] - ref[..., 4][bothhit]) / np.maximum(1, ref[..., 4][bothhit])
-    assert np.mean(drel > T_RTOL) <= 5e-3
+    c["hit_flip"] = float(np.mean(hit_g != hit_r)); c["depth_outliers"] = float(np.mean(drel > T_RTOL)) if drel.size else 0.0
+    _log("image", sd, c)
+    assert c["frac_over"] <= PIXEL_OUTLIER_MAX, c
+    assert c["mean"] <= 6e-5, c
+    assert c["hit_flip"] <= 3e-4, c
+    assert c["depth_outliers"] <= 5e-4, c
     assert counts[0] == rc["rays_primary"]
     for got, want in ((counts[1], rc["rays_shadow"]), (counts[2], rc["rays_secondary"])):
         assert abs(int(got) - int(want)) <= max(8, int(want) // 200), (counts, rc)  # a flipped silhouette pixel adds / drops a few rays
@@ -71,7 +89,8 @@ def check_subsample_image(img, counts, sd, w, h, maxdepth):
     o, om, _ = oracle_for(sd)
     ref, _, rc = o.render(w, h, mode=1, maxdepth=maxdepth, want_packed=False)
     c = compare_images(img, ref)
-    assert c["frac_over"] <= 0.01, c
-    assert c["mean"] <= 5e-4, c
+    _log("subsample", sd, c)
+    assert c["frac_over"] <= SUBSAMPLE_OUTLIER_MAX, c
+    assert c["mean"] <= 1e-4, c
     assert abs(int(counts[0]) - rc["rays_primary"]) <= max(8, rc["rays_primary"] // 500), (counts, rc)
     return c, rc

@@ -98,7 +98,8 @@ def test_full_size_counts_and_pixels_match_oracle_on_a_tile_sample(s3_full):
     assert owned.sum() == st["n_pixels"] == rc["rays_primary"] == st["rays_primary"]
     assert np.all(img[~owned] == 0)  # tiles this call does not own are left untouched
     e = (np.abs(img[owned][:, :4] - ref[owned][:, :4]) / np.maximum(1, np.abs(ref[owned][:, :4]))).max(-1)
-    assert np.mean(e > 1e-4) < 2e-3
+    parity._log("tile_sample_S3", sd, {"frac_over": float(np.mean(e > 1e-4)), "max": float(e.max())})
+    assert np.mean(e > 1e-4) <= parity.PIXEL_OUTLIER_MAX
     assert st["rays_shadow"] == rc["rays_shadow"]
     assert abs(st["bih_nodes"] - rc["bih_nodes"]) <= rc["bih_nodes"] // 5000 + 4
     assert abs(st["prim_tests"] - rc["prim_tests"]) <= rc["prim_tests"] // 5000 + 4
@@ -253,7 +254,8 @@ def test_full_size_csg_generic_tier_vs_oracle_tile_sample(gpu_ctx):
     for x, y, w, h, _ in dist.owned_layout(api.render_params(width=1920, height=1080), 5, 23):
         owned[y:y + h, x:x + w] = True
     e = (np.abs(img[owned][:, :4] - ref[owned][:, :4]) / np.maximum(1, np.abs(ref[owned][:, :4]))).max(-1)
-    assert np.mean(e > 1e-4) < 5e-3
+    parity._log("tile_sample_S4", sd, {"frac_over": float(np.mean(e > 1e-4)), "max": float(e.max())})
+    assert np.mean(e > 1e-4) <= parity.PIXEL_OUTLIER_MAX
     assert st["rays_primary"] == rc["rays_primary"]
     assert abs(st["rays_shadow"] - rc["rays_shadow"]) <= rc["rays_shadow"] // 500 + 8 and abs(st["rays_secondary"] - rc["rays_secondary"]) <= rc["rays_secondary"] // 200 + 8
     sc.release()
@@ -488,3 +490,192 @@ def test_random_soup_renders_like_the_oracle(gpu_ctx, kind):
     f, _, sf = sc.render(cam, lights, api.render_params(width=320, height=200, maxdepth=1, faithful=1))
     assert np.array_equal(img, f)  # early-out packets pick the reference traversal's hits, ties included
     sc.release()
+
+
+def test_render_tile_fog_term(gpu_ctx):
+    """renderTile stores (r + depth/400, g, b, a, depth) (Glome.hs:174, Q20); `fog = 1` reproduces that -- a miss stores
+    r = 1e6 / 400 = 2500 with alpha 0 -- and the default (fog = 0) is the get_color tuple before the term."""
+    sd = scenes.s1(nlights=1)
+    b, nm, sc = commit(gpu_ctx, sd)
+    cam, lights = product_camera_lights(sd)
+    o, om, _ = oracle_for(sd)
+    ref, _, _ = o.render(320, 180, maxdepth=1, fog=1, want_packed=False)
+    img, _, _ = sc.render(cam, lights, api.render_params(width=320, height=180, maxdepth=1, fog=1), want_packed=False)
+    plain, _, _ = sc.render(cam, lights, api.render_params(width=320, height=180, maxdepth=1), want_packed=False)
+    c = parity.compare_images(img, ref)
+    assert c["frac_over"] <= parity.PIXEL_OUTLIER_MAX, c
+    miss = img[..., 4] == 1e6
+    assert miss.any() and (~miss).any() and np.all(img[..., 0][miss] == 2500.0) and np.all(img[..., 3][miss] == 0)
+    assert np.array_equal(img[..., 1:], plain[..., 1:])
+    assert np.array_equal(img[..., 0], (plain[..., 0] + plain[..., 4] / np.float32(400)).astype(np.float32))
+    sc.release()
+
+
+def test_two_row_packet_kernel_over_a_one_leaf_bih(gpu_ctx):
+    """A deep triangle BIH (LDS stack at its 12 entries: the frame runs on the two-row, 24-wave packet instance) next to a
+    BIH whose root is a leaf of nine coincident triangles: the one-leaf tree is tested item by item without a push
+    (a continuation entry would land on a stack row the two-row instance does not have)."""
+    sd = zoo.deep_and_clump()
+    b, nm, sc = commit(gpu_ctx, sd)
+    assert sc.info()["tier"] == 0 and sc.info()["max_bih_depth"] >= 12
+    cam, lights = product_camera_lights(sd)
+    img, packed, st = sc.render(cam, lights, api.render_params(width=480, height=270, maxdepth=1))
+    f, pf, sf = sc.render(cam, lights, api.render_params(width=480, height=270, maxdepth=1, faithful=1))  # three-row counting instance
+    assert np.array_equal(img, f) and np.array_equal(packed, pf)
+    parity.check_image(img, (st["rays_primary"], st["rays_shadow"], st["rays_secondary"]), sd, 480, 270, 1)
+    # the batch path bench.py uses (several frames per launch, packed product)
+    import torch
+    dev = torch.device("cuda:0")
+    P = api.render_params(width=480, height=270, maxdepth=1)
+    px = torch.zeros((2, 270, 480), dtype=torch.int32, device=dev)
+    cams = (L.Camera * 2)(cam, cam)
+    la = (L.Light * len(lights))(*lights)
+    assert sc.lib.glome_render_packed_batch_dev(sc.h, cams, 2, la, len(lights), C.byref(P), C.c_void_p(px.data_ptr()), 270 * 480, None) == 0
+    gpu_ctx.synchronize()
+    got = px.cpu().numpy().view(np.uint32)
+    assert np.array_equal(got[0], packed) and np.array_equal(got[1], packed)
+    sc.release()
+
+
+# ------------------------------------------------------------------ BASELINE configs[4]: 1M triangles, 3840x2160, adaptive, shards
+def _bih_op(sd, nm):
+    """(host node, item ids) of the scene's `bih` call: SceneDesc node ids run over the node ops in order (a bulk op makes many)"""
+    nid, out = 0, None
+    for kind, name, args in sd.ops:
+        if kind == "N":
+            nid += args[0].shape[0]
+        elif kind == "n":
+            if name == "bih":
+                out = (nm[nid], [nm[i] for i in args[0]])
+            nid += 1
+    return out
+
+
+def _owned_mask(w, h, first, stride):
+    owned = np.zeros((h, w), bool)
+    for x, y, tw, th, _ in dist.owned_layout(api.render_params(width=w, height=h), first, stride):
+        owned[y:y + th, x:x + tw] = True
+    return owned
+
+
+@pytest.fixture(scope="module")
+def s5_bih(gpu_ctx):
+    """S5 = heightfield of 708 x 708 x 2 = 1,002,528 triangles as `bih [triangle ...]`, tree built on the device."""
+    sd = scenes.s3(708)
+    b = api.Builder()
+
+    class DevBih:
+        def __getattr__(self, name):
+            return getattr(b, name)
+
+        def bih(self, ids):
+            return gpu_ctx.bih(b, ids)[0]
+    nm, _ = sd.replay(DevBih())
+    sc = gpu_ctx.commit(b, nm[sd.root])
+    o, om, _ = oracle_for(sd)  # ~15 s for a million triangles: once per module
+    yield sd, sc, o
+    sc.release()
+
+
+def test_s5_device_built_tree_of_a_million_triangles_is_the_host_builders(gpu_ctx):
+    sd = scenes.s3(708)
+    b = api.Builder()
+    nm, _ = sd.replay(b)  # host builder (build_rec, Bih.hs:211-285)
+    host, ids = _bih_op(sd, nm)
+    assert len(ids) == 1002528
+    dev, ms = gpu_ctx.bih(b, ids)
+    _same_tree(b, host, dev)
+    assert ms > 0
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_s5_4k_tile_sample_vs_oracle(s5_bih, mode):
+    """Every 173rd 65x65 tile of the 3840x2160 frame (12 tiles, ~48k pixels) by the oracle and by the GPU, in renderTile mode
+    (faithful traversal: ray and node / primitive visit counts equal the oracle's) and in renderTileSubsample mode (whole
+    reference tiles, so the sampled tiles are exactly the frame's)."""
+    sd, sc, o = s5_bih
+    cam, lights = product_camera_lights(sd)
+    W, H, first, stride = 3840, 2160, 7, 173
+    ref, _, rc = o.render(W, H, mode=mode, maxdepth=1, tile_first=first, tile_stride=stride, nthreads=8, want_packed=False)
+    init = np.zeros((H, W, 5), np.float32)
+    img, _, st = sc.render(cam, lights, api.render_params(width=W, height=H, mode=mode, maxdepth=1, tile_first=first, tile_stride=stride, faithful=1 if mode == 0 else 0),
+                           want_packed=False, init=init)
+    owned = _owned_mask(W, H, first, stride)
+    assert owned.sum() == st["n_pixels"] and np.all(img[~owned] == 0)
+    e = (np.abs(img[owned][:, :4] - ref[owned][:, :4]) / np.maximum(1, np.abs(ref[owned][:, :4]))).max(-1)
+    parity._log(f"tile_sample_S5_mode{mode}", sd, {"frac_over": float(np.mean(e > 1e-4)), "max": float(e.max())})
+    if mode == 0:
+        assert np.mean(e > 1e-4) <= parity.PIXEL_OUTLIER_MAX, np.mean(e > 1e-4)
+        assert st["rays_primary"] == rc["rays_primary"] == owned.sum() and st["rays_shadow"] == rc["rays_shadow"]
+        assert abs(st["bih_nodes"] - rc["bih_nodes"]) <= rc["bih_nodes"] // 5000 + 4
+        assert abs(st["prim_tests"] - rc["prim_tests"]) <= rc["prim_tests"] // 5000 + 4
+    else:
+        assert np.mean(e > 1e-4) <= parity.SUBSAMPLE_OUTLIER_MAX, np.mean(e > 1e-4)
+        assert abs(int(st["rays_primary"]) - rc["rays_primary"]) <= max(8, rc["rays_primary"] // 500)
+        assert owned.sum() / 8 <= st["rays_primary"] <= 2 * owned.sum()
+
+
+def test_s5_4k_adaptive_eight_shards_reassemble_bit_exactly(gpu_ctx, s5_bih):
+    """configs[4] as stated: 3840x2160, renderTileSubsample, whole 65x65 reference tiles round-robin over 8 ranks -- each
+    rank's packed payload, one blit: the packed framebuffer of the single-GPU render, bit for bit."""
+    import torch
+    sd, sc, _ = s5_bih
+    cam, lights = product_camera_lights(sd)
+    dev = torch.device("cuda:0")
+    W, H, world = 3840, 2160, 8
+    P = api.render_params(width=W, height=H, mode=1, maxdepth=1)
+    whole_px = torch.zeros((H, W), dtype=torch.int32, device=dev)
+    sc.render_dev(cam, lights, P, None, whole_px.data_ptr())
+    la = (L.Light * len(lights))(*lights)
+    plans = [dist.ShardPlan(P, r, world, unit=1) for r in range(world)]
+    gathered = torch.zeros((world, plans[0].maxp), dtype=torch.int32, device=dev)
+    tot = 0
+    for r in range(world):
+        st = L.Stats()
+        assert sc.lib.glome_render_tiles_packed_dev(sc.h, C.byref(cam), la, len(lights), C.byref(plans[r].P_local), C.c_void_p(gathered[r].data_ptr()), C.byref(st)) == 0
+        tot += st.n_pixels
+    frame_px = torch.full((H, W), -1, dtype=torch.int32, device=dev)
+    assert sc.lib.glome_tiles_blit_all_packed_dev(gpu_ctx.h, C.byref(P), world, C.c_void_p(gathered.data_ptr()), plans[0].maxp, C.c_void_p(frame_px.data_ptr())) == 0
+    gpu_ctx.synchronize()
+    assert tot == W * H and torch.equal(frame_px, whole_px)
+
+
+@pytest.fixture(scope="module")
+def s5_mesh(gpu_ctx):
+    sd = scenes.s3(708, as_mesh=True)
+    b = api.Builder()
+
+    class DevMesh:
+        def __getattr__(self, name):
+            return getattr(b, name)
+
+        def mesh(self, verts, norms, tris, mats):
+            return gpu_ctx.mesh(b, verts, norms, tris, mats)[0]
+    nm, _ = sd.replay(DevMesh())
+    sc = gpu_ctx.commit(b, nm[sd.root])
+    o, om, _ = oracle_for(sd)
+    yield sd, sc, o
+    sc.release()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_s5_as_a_mesh_of_a_million_triangles_4k_tile_sample_vs_oracle(s5_mesh, mode):
+    """configs[4] names a Mesh: the same 1,002,528 triangles as `mesh verts [] tris` (rayint_mesh, Mesh.hs:136-198; the BVH of
+    build_tree, Mesh.hs:69-113, made on the device), 3840x2160, a tile sample against the oracle in both render modes.  A
+    Mesh casts no shadows (Mesh.hs:210), so shadow rays are traced and all come back unoccluded."""
+    sd, sc, o = s5_mesh
+    assert sc.info()["n_triangles"] == 1002528 and sc.info()["n_mesh_nodes"] > 0
+    cam, lights = product_camera_lights(sd)
+    W, H, first, stride = 3840, 2160, 11, 173
+    ref, _, rc = o.render(W, H, mode=mode, maxdepth=1, tile_first=first, tile_stride=stride, nthreads=8, want_packed=False)
+    img, _, st = sc.render(cam, lights, api.render_params(width=W, height=H, mode=mode, maxdepth=1, tile_first=first, tile_stride=stride, count_work=1 if mode == 0 else 0),
+                           want_packed=False, init=np.zeros((H, W, 5), np.float32))
+    owned = _owned_mask(W, H, first, stride)
+    e = (np.abs(img[owned][:, :4] - ref[owned][:, :4]) / np.maximum(1, np.abs(ref[owned][:, :4]))).max(-1)
+    parity._log(f"tile_sample_S5mesh_mode{mode}", sd, {"frac_over": float(np.mean(e > 1e-4)), "max": float(e.max())})
+    assert np.mean(e > 1e-4) <= (parity.PIXEL_OUTLIER_MAX if mode == 0 else parity.SUBSAMPLE_OUTLIER_MAX), np.mean(e > 1e-4)
+    if mode == 0:
+        assert st["rays_primary"] == rc["rays_primary"] == owned.sum() and st["rays_shadow"] == rc["rays_shadow"]
+        assert abs(st["mesh_nodes"] - rc["mesh_nodes"]) <= rc["mesh_nodes"] // 2000 + 4  # ordered traversal with far clipping: fp32 can flip a clip
+    else:
+        assert abs(int(st["rays_primary"]) - rc["rays_primary"]) <= max(8, rc["rays_primary"] // 500)

@@ -11,6 +11,7 @@ from glome_amd import api, scenes
 
 SCENES = dict(zoo.ALL)
 SCENES.update({"soup_tri": lambda: zoo.soup(400, 5), "soup_sphere": lambda: zoo.soup(300, 6, spheres=True), "soup_tri_only": lambda: zoo.soup(400, 7, floor=False),
+               "deep_and_clump": lambda: zoo.deep_and_clump(600, 9),
                "S1": lambda: scenes.s1(nlights=2), "S3small": lambda: scenes.s3(24), "S3mesh_small": lambda: scenes.s3(24, as_mesh=True), "S4": scenes.s4})
 
 
@@ -116,3 +117,23 @@ def test_adaptive_sampler(built, name, w, h):
     c, rc = parity.check_subsample_image(img, [int(x) for x in cnt], sd, w, h, 3)
     # the sampler traces between 1/8 and 2 primary rays per pixel (README.md:20)
     assert w * h / 8 <= int(cnt[0]) <= 2 * w * h
+
+
+def test_one_leaf_bih_of_more_than_six_items(built):
+    """The clump of zoo.deep_and_clump: build_rec keeps nine coincident triangles in ONE leaf, which is the tree's root; the
+    wave walk tests such a tree item by item without pushing anything (rt_device.hpp bih_tri_wave)."""
+    sd = zoo.deep_and_clump(600, 9)
+    b = api.Builder()
+    nm, _ = sd.replay(b)
+    nid, bihs = 0, []
+    for kind, name, args in sd.ops:
+        if kind == "N":
+            nid += args[0].shape[0]
+        elif kind == "n":
+            if name == "bih":
+                bihs.append(nm[nid])
+            nid += 1
+    ls, rs, ax, nl, lp = b.bih_dump(bihs[1])
+    assert len(nl) == 1 and nl[0] == 9  # a single node: the root leaf, nine items
+    hs = HostSim(b, nm[sd.root])
+    assert hs.info()["max_bih_depth"] >= 12 and hs.info()["tier"] == 0

@@ -183,3 +183,18 @@ def soup(n=2500, seed=5, spheres=False, floor=True):
     if not floor:  # the all-triangle (or all-sphere) kernel instance
         return _finish(sd, body)
     return _finish(sd, sd.group([sd.tex(sd.box((-8, -0.6, -8), (8, -0.1, 8)), scenes.matte(sd, (0.3, 0.5, 0.3))), body]))
+
+
+def deep_and_clump(n=2500, seed=9, k=9):
+    """Two triangle BIHs side by side in the root list: a deep one (so the flat tier's LDS stack is at its full 12 entries and the
+    frame runs on the two-row packet instance) and one whose ROOT is a leaf of `k` > 6 coincident triangles (build_rec keeps
+    objects it cannot separate in one leaf, Bih.hs:211-285) -- the one-leaf tree of bih_tri_wave."""
+    rng = np.random.default_rng(seed)
+    sd = SceneDesc()
+    c = rng.uniform(-6, 6, (n, 3)); c[:, 1] = np.abs(c[:, 1]) * 0.5
+    e = rng.normal(0, 0.35, (n, 2, 3))
+    deep = sd.bih(sd.triangles_bulk(np.concatenate([c, c + e[:, 0], c + e[:, 1]], axis=1)))
+    tri = np.array([[-2.0, 0.2, 4.0, 2.5, 0.4, 4.5, 0.0, 3.5, 3.0]])
+    clump = sd.bih(sd.triangles_bulk(np.tile(tri, (k, 1))))
+    root = sd.group([sd.tex(deep, scenes.matte(sd, (0.7, 0.6, 0.5))), sd.tex(clump, scenes.matte(sd, (0.2, 0.4, 0.9)))])
+    return _finish(sd, root, nlights=1)
