@@ -174,14 +174,53 @@ __device__ __forceinline__ bool work_to_pixel(const DRenderArgs& A, uint32_t w, 
   return true;
 }
 
+// The work queue of a render launch.  One ticket counter cannot feed the GPU: a returning atomic on one word completes
+// about every 11 ns (MI355X_MICROARCH.md, "dequeue": ~88 per microsecond), a frame of the flagship scene is 32,400 items
+// and the 6,144 resident waves get through ~150 of them per microsecond -- the waves queue up behind the counter.
+// (Measured with one counter: a launch running alone took 0.39 ms per frame whatever its grid, four launches on four slots
+// -- four counters -- 0.226.)  So the queue has kQueueShards heads, each on a cache line of its own; ticket chunk c
+// (kQueueChunk consecutive items: one 64x64 work tile) belongs to head c mod kQueueShards, so the order in which the image
+// is worked through stays what it was.  A wave starts at the head of its XCD (blocks are dealt round-robin over the XCDs:
+// speed only, never correctness) and moves on when a head runs dry.  Heads found dry are published in a mask word that is
+// written a handful of times per launch and therefore cheap to read (a load of a head itself would wait behind the
+// atomics queued on its line: measured 4x slower), so a wave rarely pays for more than one failed take.  The last wave to
+// leave puts everything back to zero: the next launch on the slot needs no reset packet on the stream.
+constexpr uint32_t kNoTicket = 0xffffffffu;
+struct TicketQueue {
+  uint32_t shard, dry;
+  __device__ __forceinline__ TicketQueue() : shard(blockIdx.x % kQueueShards), dry(0) {}
+  __device__ __forceinline__ uint32_t take(const DRenderArgs& A) {  // lane 0 only
+    constexpr uint32_t kAll = (1u << kQueueShards) - 1u;
+    while (dry != kAll) {
+      if (!((dry >> shard) & 1u)) {
+        const uint32_t i = atomicAdd(&A.counters->heads[shard * kQueueHeadStride], 1u);
+        if (i < A.shard_cap) return ((i / kQueueChunk) * kQueueShards + shard) * kQueueChunk + (i % kQueueChunk);
+        atomicOr(&A.counters->dry, 1u << shard);
+        dry |= (1u << shard) | __hip_atomic_load(&A.counters->dry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      shard = (shard + 1) % kQueueShards;
+    }
+    return kNoTicket;
+  }
+  __device__ __forceinline__ void leave(const DRenderArgs& A) {  // lane 0 only, after its last take
+    if (atomicAdd(&A.counters->done, 1u) == gridDim.x - 1u) {  // every other wave has taken its last ticket
+      for (uint32_t h = 0; h < kQueueShards; h++) __hip_atomic_store(&A.counters->heads[h * kQueueHeadStride], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&A.counters->dry, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&A.counters->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+};
+
 template <class TIER>
 __device__ __forceinline__ void render_loop(const DRenderArgs& A, TIER& T) {
   int lane = threadIdx.x & 63;
+  TicketQueue Q;
   for (;;) {
-    uint32_t w = 0;
-    if (lane == 0) w = atomicAdd(&A.counters->next_work, 1u) - A.work_base;
+    uint32_t w = kNoTicket;
+    if (lane == 0) w = Q.take(A);
     w = __shfl(w, 0, 64);
-    if (w >= A.total_waves * (uint32_t)A.nframes) break;
+    if (w == kNoTicket) break;
+    if (w >= A.total_waves * (uint32_t)A.nframes) continue;  // padding of the last round of chunks
     const uint32_t frame = w / A.total_waves;  // wave-uniform
     w -= frame * A.total_waves;
 #if defined(GLOME_EXP_TIMING)
@@ -215,6 +254,7 @@ __device__ __forceinline__ void render_loop(const DRenderArgs& A, TIER& T) {
     { unsigned int d32 = (unsigned int)(__builtin_readcyclecounter() - tw0); d32 = __shfl(d32, 0, 64); if (A.out5) A.out5[o * 5 + 4] = (float)d32; }
 #endif
   }
+  if (lane == 0) Q.leave(A);
 }
 
 // TWO_ROWS: the wave's LDS holds two stack rows per entry instead of three (lane_stack); legal when no lane ever pushes on
@@ -231,7 +271,8 @@ __global__ void __launch_bounds__(64, LB) k_render_flat(DRenderArgs A, int stack
 __global__ void __launch_bounds__(64) k_render_generic(DRenderArgs A) {
   GenericTier T{A.S, A.lights, A.nlights, Cnt()};
   render_loop(A, T);
-  flush_counters(A.counters, T.cnt, T.err);
+  if (A.want_counters) flush_counters(A.counters, T.cnt, T.err);
+  else if (__builtin_amdgcn_ballot_w64(T.err != 0) && (threadIdx.x & 63) == 0) atomicOr(&A.counters->error, 1u);
 }
 
 
@@ -465,9 +506,6 @@ struct glome_ctx {
     size_t ovf_bytes = 0;
     float* d_scratch = nullptr;  // adaptive sampler working buffer
     size_t scratch_bytes = 0;
-    // value of d_counters->next_work once the launches queued on this slot have run: a render launch that needs no
-    // statistics does not reset the counters, it takes its work items relative to this base (one stream packet per frame)
-    uint32_t work_base = 0;
     bool launched = false;  // a render launch went out on this slot since its error word was last polled
   };
   static constexpr int kSlots = 8;
@@ -822,7 +860,6 @@ static int check_device_error(glome_ctx* ctx) { return poll_device_error(ctx, ct
 
 static int reset_counters(glome_ctx* ctx) {
   HIPCHK(ctx, hipMemsetAsync(ctx->slot().d_counters, 0, offsetof(DCounters, error), ctx->stream));  // not the sticky error word
-  ctx->slot().work_base = 0;
   return 0;
 }
 
@@ -913,13 +950,16 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
   A.nlights = nlights; A.width = P->width; A.height = P->height; A.fog = P->fog; A.maxdepth = P->maxdepth;
   memcpy(A.thresholds, P->thresholds, 16);
   A.tiles = tt->dev; A.tile_lut = tt->lut; A.ntiles = (int)tt->host.size(); A.total_waves = tt->total_waves;
+  {  // tickets per queue head: the launch's chunks dealt round-robin over the heads, the last round padded
+    const uint32_t tickets = A.total_waves * (uint32_t)nframes, round = kQueueChunk * kQueueShards;
+    A.shard_cap = ((tickets + round - 1) / round) * kQueueChunk;
+  }
   // dense 0: full frame (rgbad and / or packed); 1: dense rgbad tile payload; 2: dense packed-pixel tile payload only
   A.out5 = dense == 2 ? nullptr : rgbad_dev; A.packed = dense == 1 ? nullptr : packed_dev; A.counters = ctx->slot().d_counters; A.dense = dense != 0;
-  // a plain frame (no statistics wanted, renderTile mode) does not reset the counters: its work queue starts at the
-  // slot's running base, so the frame is a single packet on the stream
-  const bool bare = !stats && P->mode == GLOME_MODE_TILE && !P->faithful && !P->count_work && ctx->slot().work_base < 0x70000000u;
+  // a plain frame (no statistics wanted, renderTile mode) does not reset the counters -- the queue heads are put back by
+  // the last wave of the launch before -- so the frame is a single packet on the stream
+  const bool bare = !stats && P->mode == GLOME_MODE_TILE && !P->faithful && !P->count_work;
   if (!bare && (rc = reset_counters(ctx))) return rc;
-  A.work_base = ctx->slot().work_base;
   A.want_counters = (bare || (P->mode == GLOME_MODE_SUBSAMPLE && !stats)) ? 0 : 1;  // nobody reads them without `stats`
   hipEvent_t ev_start = ctx->ev0, ev_stop = ctx->ev1;
   if (A.ntiles > 0 && P->mode == GLOME_MODE_SUBSAMPLE) {
@@ -971,7 +1011,6 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
     launch_render(s, A, P, grid, lds);
     HIPCHK(ctx, hipGetLastError());
     if (timed) HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
-    ctx->slot().work_base += A.total_waves * (uint32_t)nframes + (uint32_t)grid;  // every wave of the grid takes one ticket past the end
   }
   if (stats) {
     memset(stats, 0, sizeof(*stats));

@@ -88,10 +88,17 @@ struct DLight { float pos[3], color[3], rad; int32_t shadow; };
 
 struct DTile { int32_t x, y, w, h; uint32_t wave_base; uint32_t pix_base; };  // pix_base: offset of the tile in a dense payload
 
-struct DCounters {  // device-side atomics, one block per launch
+constexpr uint32_t kQueueShards = 8;       // heads of a render launch's work queue (one per XCD)
+constexpr uint32_t kQueueHeadStride = 32;  // words between heads: every head on its own 128-byte line
+constexpr uint32_t kQueueChunk = 64;       // consecutive tickets that belong to one head (one 64x64 work tile of 8x8 blocks)
+struct DCounters {  // device-side atomics, one block per launch slot
   unsigned long long rays_primary, rays_shadow, rays_secondary, bih_nodes, mesh_nodes, prim_tests;
-  unsigned int next_work;  // persistent-kernel work queue head
-  unsigned int error;      // set when a device-side limit was hit (stack overflow guard, CSG cap)
+  unsigned int heads[kQueueShards * kQueueHeadStride];  // persistent-kernel work queue heads (glome_device.hip TicketQueue)
+  unsigned int dry_pad[31];
+  unsigned int dry;        // mask of heads found empty (own line: written a few times per launch, read whenever a wave changes heads)
+  unsigned int done_pad[31];
+  unsigned int done;       // waves of the running launch that have left the queue (the last one resets the heads)
+  unsigned int error;      // sticky: set when a device-side limit was hit (stack overflow guard, CSG cap); reset_counters stops short of it
 };
 
 struct DRenderArgs {
@@ -107,7 +114,7 @@ struct DRenderArgs {
   const uint32_t* tile_lut;  // tile of every 64th work item
   int32_t ntiles;
   uint32_t total_waves;
-  uint32_t work_base;   // value of counters->next_work when this launch starts (0 after a counter reset)
+  uint32_t shard_cap;   // tickets per queue head of this launch (whole chunks; the last round of chunks may be padding)
   int32_t dense;       // 1: out5 is a dense tile payload (tile order, row major inside a tile) instead of a frame
   float* scratch;      // adaptive sampler: dense per-tile working buffer `v` (owned pixels * 5 floats)
   unsigned int* ss_cnt;  // adaptive sampler: [8 + pass] work-queue head of the pass

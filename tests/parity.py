@@ -72,8 +72,10 @@ def check_image(img, counts, sd, w, h, maxdepth):
     drel = np.abs(img[..., 4][bothhit] - ref[..., 4][bothhit]) / np.maximum(1, ref[..., 4][bothhit])
     c["hit_flip"] = float(np.mean(hit_g != hit_r)); c["depth_outliers"] = float(np.mean(drel > T_RTOL)) if drel.size else 0.0
     _log("image", sd, c)
-    assert c["frac_over"] <= PIXEL_OUTLIER_MAX, c
-    assert c["mean"] <= 6e-5, c
+    # a scene may state a wider bound with its reason (zoo.textures: a step-function texture flips between two materials
+    # where an fp32 hit point lands on the other side of a stripe edge)
+    assert c["frac_over"] <= getattr(sd, "pixel_outlier_max", PIXEL_OUTLIER_MAX), c
+    assert c["mean"] <= getattr(sd, "pixel_mean_max", 6e-5), c
     assert c["hit_flip"] <= 3e-4, c
     assert c["depth_outliers"] <= 5e-4, c
     assert counts[0] == rc["rays_primary"]

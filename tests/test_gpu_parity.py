@@ -507,7 +507,8 @@ def test_render_tile_fog_term(gpu_ctx):
     miss = img[..., 4] == 1e6
     assert miss.any() and (~miss).any() and np.all(img[..., 0][miss] == 2500.0) and np.all(img[..., 3][miss] == 0)
     assert np.array_equal(img[..., 1:], plain[..., 1:])
-    assert np.array_equal(img[..., 0], (plain[..., 0] + plain[..., 4] / np.float32(400)).astype(np.float32))
+    # (the device divides through v_rcp_f32: within an ulp or two of the exact quotient)
+    assert np.allclose(img[..., 0], plain[..., 0] + plain[..., 4] / np.float32(400), rtol=1e-6, atol=0)
     sc.release()
 
 
@@ -676,6 +677,8 @@ def test_s5_as_a_mesh_of_a_million_triangles_4k_tile_sample_vs_oracle(s5_mesh, m
     assert np.mean(e > 1e-4) <= (parity.PIXEL_OUTLIER_MAX if mode == 0 else parity.SUBSAMPLE_OUTLIER_MAX), np.mean(e > 1e-4)
     if mode == 0:
         assert st["rays_primary"] == rc["rays_primary"] == owned.sum() and st["rays_shadow"] == rc["rays_shadow"]
-        assert abs(st["mesh_nodes"] - rc["mesh_nodes"]) <= rc["mesh_nodes"] // 2000 + 4  # ordered traversal with far clipping: fp32 can flip a clip
+        # the device walk re-tests a postponed child against the best hit of the whole mesh so far, which is at most the depth
+        # the reference clips with (Mesh.hs:178, 190: the first child's result): same hits, a few per cent fewer nodes
+        assert 0.95 * rc["mesh_nodes"] <= st["mesh_nodes"] <= rc["mesh_nodes"] + 4, (st["mesh_nodes"], rc["mesh_nodes"])
     else:
         assert abs(int(st["rays_primary"]) - rc["rays_primary"]) <= max(8, rc["rays_primary"] // 500)

@@ -154,7 +154,11 @@ def textures():
         sd.tex(sd.box((1.2, 0, -1), (3.2, 2, 1)), square),
         sd.tex(sd.cone((5, 0, 0), 1.0, (5, 2.5, 0), 0.2), sine),
     ]
-    return _finish(sd, sd.group([pl, sd.bih(items)]))
+    sd = _finish(sd, sd.group([pl, sd.bih(items)]))
+    # square_wave / the stripe edges are step functions of the hit point: an fp32 hit point a few ulp from an edge takes the
+    # other material (measured on MI355X: 25 of 57,600 pixels, errors up to 0.2); everything else is at the usual level
+    sd.pixel_outlier_max, sd.pixel_mean_max = 1e-3, 2e-4
+    return sd
 
 
 ALL = {"flat_mixed": flat_mixed, "quadrics": quadrics, "csg": csg, "nested": nested, "mesh": mesh_scene, "materials": materials, "textures": textures}
