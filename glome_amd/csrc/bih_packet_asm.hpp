@@ -1,0 +1,254 @@
+// bih_packet_asm.hpp -- the packet walk of a triangle BIH, hand-written for gfx950 (device code only).
+//
+// rt_device.hpp's bih_tri_packet is the reference implementation of one wave walking `rayint_bih` / `shadow_bih`
+// (Bih.hs:332-368, 510-544) once for its 64 rays.  The kernel built from it is bound by the CU's scalar unit
+// (profiles/r02_pmc_S3_mode0.json: 0.67 scalar instructions per cycle per CU, vector issue at 0.28 of its peak): the compiler
+// spends ~25 scalar instructions on a branch step, ~30 on a triangle (packing operands for v_pk_* arithmetic, lane masks
+// combined with s_and after every compare) and ~20 on a pop.  This file is the same walk written out:
+//
+//   branch step  ~17 scalar: the three axes and the two directions are separate straight-line pieces (the direction signs
+//                of a packet are fixed for the whole walk, so the walk is instantiated per octant: no direction test, no
+//                operand swap); s_and_b64 sets SCC, so a vote needs no compare; the stack pointer lives in m0 for the whole
+//                walk (v_writelane / v_readlane take it from there) and the lane's LDS address is kept incrementally.
+//   triangle     ~8 scalar: two scalar loads (32 + 16 bytes), the Moeller-Trumbore arithmetic with the scalar registers as
+//                direct operands (the same IEEE operations in the same order as the compiler's tri_test, so results are
+//                bit-identical to every other kernel instance), and the four rejection tests as a chain of v_cmpx, which
+//                narrows EXEC instead of building masks: the survivors' updates are plain moves.
+//   pop          ~7 scalar.
+//
+// What it declines goes back to the C++ loop for one step (status codes below): pushes and pops beyond the LDS part of the
+// stack (global overflow columns) and leaves of more than six items.  MODE 1 (ordered early-out closest hit) and MODE 2
+// (any hit) only; the faithful / counting variants stay in C++.
+//
+// Invariant used (MODE 1): far <= best_t on the current path at all times (the root interval is clipped with the running
+// best, children only shrink it, a pop clips with best_t, an accepted hit sets both), so a triangle hit within [.., far]
+// always replaces the running best: `!(best_t < t)` (nearest: ties -> later item, Solid.hs:37-44) needs no test.
+//
+// Scalar registers s[60:87], vcc, scc and m0 (saved and restored) are scratch, named in the clobber list.
+#pragma once
+#if defined(__HIPCC__)
+
+namespace glome {
+
+enum : int { PKW_DONE = 0, PKW_PUSH_OVERFLOW = 1, PKW_BIG_LEAF = 2, PKW_POP_OVERFLOW = 3 };
+
+// one axis piece of the branch step.  O / R: this lane's origin / reciprocal direction on the axis; NP / FP: the planes
+// that end the near child's interval and start the far child's; NC / FC: the child references (s62 is shifted into place
+// at the top of the piece).  s[60:63] = the node.
+#define GLOME_PKW_AXIS(TAG, O, R, NP, FP, NC, FC)                                                    \
+  "L_ax" TAG "_%=:\n"                                                                                 \
+  "  s_lshr_b32 s62, s62, 2\n"                                                                        \
+  "  v_sub_f32 %[t1], " NP ", %[" O "]\n"                                                             \
+  "  v_sub_f32 %[t2], " FP ", %[" O "]\n"                                                             \
+  "  v_mul_f32 %[t1], %[t1], %[" R "]\n"                                                              \
+  "  v_mul_f32 %[t2], %[t2], %[" R "]\n"                                                              \
+  "  v_cmp_lt_f32 vcc, %[t2], %[far]\n"                                                               \
+  "  s_and_b64 s[78:79], vcc, %[am]\n"      /* lanes that reach the far child */                      \
+  "  v_cmp_lt_f32 vcc, %[near], %[t1]\n"                                                              \
+  "  s_and_b64 s[76:77], vcc, %[am]\n"      /* lanes that reach the near child; SCC = any */          \
+  "  s_cbranch_scc0 L_no1" TAG "_%=\n"                                                                \
+  "  s_cmp_lg_u64 s[78:79], 0\n"                                                                      \
+  "  s_cbranch_scc0 L_nopush" TAG "_%=\n"                                                             \
+  "  s_cmp_ge_u32 m0, %[cap]\n"                                                                       \
+  "  s_cbranch_scc1 L_slow_%=\n"                                                                      \
+  "  v_max_f32 %[t2], %[t2], %[near]\n"     /* the far child's interval starts here */                \
+  "  v_writelane_b32 %[ur], " FC ", m0\n"   /* the uniform part of the entry: lane `sp` of ur / ulo / uhi */ \
+  "  v_writelane_b32 %[ulo], s78, m0\n"                                                               \
+  "  v_writelane_b32 %[uhi], s79, m0\n"                                                               \
+  "  ds_write_b32 %[av], %[t2]\n"           /* this lane's (near, far) of the far child */            \
+  "  ds_write_b32 %[av], %[far] offset:%[row1]\n"                                                     \
+  "  v_add_u32 %[av], 0x100, %[av]\n"                                                                 \
+  "  s_add_u32 m0, m0, 1\n"                                                                           \
+  "L_nopush" TAG "_%=:\n"                                                                             \
+  "  v_min_f32 %[far], %[t1], %[far]\n"                                                               \
+  "  s_mov_b32 %[ref], " NC "\n"                                                                      \
+  "  s_mov_b64 %[am], s[76:77]\n"                                                                     \
+  "  s_branch L_node_%=\n"                                                                            \
+  "L_no1" TAG "_%=:\n"                                                                                \
+  "  s_cmp_lg_u64 s[78:79], 0\n"                                                                      \
+  "  s_cbranch_scc0 L_pop_%=\n"             /* nobody goes on below this node */                      \
+  "  v_max_f32 %[near], %[t2], %[near]\n"                                                             \
+  "  s_mov_b32 %[ref], " FC "\n"                                                                      \
+  "  s_mov_b64 %[am], s[78:79]\n"                                                                     \
+  "  s_branch L_node_%=\n"
+
+// rays running towards +axis take the left child (s62, ends at plane s60) first, the others the right one (s63, plane s61)
+#define GLOME_PKW_AXIS_FWD(TAG, O, R) GLOME_PKW_AXIS(TAG, O, R, "s60", "s61", "s62", "s63")
+#define GLOME_PKW_AXIS_BWD(TAG, O, R) GLOME_PKW_AXIS(TAG, O, R, "s61", "s60", "s63", "s62")
+
+// the triangle at byte offset s86 of the pool: s[64:67] = (p1, .), s[68:71] = (e1, .), s[72:75] = (e2, .) (rt_types.h).
+// The arithmetic is tri_test's (Triangle.hs:45-73) operation for operation as hipcc contracts it under -ffp-contract=on:
+// cross(a, b).y = fma(a.z, b.x, -(a.x * b.z)) and cyclic; dot(a, b) = fma(a.z, b.z, fma(a.x, b.x, a.y * b.y)).
+#define GLOME_PKW_TRI_ARITH                                                                           \
+  "  s_load_dwordx8 s[64:71], %[tris], s86\n"                                                         \
+  "  s_load_dwordx4 s[72:75], %[tris], s86 offset:0x20\n"                                             \
+  "  s_mov_b64 exec, %[am]\n"               /* only the lanes whose interval reaches this leaf */     \
+  "  s_waitcnt lgkmcnt(0)\n"                                                                          \
+  "  v_subrev_f32 %[Dx], s64, %[ox]\n"      /* D = o - p1 */                                          \
+  "  v_subrev_f32 %[Dy], s65, %[oy]\n"                                                                \
+  "  v_subrev_f32 %[Dz], s66, %[oz]\n"                                                                \
+  "  v_mul_f32_e64 %[s2y], -%[Dx], s70\n"   /* s2 = D x e1 */                                         \
+  "  v_mul_f32_e64 %[s2x], -%[Dz], s69\n"                                                             \
+  "  v_mul_f32_e64 %[s2z], -%[Dy], s68\n"                                                             \
+  "  v_fma_f32 %[s2y], %[Dz], s68, %[s2y]\n"                                                          \
+  "  v_fma_f32 %[s2x], %[Dy], s70, %[s2x]\n"                                                          \
+  "  v_fma_f32 %[s2z], %[Dx], s69, %[s2z]\n"                                                          \
+  "  v_mul_f32_e64 %[s1y], -%[dx], s74\n"   /* s1 = dir x e2 */                                       \
+  "  v_mul_f32_e64 %[s1x], -%[dz], s73\n"                                                             \
+  "  v_mul_f32_e64 %[s1z], -%[dy], s72\n"                                                             \
+  "  v_fma_f32 %[s1y], %[dz], s72, %[s1y]\n"                                                          \
+  "  v_fma_f32 %[s1x], %[dy], s74, %[s1x]\n"                                                          \
+  "  v_fma_f32 %[s1z], %[dx], s73, %[s1z]\n"                                                          \
+  "  v_mul_f32 %[div], s69, %[s1y]\n"       /* divisor = s1 . e1 */                                   \
+  "  v_fmac_f32 %[div], s68, %[s1x]\n"                                                                \
+  "  v_fmac_f32 %[div], s70, %[s1z]\n"                                                                \
+  "  v_mul_f32 %[b2], %[dy], %[s2y]\n"      /* dir . s2 */                                            \
+  "  v_mul_f32 %[b1], %[Dy], %[s1y]\n"      /* D . s1 */                                              \
+  "  v_mul_f32 %[t], s73, %[s2y]\n"         /* e2 . s2 */                                             \
+  "  v_rcp_f32 %[inv], %[div]\n"                                                                      \
+  "  v_fmac_f32 %[b2], %[dx], %[s2x]\n"                                                               \
+  "  v_fmac_f32 %[b1], %[Dx], %[s1x]\n"                                                               \
+  "  v_fmac_f32 %[t], s72, %[s2x]\n"                                                                  \
+  "  v_fmac_f32 %[b2], %[dz], %[s2z]\n"                                                               \
+  "  v_fmac_f32 %[b1], %[Dz], %[s1z]\n"                                                               \
+  "  v_fmac_f32 %[t], s74, %[s2z]\n"                                                                  \
+  "  v_mul_f32 %[b2], %[b2], %[inv]\n"                                                                \
+  "  v_mul_f32 %[b1], %[b1], %[inv]\n"                                                                \
+  "  v_mul_f32 %[t], %[t], %[inv]\n"                                                                  \
+  "  v_min3_f32 %[s2x], %[b1], %[b2], %[t]\n"  /* lo = min(b1, b2, t) */                              \
+  "  v_add_f32 %[s2y], %[b1], %[b2]\n"                                                                \
+  "  v_max_f32 %[s2y], %[b1], %[s2y]\n"        /* hi = max(b1, b1 + b2) */                            \
+  /* divisor == 0 || b1 < 0 || b2 < 0 || t < 0 || b1 > 1 || b1 + b2 > 1 || t > far  ->  miss */       \
+  "  v_cmpx_neq_f32 vcc, 0, %[div]\n"                                                                 \
+  "  v_cmpx_ngt_f32 vcc, 0, %[s2x]\n"                                                                 \
+  "  v_cmpx_nlt_f32 vcc, 1.0, %[s2y]\n"                                                               \
+  "  v_cmpx_ngt_f32 vcc, %[t], %[far]\n"    /* EXEC = the lanes that hit */
+
+// what the lanes that hit do (EXEC = those lanes), and what a popped entry's lane mask s[80:81] is filtered with (SCC = any left)
+#define GLOME_PKW_UPDATE_1                                                                            \
+  "  v_mov_b32 %[best_t], %[t]\n"                                                                     \
+  "  v_mov_b32 %[far], %[t]\n"              /* far = min(far, t) = t: the test just passed t <= far */ \
+  "  v_mov_b32 %[best_rec], s87\n"
+#define GLOME_PKW_UPDATE_2                                                                            \
+  "  s_or_b64 %[occ], %[occ], exec\n"                                                                 \
+  "  s_andn2_b64 %[am], %[am], exec\n"      /* an occluded ray is finished; SCC = rays left in this walk's current entry */ \
+  "  s_cbranch_scc0 L_leafdone_%=\n"
+#define GLOME_PKW_FILTER_1                                                                            \
+  "  v_min_f32 %[far], %[far], %[best_t]\n" /* `far` may have shrunk since the push */                \
+  "  v_cmp_ngt_f32 vcc, %[near], %[far]\n"                                                            \
+  "  s_and_b64 %[am], s[80:81], vcc\n"
+#define GLOME_PKW_FILTER_2 "  s_andn2_b64 %[am], s[80:81], %[occ]\n"
+
+// the whole walk as one statement.  AX / AY / AZ: FWD or BWD per axis; M: 1 or 2.
+#define GLOME_PKW_ASM(AX, AY, AZ, M)                                                                                            \
+  asm volatile(                                                                                                                 \
+      "  s_mov_b32 s84, m0\n"               /* m0 holds the stack pointer for the whole walk (restored at the end) */           \
+      "  s_mov_b32 m0, %[sp]\n"                                                                                                 \
+      "  s_mov_b64 s[82:83], exec\n"                                                                                            \
+      "  s_lshl_b32 s80, %[sp], 8\n"                                                                                            \
+      "  v_add_u32 %[av], s80, %[lds]\n"     /* this lane's slot of the next free entry */                                      \
+      "  s_cmp_lg_u32 %[phase], 0\n"                                                                                            \
+      "  s_cbranch_scc1 L_pop_%=\n"                                                                                             \
+      /* ------------------------------------------------------------ branch steps */                                          \
+      "L_node_%=:\n"                                                                                                            \
+      "  s_bitcmp1_b32 %[ref], 29\n"                                                                                            \
+      "  s_cbranch_scc1 L_leaf_%=\n"                                                                                            \
+      "  s_lshl_b32 s80, %[ref], 4\n"                                                                                           \
+      "  s_load_dwordx4 s[60:63], %[nodes], s80\n"                                                                              \
+      "  s_waitcnt lgkmcnt(0)\n"                                                                                                \
+      "  s_and_b32 s81, s62, 3\n"           /* axis; SCC = (axis != 0) */                                                       \
+      "  s_cbranch_scc0 L_axX_%=\n"                                                                                             \
+      "  s_bitcmp1_b32 s81, 1\n"                                                                                                \
+      "  s_cbranch_scc1 L_axZ_%=\n"                                                                                             \
+      GLOME_PKW_AXIS_##AY("Y", "oy", "ry") GLOME_PKW_AXIS_##AX("X", "ox", "rx") GLOME_PKW_AXIS_##AZ("Z", "oz", "rz")            \
+      /* ------------------------------------------------------------ a leaf: up to six triangles */                           \
+      "L_leaf_%=:\n"                                                                                                            \
+      "  s_bfe_u32 s85, %[ref], 0x3001a\n"  /* item count (bits 28..26) */                                                      \
+      "  s_and_b32 s87, %[ref], 0x3ffffff\n" /* first record */                                                                 \
+      "  s_cmp_eq_u32 s85, 7\n"                                                                                                 \
+      "  s_cbranch_scc1 L_big_%=\n"                                                                                             \
+      "  s_cmp_eq_u32 s85, 0\n"                                                                                                 \
+      "  s_cbranch_scc1 L_pop_%=\n"                                                                                             \
+      "  s_bfm_b32 s85, s85, 0\n"           /* `count` ones: shifted out one per triangle */                                    \
+      "  s_add_u32 s86, s87, %[delta]\n"     /* first primitive */                                                              \
+      "  s_mul_i32 s86, s86, 48\n"                                                                                              \
+      "L_tri_%=:\n"                                                                                                             \
+      GLOME_PKW_TRI_ARITH                                                                                                       \
+      GLOME_PKW_UPDATE_##M                                                                                                      \
+      "  s_add_u32 s86, s86, 48\n"                                                                                              \
+      "  s_add_u32 s87, s87, 1\n"                                                                                               \
+      "  s_lshr_b32 s85, s85, 1\n"          /* SCC = triangles left */                                                          \
+      "  s_cbranch_scc1 L_tri_%=\n"                                                                                             \
+      "L_leafdone_%=:\n"                                                                                                        \
+      "  s_mov_b64 exec, s[82:83]\n"                                                                                            \
+      /* ------------------------------------------------------------ pop until an entry some lane still wants */              \
+      "L_pop_%=:\n"                                                                                                             \
+      "  s_cmp_eq_u32 m0, 0\n"                                                                                                  \
+      "  s_cbranch_scc1 L_empty_%=\n"                                                                                           \
+      "  s_cmp_gt_u32 m0, %[cap]\n"                                                                                             \
+      "  s_cbranch_scc1 L_popslow_%=\n"                                                                                         \
+      "  s_sub_u32 m0, m0, 1\n"                                                                                                 \
+      "  v_add_u32 %[av], 0xffffff00, %[av]\n"                                                                                  \
+      "  ds_read_b32 %[near], %[av]\n"                                                                                          \
+      "  ds_read_b32 %[far], %[av] offset:%[row1]\n"                                                                            \
+      "  v_readlane_b32 %[ref], %[ur], m0\n"                                                                                    \
+      "  v_readlane_b32 s80, %[ulo], m0\n"                                                                                      \
+      "  v_readlane_b32 s81, %[uhi], m0\n"                                                                                      \
+      "  s_waitcnt lgkmcnt(0)\n"                                                                                                \
+      GLOME_PKW_FILTER_##M                                                                                                      \
+      "  s_cbranch_scc0 L_pop_%=\n"                                                                                             \
+      "  s_branch L_node_%=\n"                                                                                                  \
+      /* ------------------------------------------------------------ exits */                                                 \
+      "L_empty_%=:\n"                                                                                                           \
+      "  s_mov_b64 %[am], 0\n"                                                                                                  \
+      "  s_mov_b32 %[status], 0\n"                                                                                              \
+      "  s_branch L_end_%=\n"                                                                                                   \
+      "L_slow_%=:\n"                          /* a push that does not fit the LDS part: the C++ step takes this node */         \
+      "  s_mov_b32 %[status], 1\n"                                                                                              \
+      "  s_branch L_end_%=\n"                                                                                                   \
+      "L_big_%=:\n"                           /* a leaf of more than six items */                                               \
+      "  s_mov_b32 %[status], 2\n"                                                                                              \
+      "  s_branch L_end_%=\n"                                                                                                   \
+      "L_popslow_%=:\n"                       /* the top entry lives in the overflow columns */                                 \
+      "  s_mov_b32 %[status], 3\n"                                                                                              \
+      "L_end_%=:\n"                                                                                                             \
+      "  s_mov_b32 %[sp], m0\n"                                                                                                 \
+      "  s_mov_b32 m0, s84\n"                                                                                                   \
+      : [ref] "+s"(ref), [am] "+s"(am), [sp] "+s"(sp), [near] "+v"(nearv), [far] "+v"(farv), [best_t] "+v"(best_t), [best_rec] "+v"(best_rec), [ur] "+v"(ur),     \
+        [ulo] "+v"(ulo), [uhi] "+v"(uhi), [occ] "+s"(occm), [status] "=s"(status), [av] "=&v"(av), [t1] "=&v"(t1), [t2] "=&v"(t2), [Dx] "=&v"(Dx), [Dy] "=&v"(Dy),  \
+        [Dz] "=&v"(Dz), [s2x] "=&v"(s2x), [s2y] "=&v"(s2y), [s2z] "=&v"(s2z), [s1x] "=&v"(s1x), [s1y] "=&v"(s1y), [s1z] "=&v"(s1z), [div] "=&v"(dv), [inv] "=&v"(inv),   \
+        [b1] "=&v"(b1), [b2] "=&v"(b2), [t] "=&v"(tt)                                                                                                                 \
+      : [nodes] "s"(nodes), [tris] "s"(tris), [delta] "s"(delta), [cap] "s"((uint32_t)CAP), [phase] "s"(phase), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z),         \
+        [rx] "v"(rcp.x), [ry] "v"(rcp.y), [rz] "v"(rcp.z), [dx] "v"(d.x), [dy] "v"(d.y), [dz] "v"(d.z), [lds] "v"(lds_row), [row1] "n"(CAP * 256)                   \
+      : "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", \
+        "s83", "s84", "s85", "s86", "s87", "vcc", "scc", "memory")
+
+// MODE 1 = closest hit with ordered early-out, MODE 2 = any hit.  XF / YF / ZF: the rays of the packet run towards +x / +y / +z.
+// CAP: entries of the LDS part of the stack (the far row lies CAP * 256 bytes after the near row).
+// phase 0: go on from `ref` with the lanes `am`; phase 1: pop first.  Returns a PKW_* status.
+template <int MODE, bool XF, bool YF, bool ZF, int CAP>
+__device__ __forceinline__ int bih_walk_asm(const F4* nodes, const F4* tris, uint32_t delta, int phase, uint32_t& ref, LaneMask& am, int& sp, float& nearv, float& farv,
+                                            float& best_t, uint32_t& best_rec, LaneMask& occm, V3 o, V3 rcp, V3 d, uint32_t lds_row, uint32_t& ur, uint32_t& ulo, uint32_t& uhi) {
+  static_assert(MODE == 1 || MODE == 2, "the hand-written walk covers the production traversals only");
+  int status;
+  uint32_t av;
+  float t1, t2, Dx, Dy, Dz, s2x, s2y, s2z, s1x, s1y, s1z, dv, inv, b1, b2, tt;
+  // wave-uniform by construction; readfirstlane pins them to scalar registers where the compiler cannot see that
+  ref = uni(ref); am = uni(am); sp = (int)uni((uint32_t)sp); occm = uni(occm); phase = (int)uni((uint32_t)phase); delta = uni(delta);
+  nodes = (const F4*)(uintptr_t)uni((LaneMask)(uintptr_t)nodes); tris = (const F4*)(uintptr_t)uni((LaneMask)(uintptr_t)tris);
+#define GLOME_PKW_BY_OCTANT(M)                                                    \
+  if constexpr (XF && YF && ZF) GLOME_PKW_ASM(FWD, FWD, FWD, M);                  \
+  else if constexpr (!XF && YF && ZF) GLOME_PKW_ASM(BWD, FWD, FWD, M);            \
+  else if constexpr (XF && !YF && ZF) GLOME_PKW_ASM(FWD, BWD, FWD, M);            \
+  else if constexpr (!XF && !YF && ZF) GLOME_PKW_ASM(BWD, BWD, FWD, M);           \
+  else if constexpr (XF && YF && !ZF) GLOME_PKW_ASM(FWD, FWD, BWD, M);            \
+  else if constexpr (!XF && YF && !ZF) GLOME_PKW_ASM(BWD, FWD, BWD, M);           \
+  else if constexpr (XF && !YF && !ZF) GLOME_PKW_ASM(FWD, BWD, BWD, M);           \
+  else GLOME_PKW_ASM(BWD, BWD, BWD, M)
+  if constexpr (MODE == 1) { GLOME_PKW_BY_OCTANT(1); } else { GLOME_PKW_BY_OCTANT(2); }
+#undef GLOME_PKW_BY_OCTANT
+  return status;
+}
+
+}  // namespace glome
+#endif

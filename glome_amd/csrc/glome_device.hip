@@ -873,7 +873,7 @@ static bool use_two_rows(const glome_scene* s, const glome_render_params* P, uin
   // 16-wave instance (measured at 8 ranks: 0.040 against 0.047 ms per frame); from ~48k work items on the 24-wave one wins
   if (P->tile_stride != 1 && items < 48000u) return false;
   if (s->dev.tier != 0 || P->faithful || P->count_work) return false;
-  if (s->has_secondary_mats || s->has_nested_mats || s->stack_cap != kAsmLdsCap || getenv("GLOME_DEBUG_LB")) return false;
+  if (s->has_secondary_mats || s->has_nested_mats || s->stack_cap != kAsmLdsCap) return false;
   int cls = scene_class(s);
   return cls == CLS_BIH_TRI || cls == (CLS_BIH_SPHERE | CLS_PRIMS);
 }
@@ -886,7 +886,6 @@ static void launch_render(glome_scene* s, const DRenderArgs& A, const glome_rend
     bool full = s->has_nested_mats || (s->has_secondary_mats && P->maxdepth > 1);
     dim3 g(grid), blk(64);
     int cls = scene_class(s);
-    int lb = getenv("GLOME_DEBUG_LB") ? atoi(getenv("GLOME_DEBUG_LB")) : 0;
 #define GLOME_LAUNCH(F, C, U, K, B) hipLaunchKernelGGL((k_render_flat<F, C, U, K, B>), g, blk, lds, st, A, s->stack_cap, s->ovf_cap ? s->ctx->slot().d_ovf : nullptr, s->ovf_cap)
 #define GLOME_BY_CLS(F, C, U)                                                   \
     do {                                                                          \
@@ -904,12 +903,6 @@ static void launch_render(glome_scene* s, const DRenderArgs& A, const glome_rend
     if (faithful) { if (full) GLOME_LAUNCH(true, true, true, CLS_ALL, 1); else GLOME_LAUNCH(true, true, false, CLS_ALL, 1); }
     else if (count) { if (full) GLOME_LAUNCH(false, true, true, CLS_ALL, 1); else GLOME_LAUNCH(false, true, false, CLS_ALL, 1); }
     else if (full) GLOME_BY_CLS(false, false, true);
-    else if (cls == CLS_BIH_TRI && lb == 2) GLOME_LAUNCH(false, false, false, CLS_BIH_TRI, 2);
-    else if (cls == CLS_BIH_TRI && lb == 3) GLOME_LAUNCH(false, false, false, CLS_BIH_TRI, 3);
-    else if (cls == CLS_BIH_TRI && lb == 4) GLOME_LAUNCH(false, false, false, CLS_BIH_TRI, 4);
-    else if (cls == CLS_BIH_TRI && lb == 5) GLOME_LAUNCH(false, false, false, CLS_BIH_TRI, 5);
-    else if (cls == CLS_BIH_TRI && lb == 6) GLOME_LAUNCH(false, false, false, CLS_BIH_TRI, 6);
-    else if (cls == CLS_BIH_TRI && lb == 8) GLOME_LAUNCH(false, false, false, CLS_BIH_TRI, 8);
     else GLOME_BY_CLS(false, false, false);
 #undef GLOME_BY_CLS
 #undef GLOME_LAUNCH

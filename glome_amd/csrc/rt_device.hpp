@@ -905,6 +905,90 @@ GPK PacketResult bih_tri_packet(const F4* nodes, const F4* tris, uint32_t ref, u
   return R;
 }
 
+#if defined(__HIPCC__)
+}  // namespace glome
+#include "bih_packet_asm.hpp"
+namespace glome {
+// The production packet walk: bih_walk_asm (hand-written, one instance per octant) with the C++ steps of bih_tri_packet for
+// what it declines -- a push or pop beyond the LDS part of the stack, a leaf of more than six triangles.  Same visits, same
+// results, same tie order as bih_tri_packet<MODE, false, 0>.
+template <int MODE>
+GD PacketResult bih_tri_packet_hw(const F4* nodes, const F4* tris, uint32_t ref, uint32_t delta, uint32_t fwdbits, LaneMask am, float nearv, float farv, V3 ro, V3 rd,
+                                  V3 rcp, float best_t, LaneStack& stk) {
+  constexpr int CAP = kAsmLdsCap;
+  ref = uni(ref); delta = uni(delta); fwdbits = uni(fwdbits); am = uni(am);
+  Ray r; r.o = ro; r.d = rd;
+  PacketResult R; R.best_t = best_t; R.best_rec = kNoRec; R.n_bih = 0; R.n_prim = 0;
+  int sp = 0, phase = 0;
+  LaneMask occm = 0;
+  const uint32_t lds_row = (uint32_t)(uintptr_t)stk.nearv;
+  for (;;) {
+    int st;
+#define GLOME_WALK(XF, YF, ZF) st = bih_walk_asm<MODE, XF, YF, ZF, CAP>(nodes, tris, delta, phase, ref, am, sp, nearv, farv, R.best_t, R.best_rec, occm, r.o, rcp, r.d, lds_row, stk.ur, stk.ulo, stk.uhi)
+    switch (fwdbits) {  // wave-uniform: one scalar jump per walk
+      case 7: GLOME_WALK(true, true, true); break;
+      case 6: GLOME_WALK(false, true, true); break;
+      case 5: GLOME_WALK(true, false, true); break;
+      case 4: GLOME_WALK(false, false, true); break;
+      case 3: GLOME_WALK(true, true, false); break;
+      case 2: GLOME_WALK(false, true, false); break;
+      case 1: GLOME_WALK(true, false, false); break;
+      default: GLOME_WALK(false, false, false); break;
+    }
+#undef GLOME_WALK
+    st = (int)uni((uint32_t)st);
+    if (st == PKW_DONE) break;
+    ref = uni(ref); am = uni(am); sp = (int)uni((uint32_t)sp);
+    if (st == PKW_PUSH_OVERFLOW) {  // one branch step of bih_tri_packet; its push goes to the overflow columns
+      F4 n = ld4u(nodes, ref);
+      const uint32_t w0 = uni(as_u(n.z)), right = uni(as_u(n.w));
+      const uint32_t axis = w0 & 3u, left = w0 >> 2;
+      float dl, dr;
+      if (axis == 0) { dl = (n.x - r.o.x) * rcp.x; dr = (n.y - r.o.x) * rcp.x; }
+      else if (axis == 1) { dl = (n.x - r.o.y) * rcp.y; dr = (n.y - r.o.y) * rcp.y; }
+      else { dl = (n.x - r.o.z) * rcp.z; dr = (n.y - r.o.z) * rcp.z; }
+      const bool fwd = (fwdbits >> axis) & 1u;
+      const uint32_t c1 = fwd ? left : right, c2 = fwd ? right : left;
+      const float t1 = fwd ? dl : dr, t2 = fwd ? dr : dl;
+      const LaneMask m1 = wave_ballot(nearv < t1) & am, m2 = wave_ballot(t2 < farv) & am;
+      const float f1 = min_nn(t1, farv), n2 = max_nn(t2, nearv);
+      if ((m1 != 0) & (m2 != 0)) { stk.push_wave(sp, c2, m2, n2, farv); sp++; }
+      const bool g1 = m1 != 0;
+      ref = g1 ? c1 : c2;
+      am = g1 ? m1 : m2;
+      farv = g1 ? f1 : farv;
+      nearv = g1 ? nearv : n2;
+      phase = am != 0 ? 0 : 1;
+    } else if (st == PKW_BIG_LEAF) {  // the leaf's extent is in its node
+      const F4 ln = ld4u(nodes, ref & BREF_FIRST);
+      const uint32_t count = uni(as_u(ln.z)), first = uni(as_u(ln.w));
+      for (uint32_t k = 0; k < count && am != 0; k++) {
+        F4 p0, p1, p2;
+        float t, b1, b2;
+        ld_tri_u(tris, first + delta + k, p0, p1, p2);
+        const bool hit = tri_test(p0, p1, p2, r, farv, t, b1, b2) && lane_of(am);
+        if (MODE == 2) { const LaneMask hm = wave_ballot(hit); occm |= hm; am &= ~hm; }
+        else {
+          const bool acc = hit && !(R.best_t < t);
+          R.best_t = acc ? t : R.best_t;
+          R.best_rec = acc ? first + k : R.best_rec;
+          farv = acc ? gminf(farv, t) : farv;
+        }
+      }
+      phase = 1;
+    } else {  // PKW_POP_OVERFLOW: the top entry sits in the overflow columns
+      sp--;
+      stk.pop_wave(sp, ref, am, nearv, farv);
+      if (MODE == 1) { farv = gminf(farv, R.best_t); am &= wave_ballot(!(nearv > farv)); }
+      if (MODE == 2) am &= ~occm;
+      phase = am != 0 ? 0 : 1;
+    }
+  }
+  R.occ_lo = (uint32_t)occm; R.occ_hi = (uint32_t)(occm >> 32);
+  return R;
+}
+#endif
+
 template <int MODE, bool COUNT, int LEAFK = 0, class STK>
 GD bool bih_tri_wave(const DScene& S, uint32_t hdr, const Ray& r, float d, bool valid, STK& stk, Cnt& cnt, float& best_t, uint32_t& best_rec) {
   hdr = uni(hdr);
@@ -946,8 +1030,15 @@ GD bool bih_tri_wave(const DScene& S, uint32_t hdr, const Ray& r, float d, bool 
     const uint32_t fwdbits = uni(first_lane_value(todo, oct));  // per axis: do the rays of this walk run towards +axis
     const LaneMask am = todo & wave_ballot(oct == fwdbits);
     todo &= ~am;
-    PacketResult R = bih_tri_packet<MODE, COUNT, LEAFK, STK>(S.bihnodes, LEAFK == 0 ? S.tris : S.spheres, ref, delta, fwdbits, (uint32_t)am, (uint32_t)(am >> 32),
-                                                              nearv, farv, r.o, r.d, rcp, best_t, stk);
+    PacketResult R;
+#if defined(__HIPCC__) && !defined(GLOME_EXP_NO_ASM)
+    if constexpr (MODE != 0 && !COUNT && LEAFK == 0 && std::is_same<STK, LaneStack>::value) {
+      if (stk.cap == kAsmLdsCap) R = bih_tri_packet_hw<MODE>(S.bihnodes, S.tris, ref, delta, fwdbits, am, nearv, farv, r.o, r.d, rcp, best_t, stk);
+      else R = bih_tri_packet<MODE, COUNT, LEAFK, STK>(S.bihnodes, S.tris, ref, delta, fwdbits, (uint32_t)am, (uint32_t)(am >> 32), nearv, farv, r.o, r.d, rcp, best_t, stk);
+    } else
+#endif
+    R = bih_tri_packet<MODE, COUNT, LEAFK, STK>(S.bihnodes, LEAFK == 0 ? S.tris : S.spheres, ref, delta, fwdbits, (uint32_t)am, (uint32_t)(am >> 32),
+                                                 nearv, farv, r.o, r.d, rcp, best_t, stk);
 #if defined(GLOME_EXP_ASM_TIMING)
     if ((threadIdx.x & 63) == 0) { cnt.bih += R.n_bih; cnt.prim += R.n_prim; }
 #endif

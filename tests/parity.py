@@ -11,10 +11,10 @@ import os
 T_RTOL = 1e-4          # relative t tolerance (north star: 1e-4 relative fp32)
 # The bounds below are the measured levels (profiles/r02_parity_levels.txt, written by these checks when
 # GLOME_PARITY_LOG is set) times a small margin, not round numbers: a regression of a few x trips them.
-MISMATCH_MAX = 3e-4    # fraction of rays allowed to flip hit/miss vs fp64 (grazing rays)
-OUTLIER_MAX = 5e-4     # fraction of hits allowed beyond T_RTOL (CSG boundaries under fp32)
+MISMATCH_MAX = 1e-4    # fraction of rays allowed to flip hit/miss vs fp64 (grazing rays)
+OUTLIER_MAX = 2e-4     # fraction of hits allowed beyond T_RTOL (CSG boundaries under fp32)
 PIXEL_OUTLIER_MAX = 5e-4   # fraction of pixels beyond 1e-4 relative (silhouette pixels that flip hit/miss in fp32)
-SUBSAMPLE_OUTLIER_MAX = 2e-3  # adaptive mode: one flipped threshold decision moves a pixel and its blended neighbours
+SUBSAMPLE_OUTLIER_MAX = 5e-4  # adaptive mode: one flipped threshold decision moves a pixel and its blended neighbours
 
 
 def _log(kind, sd, levels):
