@@ -9,7 +9,7 @@
 //                                       rt_device.hpp bih_tri_wave) -> shadow rays -> shade -> secondary rays (per lane).
 //                                       No ray streams in HBM at all.
 //   k_render_generic                    same loop over the generic interpreter (rt_generic.hpp)
-//   k_ss_pass_flat / k_ss_pass_generic  one pass of the adaptive sampler (renderTileSubsample, Glome.hs:226-323)
+//   k_ss_frame_flat / k_ss_frame_generic  the adaptive sampler (renderTileSubsample, Glome.hs:226-323): five passes, one launch
 //   k_rayint_batch / k_shadow_batch / k_inside_batch   the `Solid` method seams on SoA ray streams
 //   k_tiles_pack / k_tiles_blit / k_tiles_blit_packed  Tile payload <-> frame (blitTile, Glome.hs:353-358)
 //   k_bb_* / k_mb_* (bih_build_device.hpp)             `bih` and the Mesh BVH built level by level (Bih.hs:211-285, Mesh.hs:69-113)
@@ -278,24 +278,17 @@ __global__ void __launch_bounds__(64) k_render_generic(DRenderArgs A) {
 
 // ------------------------------------------------------------------------------------------------ adaptive sampler
 // renderTileSubsample (Glome.hs:226-323).  The reference runs five passes over each 65x65 tile; a pass looks at
-// neighbour contrast (`decide`, Glome.hs:213-219) and either averages or traces a fresh sample.  Here a pass is ONE
-// launch over all owned tiles: persistent waves pull regions of a tile's candidate lattice (ss_block_pixel: blocks of
-// 64 candidates of the pass in a compact pixel area, one per lane; 1 or 2x2 blocks per region); a lane takes the
-// contrast test and writes the average when that settles it; the candidates that need a sample are compacted over
-// the region (ballot + LDS list) and traced 64 at a time -- neighbours in the image, so the rays are walked as a
-// packet.  A region in which nobody needs a sample does no tracing at all.
+// neighbour contrast (`decide`, Glome.hs:213-219) and either averages or traces a fresh sample.  Here persistent waves
+// pull regions of a tile's candidate lattice (ss_block_pixel: blocks of 64 candidates of a pass in a compact pixel area,
+// one per lane; 1 or 2x2 blocks per region); a lane takes the contrast test and writes the average when that settles it;
+// the candidates that need a sample are compacted over the region (ballot + LDS list) and traced 64 at a time --
+// neighbours in the image, so the rays are walked as a packet.  A region in which nobody needs a sample traces nothing.
 // The working buffer `v` is a dense per-tile array in global memory (tile order, row major inside a tile), so all
 // neighbour reads stay inside the tile like the reference's getc (Glome.hs:233-235); `v2` is the output.  A pass reads
-// what the previous passes wrote anywhere in the tile, hence one launch per pass.
+// what the previous passes wrote anywhere in the tile: ss_frame_loop below orders the passes per tile.
 // channel planes, not 5-float structs: the lanes of a block read neighbouring pixels, so a plane read is (nearly) contiguous
 struct SSBuf { float* v; size_t plane; };
-__device__ __forceinline__ TC ss_load(const SSBuf& b, size_t i) { const float* p = b.v + i; return tc(p[0], p[b.plane], p[2 * b.plane], p[3 * b.plane], p[4 * b.plane]); }
-__device__ __forceinline__ void ss_store(const SSBuf& b, size_t i, const TC& c) { float* p = b.v + i; p[0] = c.r; p[b.plane] = c.g; p[2 * b.plane] = c.b; p[3 * b.plane] = c.a; p[4 * b.plane] = c.d; }
 __device__ __forceinline__ void out5_store(float* v, size_t i, const TC& c) { float* p = v + i * 5; p[0] = c.r; p[1] = c.g; p[2] = c.b; p[3] = c.a; p[4] = c.d; }
-__device__ __forceinline__ TC ss_getc(const SSBuf& v, const DTile& t, int dx, int dy) {  // getc: outside the tile reads blank
-  if (dx >= 0 && dx < t.w && dy >= 0 && dy < t.h) return ss_load(v, (size_t)t.pix_base + (size_t)dy * t.w + dx);
-  return tc_blank();
-}
 __device__ __forceinline__ size_t ss_out_index(const DRenderArgs& A, const DTile& t, int dx, int dy) {
   return A.dense ? (size_t)t.pix_base + (size_t)dy * t.w + dx : (size_t)(t.y + dy) * A.width + (t.x + dx);
 }
@@ -305,26 +298,85 @@ __device__ __forceinline__ void ss_write_out(const DRenderArgs& A, const DTile& 
   if (A.packed) A.packed[o] = rgbf(c.r * c.a, c.g * c.a, c.b * c.a);
 }
 
+// One launch renders the frame: its work items are (pass, tile, region) in pass-major order, and an item of pass p waits
+// for the tile's pass p - 1 (a counter per tile and pass) instead of the whole frame's -- no launch boundary between the
+// passes, no tail of a short launch five times per frame, and the tiles that are early go on with their next pass while
+// the late ones finish the last.
+//   Order and progress: the items are dealt to kSSHeads queue heads by tile (tile mod kSSHeads); each head hands its items
+//   out in order, so whatever an item waits for (earlier passes of the SAME tile) was handed out before it, to a wave that
+//   is running: the oldest unfinished item of a head never waits.
+//   Visibility: the working buffer `v` is written by one wave and read by others, on other CUs and XCDs, inside one
+//   launch.  Every store to it is an agent-scope (sc1, write-through) store, every load an agent-scope (sc1) load that
+//   bypasses the CU's L1; a wave drains its stores (s_waitcnt vmcnt(0)) before it counts its region as done, and polls the
+//   counter with an agent-scope load before its first read (cdna_hip_programming.md, Guideline 16: payload and flag
+//   both sc1, producer drained).  The pixels of the frame are write-only.
+constexpr uint32_t kSSHeads = 8, kSSHeadStride = 32;
+__device__ __forceinline__ float ss_ld(const float* p) { return as_f(__hip_atomic_load((const unsigned int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+__device__ __forceinline__ void ss_st(float* p, float x) { __hip_atomic_store((unsigned int*)p, as_u(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ TC ss_load(const SSBuf& b, size_t i) { const float* p = b.v + i; return tc(ss_ld(p), ss_ld(p + b.plane), ss_ld(p + 2 * b.plane), ss_ld(p + 3 * b.plane), ss_ld(p + 4 * b.plane)); }
+__device__ __forceinline__ void ss_store(const SSBuf& b, size_t i, const TC& c) { float* p = b.v + i; ss_st(p, c.r); ss_st(p + b.plane, c.g); ss_st(p + 2 * b.plane, c.b); ss_st(p + 3 * b.plane, c.a); ss_st(p + 4 * b.plane, c.d); }
+__device__ __forceinline__ TC ss_getc(const SSBuf& v, const DTile& t, int dx, int dy) {  // getc: outside the tile reads blank
+  if (dx >= 0 && dx < t.w && dy >= 0 && dy < t.h) return ss_load(v, (size_t)t.pix_base + (size_t)dy * t.w + dx);
+  return tc_blank();
+}
+struct SSPlan {  // per pass: regions per tile, regions per tile row, first item of the pass in a head's sequence
+  uint32_t per_tile[6], nrx[6], first[7];
+  uint32_t tiles_per_head;
+};
+__device__ __forceinline__ SSPlan ss_plan(const DRenderArgs& A) {
+  SSPlan P;
+  P.tiles_per_head = ((uint32_t)A.ntiles + kSSHeads - 1) / kSSHeads;
+  P.first[1] = 0; P.per_tile[0] = 0; P.nrx[0] = 1; P.first[0] = 0;
+  for (int p = 1; p <= 5; p++) {
+    int nrx;
+    P.per_tile[p] = (uint32_t)ss_regions_per_tile(p, A.blocksize, nrx);  // laid out for full tiles; edge tiles leave regions empty
+    P.nrx[p] = (uint32_t)nrx;
+    P.first[p + 1] = P.first[p] + P.per_tile[p] * P.tiles_per_head;
+  }
+  return P;
+}
+
 template <class TIER>
-__device__ __forceinline__ void ss_pass_loop(const DRenderArgs& A, TIER& T, int pass) {
+__device__ __forceinline__ void ss_frame_loop(const DRenderArgs& A, TIER& T) {
   __shared__ uint32_t need_list[256];  // candidates of the region that need a sample: dx | dy << 8 (one wave per block)
   const SSBuf v{A.scratch, (size_t)A.ss_plane};
   const int lane = threadIdx.x & 63;
-  const float thr = pass >= 2 ? A.thresholds[pass - 2] : 0.0f;
-  int ox[4], oy[4];
-  ss_neighbours(pass, ox, oy);
-  int bw, bh, nrx;
-  ss_block_shape(pass, bw, bh);
-  const int rb = ss_region_blocks(pass);
-  const uint32_t per_tile = (uint32_t)ss_regions_per_tile(pass, A.blocksize, nrx);  // laid out for full tiles; edge tiles leave regions empty
-  const uint32_t total = per_tile * (uint32_t)A.ntiles;
+  const SSPlan PL = ss_plan(A);
+  uint32_t shard = blockIdx.x % kSSHeads, dry = 0;  // (lane 0's)
   for (;;) {
-    uint32_t w = 0;
-    if (lane == 0) w = atomicAdd(&A.ss_cnt[8 + pass], 1u);  // queue head of this pass
-    w = __shfl(w, 0, 64);
-    if (w >= total) break;
-    const DTile t = A.tiles[w / per_tile];
-    const int r = (int)(w % per_tile), rx = r % nrx, ry = r / nrx;
+    // ---- take the next item of a queue head (TicketQueue's scheme, over the frame's own heads)
+    uint32_t w = kNoTicket, h = 0;
+    if (lane == 0) {
+      while (dry != (1u << kSSHeads) - 1u) {
+        if (!((dry >> shard) & 1u)) {
+          const uint32_t i = atomicAdd(&A.ss_cnt[shard * kSSHeadStride], 1u);
+          if (i < PL.first[6]) { w = i; h = shard; break; }
+          atomicOr(&A.ss_cnt[kSSHeads * kSSHeadStride], 1u << shard);
+          dry |= (1u << shard) | __hip_atomic_load(&A.ss_cnt[kSSHeads * kSSHeadStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        shard = (shard + 1) % kSSHeads;
+      }
+    }
+    w = __shfl(w, 0, 64); h = __shfl(h, 0, 64);
+    if (w == kNoTicket) break;
+    int pass = 1;
+    while (w >= PL.first[pass + 1]) pass++;
+    const uint32_t j = w - PL.first[pass];
+    const uint32_t ti = (j / PL.per_tile[pass]) * kSSHeads + h;  // tile (ti mod kSSHeads == h)
+    if (ti >= (uint32_t)A.ntiles) continue;                       // padding of the last round of tiles
+    const int r = (int)(j % PL.per_tile[pass]), rx = r % (int)PL.nrx[pass], ry = r / (int)PL.nrx[pass];
+    const DTile t = A.tiles[ti];
+    unsigned int* done = A.ss_done + (size_t)ti * 8;
+    if (pass >= 2) {  // the tile's previous pass must be complete (its regions read each other's pixels)
+      if (lane == 0) while (__hip_atomic_load(&done[pass - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < PL.per_tile[pass - 1]) __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_wave_barrier();
+    }
+    const float thr = pass >= 2 ? A.thresholds[pass - 2] : 0.0f;
+    int ox[4], oy[4];
+    ss_neighbours(pass, ox, oy);
+    int bw, bh;
+    ss_block_shape(pass, bw, bh);
+    const int rb = ss_region_blocks(pass);
     // ---- decide: every candidate of the region takes the contrast test; the ones that need a sample are listed
     uint32_t n = 0;  // wave-uniform
     for (int sb = 0; sb < rb * rb; sb++) {
@@ -364,30 +416,34 @@ __device__ __forceinline__ void ss_pass_loop(const DRenderArgs& A, TIER& T, int 
       get_coordsf(A.width, A.height, (float)(t.x + dx) + off, (float)(t.y + dy) + off, xc, yc);
       Ray ray = primary_ray(A.cam, xc, yc);
       if (valid) T.cnt.primary++;
-      HitG h;
-      CA col = trace_primary(T, ray, kInf, A.maxdepth, valid, &h);
+      HitG hh;
+      CA col = trace_primary(T, ray, kInf, A.maxdepth, valid, &hh);
       if (!valid) continue;
-      TC s = tc(col.r, col.g, col.b, col.a, h.hit ? h.t : kInf);
-      if (pass < 5) ss_store(v, (size_t)t.pix_base + (size_t)dy * t.w + dx, s);
+      TC smp = tc(col.r, col.g, col.b, col.a, hh.hit ? hh.t : kInf);
+      if (pass < 5) ss_store(v, (size_t)t.pix_base + (size_t)dy * t.w + dx, smp);
       else {
         TC a = ss_getc(v, t, dx + ox[0], dy + oy[0]), bb = ss_getc(v, t, dx + ox[1], dy + oy[1]);
         TC c = ss_getc(v, t, dx + ox[2], dy + oy[2]), d = ss_getc(v, t, dx + ox[3], dy + oy[3]);
-        ss_write_out(A, t, dx, dy, ss_pass5_blend(s, a, bb, c, d, dx == t.w - 1, dy == t.h - 1));
+        ss_write_out(A, t, dx, dy, ss_pass5_blend(smp, a, bb, c, d, dx == t.w - 1, dy == t.h - 1));
       }
     }
     __syncthreads();  // the list is reused by the next region
+    if (pass < 5) {   // the region's pixels are in memory before it counts as done
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) atomicAdd(&done[pass], 1u);
+    }
   }
 }
 template <bool FULL, int CLS, int LB = 1, bool TWO_ROWS = false>
-__global__ void __launch_bounds__(64, LB) k_ss_pass_flat(DRenderArgs A, int pass, int stack_cap, uint32_t* ovf, int ovf_cap) {
+__global__ void __launch_bounds__(64, LB) k_ss_frame_flat(DRenderArgs A, int stack_cap, uint32_t* ovf, int ovf_cap) {
   extern __shared__ uint32_t lds[];
   FlatTier<false, false, FULL, CLS> T{A.S, A.lights, A.nlights, lane_stack<TWO_ROWS>(lds, stack_cap, ovf, ovf_cap), Cnt()};
-  ss_pass_loop(A, T, pass);
+  ss_frame_loop(A, T);
   if (A.want_counters) flush_counters(A.counters, T.cnt, 0);
 }
-__global__ void __launch_bounds__(64) k_ss_pass_generic(DRenderArgs A, int pass) {
+__global__ void __launch_bounds__(64) k_ss_frame_generic(DRenderArgs A) {
   GenericTier T{A.S, A.lights, A.nlights, Cnt()};
-  ss_pass_loop(A, T, pass);
+  ss_frame_loop(A, T);
   if (A.want_counters) flush_counters(A.counters, T.cnt, T.err);
   else if (__builtin_amdgcn_ballot_w64(T.err != 0) && (threadIdx.x & 63) == 0) atomicOr(&A.counters->error, 1u);
 }
@@ -956,38 +1012,39 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
   A.want_counters = (bare || (P->mode == GLOME_MODE_SUBSAMPLE && !stats)) ? 0 : 1;  // nobody reads them without `stats`
   hipEvent_t ev_start = ctx->ev0, ev_stop = ctx->ev1;
   if (A.ntiles > 0 && P->mode == GLOME_MODE_SUBSAMPLE) {
-    // scratch: v (5 floats per owned pixel) | 16 counters (per-pass queue heads)
+    // scratch: v (5 float planes over the owned pixels) | queue heads, one per 128-byte line, then the dry mask | one
+    // line of pass counters per tile
     size_t npx = (size_t)tt->pixels;
-    if ((rc = ensure_scratch(ctx, npx * 5 * sizeof(float) + 16 * sizeof(unsigned int)))) return rc;
+    const size_t ctl_words = (size_t)(kSSHeads + 1) * kSSHeadStride + (size_t)A.ntiles * 8;
+    if ((rc = ensure_scratch(ctx, npx * 5 * sizeof(float) + ctl_words * sizeof(unsigned int)))) return rc;
     A.scratch = ctx->slot().d_scratch;
     A.ss_cnt = (unsigned int*)(A.scratch + npx * 5);
+    A.ss_done = A.ss_cnt + (size_t)(kSSHeads + 1) * kSSHeadStride;
     A.ss_plane = (uint32_t)npx;
     A.blocksize = P->blocksize;
-    HIPCHK(ctx, hipMemsetAsync(A.ss_cnt, 0, 16 * sizeof(unsigned int), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(A.ss_cnt, 0, ctl_words * sizeof(unsigned int), ctx->stream));
     bool pooled = ctx->timing && (ctx->timing_seen++ % ctx->timing_stride) == 0 && ctx->pool_used + 2 <= (int)ctx->pool.size();
     hipEvent_t e0 = pooled ? ctx->pool[ctx->pool_used] : ctx->ev0, e1 = pooled ? ctx->pool[ctx->pool_used + 1] : ctx->ev1;
     if (pooled) ctx->pool_used += 2;
     ev_start = e0; ev_stop = e1;
     HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
-    const bool two_rows = use_two_rows(s, P) && scene_class(s) == CLS_BIH_TRI;  // (the sample passes have a triangle-class instance only)
+    const bool two_rows = use_two_rows(s, P) && scene_class(s) == CLS_BIH_TRI;  // (the sampler has a triangle-class instance only)
     size_t lds = s->dev.tier == 0 ? flat_lds_bytes(s->stack_cap, two_rows) : 0;
     bool full = s->has_nested_mats || (s->has_secondary_mats && P->maxdepth > 1);
     bool tri = s->dev.tier == 0 && (s->cls_mask & ~CLS_BIH_TRI) == 0;
+    uint32_t items = 0;
+    for (int pass = 1; pass <= 5; pass++) { int nbx; items += (uint32_t)ss_regions_per_tile(pass, P->blocksize, nbx) * (uint32_t)A.ntiles; }
+    // (a wave that is not resident yet holds no item, so the items a running wave waits for are always with running waves)
+    int tgrid = persistent_grid(ctx, lds, items, two_rows ? 24 : 32, grid_floor(s));
+    if (s->dev.tier == 0 && s->ovf_cap && (rc = ensure_overflow(ctx, tgrid, 1, s->ovf_cap))) return rc;
     uint32_t* ov = s->ovf_cap ? ctx->slot().d_ovf : nullptr;
-    for (int pass = 1; pass <= 5; pass++) {
-      int nbx;
-      uint32_t items = (uint32_t)ss_regions_per_tile(pass, P->blocksize, nbx) * (uint32_t)A.ntiles;
-      int tgrid = persistent_grid(ctx, lds, items, two_rows ? 24 : 32, grid_floor(s));
-      if (s->dev.tier == 0 && s->ovf_cap && (rc = ensure_overflow(ctx, tgrid, 1, s->ovf_cap))) return rc;
-      ov = s->ovf_cap ? ctx->slot().d_ovf : nullptr;
-      dim3 g(tgrid), blk(64);
-      if (s->dev.tier != 0) hipLaunchKernelGGL(k_ss_pass_generic, g, blk, 0, ctx->stream, A, pass);
-      else if (two_rows) hipLaunchKernelGGL((k_ss_pass_flat<false, CLS_BIH_TRI, 6, true>), g, blk, lds, ctx->stream, A, pass, s->stack_cap, ov, s->ovf_cap);
-      else if (tri && !full) hipLaunchKernelGGL((k_ss_pass_flat<false, CLS_BIH_TRI>), g, blk, lds, ctx->stream, A, pass, s->stack_cap, ov, s->ovf_cap);
-      else if (tri) hipLaunchKernelGGL((k_ss_pass_flat<true, CLS_BIH_TRI>), g, blk, lds, ctx->stream, A, pass, s->stack_cap, ov, s->ovf_cap);
-      else if (!full) hipLaunchKernelGGL((k_ss_pass_flat<false, CLS_ALL>), g, blk, lds, ctx->stream, A, pass, s->stack_cap, ov, s->ovf_cap);
-      else hipLaunchKernelGGL((k_ss_pass_flat<true, CLS_ALL>), g, blk, lds, ctx->stream, A, pass, s->stack_cap, ov, s->ovf_cap);
-    }
+    dim3 g(tgrid), blk(64);
+    if (s->dev.tier != 0) hipLaunchKernelGGL(k_ss_frame_generic, g, blk, 0, ctx->stream, A);
+    else if (two_rows) hipLaunchKernelGGL((k_ss_frame_flat<false, CLS_BIH_TRI, 6, true>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
+    else if (tri && !full) hipLaunchKernelGGL((k_ss_frame_flat<false, CLS_BIH_TRI>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
+    else if (tri) hipLaunchKernelGGL((k_ss_frame_flat<true, CLS_BIH_TRI>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
+    else if (!full) hipLaunchKernelGGL((k_ss_frame_flat<false, CLS_ALL>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
+    else hipLaunchKernelGGL((k_ss_frame_flat<true, CLS_ALL>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
   } else if (A.ntiles > 0) {

@@ -117,7 +117,8 @@ struct DRenderArgs {
   uint32_t shard_cap;   // tickets per queue head of this launch (whole chunks; the last round of chunks may be padding)
   int32_t dense;       // 1: out5 is a dense tile payload (tile order, row major inside a tile) instead of a frame
   float* scratch;      // adaptive sampler: dense per-tile working buffer `v` (owned pixels * 5 floats)
-  unsigned int* ss_cnt;  // adaptive sampler: [8 + pass] work-queue head of the pass
+  unsigned int* ss_cnt;  // adaptive sampler: queue heads (one per 128-byte line), then the mask of dry heads
+  unsigned int* ss_done; // adaptive sampler: [tile * 8 + pass] regions of the tile's pass that are complete
   uint32_t ss_plane;     // adaptive sampler: pixels per channel plane of the working buffer `scratch` (r | g | b | a | depth planes)
   int32_t blocksize;     // adaptive sampler: tile edge (<= 65); work items are laid out for full-size tiles
   float* out5;         // width*height*5
