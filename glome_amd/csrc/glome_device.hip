@@ -49,9 +49,9 @@ struct FlatTier {
     return finalize_flat<CLS>(S, r, c);
   }
   __device__ __forceinline__ bool occluded(const Ray& r, float d) { return occluded_flat<COUNT, CLS>(S, r, d, stk, cnt); }
-  // wave-wide calls (every lane of the wave makes them together; `valid` = the lane holds a ray).  Triangle and sphere
-  // BIHs are walked as packets in the lean kernels; kernels with out-of-line shader calls (FULL) keep the per-lane walk.
-  static constexpr bool PACKETS = !FULL_ && (CLS & (CLS_BIH_TRI | CLS_BIH_SPHERE)) != 0;
+  // wave-wide calls (every lane of the wave makes them together; `valid` = the lane holds a ray): triangle and sphere
+  // BIHs are walked as packets, by primary, shadow and secondary rays alike
+  static constexpr bool PACKETS = (CLS & (CLS_BIH_TRI | CLS_BIH_SPHERE)) != 0;
   __device__ __forceinline__ HitG closest_wave(const Ray& r, float tmax, bool valid) {
 #if defined(GLOME_EXP_TIMING)
     unsigned long long t0 = __builtin_readcyclecounter();
@@ -79,8 +79,6 @@ struct FlatTier {
     if constexpr (PACKETS) return occluded_flat<COUNT, CLS, true>(S, r, d, stk, cnt, valid);
     else return valid && occluded(r, d);
   }
-  __device__ __noinline__ HitG closest_ni(const Ray& r, float tmax) { return closest(r, tmax); }
-  __device__ __noinline__ bool occluded_ni(const Ray& r, float d) { return occluded(r, d); }
 };
 struct GenericTier {
   static constexpr bool FULL = true;
@@ -102,8 +100,6 @@ struct GenericTier {
     err = g.err;
     return o;
   }
-  __device__ __forceinline__ HitG closest_ni(const Ray& r, float tmax) { return closest(r, tmax); }  // rayint_g is out of line already
-  __device__ __forceinline__ bool occluded_ni(const Ray& r, float d) { return occluded(r, d); }
   __device__ __forceinline__ HitG closest_wave(const Ray& r, float tmax, bool valid) { return valid ? closest(r, tmax) : hit_miss(); }
   __device__ __forceinline__ bool occluded_wave(const Ray& r, float d, bool valid) { return valid && occluded(r, d); }
 };

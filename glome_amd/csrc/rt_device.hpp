@@ -1342,16 +1342,18 @@ GD float tx_weight(uint32_t fn, float constant, float p0, float p1, float p2, V3
 }
 
 // ------------------------------------------------------------------ trace / shade (Trace.hs:59-82, Shader.hs:65-184)
-// TIER supplies closest / occluded (force-inlined, for the primary path) and closest_ni / occluded_ni (one shared
-// out-of-line copy each, for secondary rays), and carries the lights + counters.
+// TIER supplies closest / occluded (per lane) and closest_wave / occluded_wave (all lanes of the wave together, `valid` =
+// the lane holds a ray), and carries the lights + counters.
 //
-// glome's trace <-> mpostshade recursion is bounded by `recurs` (maxdepth, Glome.hs:25).  On the device the bound
-// is static: TraceFn<R> only calls TraceFn<R-1>, PostFn<R,MD> only PostFn<R,MD-1>, each one out-of-line function,
-// so the call graph is a DAG and every stack frame is fixed.  The runtime `recurs` (<= R) carries the scene's
-// actual maxdepth.
+// glome's trace <-> mpostshade recursion is bounded by `recurs` (maxdepth, Glome.hs:25) and by the nesting of Blend /
+// AdditiveLayers materials.  On the device it is not a recursion at all: shade_vm below is the same evaluation as an
+// explicit state machine per lane (a frame per trace level, a frame per material being evaluated) whose two expensive
+// requests -- a closest hit, a light list -- are served for the whole wave at ONE place in the code.  So secondary rays
+// re-enter the same wave-wide traversal as primary rays (the lanes that hold one are the packet), nothing is called out
+// of line, and the kernel's registers are those of one traversal plus one shading step, not a nest of call frames.
 struct LightCache { bool done; uint32_t mask; };  // the lazily evaluated ctxb of Trace.hs:63: visibility per light
 
-template <bool INL, class TIER>
+template <class TIER>
 GD uint32_t preshade(TIER& T, const HitG& h) {  // mpreshade, Shader.hs:65-80 (Q18)
   uint32_t mask = 0;
   for (int i = 0; i < T.nlights; i++) {
@@ -1364,8 +1366,7 @@ GD uint32_t preshade(TIER& T, const HitG& h) {  // mpreshade, Shader.hs:65-80 (Q
     if (L.shadow) {
       T.cnt.shadow++;
       Ray sr; sr.o = vscaleadd(h.p, h.n, kDel); sr.d = ldir;
-      bool occ = INL ? T.occluded(sr, llen - (2 * kDel)) : T.occluded_ni(sr, llen - (2 * kDel));
-      if (occ) continue;
+      if (T.occluded(sr, llen - (2 * kDel))) continue;
     }
     mask |= 1u << i;
   }
@@ -1394,165 +1395,236 @@ GD uint32_t preshade_wave(TIER& T, const HitG& h, bool want) {
   return mask;
 }
 
-template <int R, class TIER> struct TraceFn;
-template <int R, int MD, class TIER> struct PostFn;
+// Surface, Shader.hs:90-105 (Q17): ambient + sum over the visible lights of lcolor * (blinn * ks + (l . n) * kd)
+template <class TIER>
+GD CA surface_shade(TIER& T, const F4& m1, const F4& m2, uint32_t lightmask, const Ray& ray, const HitG& h) {
+  const float amb = m2.x, kd = m2.y, ks = m2.z, shine = m2.w;
+  const V3 eyedir = vneg(ray.d), n = h.n, p = h.p;
+  float ar = m1.x * amb, ag = m1.y * amb, ab = m1.z * amb;  // cscale color amb
+  float dr = 0, dg = 0, db = 0;                             // foldl' cadd c_black
+  for (int i = 0; i < T.nlights; i++) {
+    if (!((lightmask >> i) & 1u)) continue;
+    const DLight& L = T.lights[i];
+    V3 lvec = v3(L.pos[0], L.pos[1], L.pos[2]) - p;
+    float llen = sqrtf(vdot(lvec, lvec));
+    V3 ldir = lvec * (1.0f / llen);
+    float fall = 1.0f / (llen * llen);  // falloff, Shader.hs:23
+    V3 half = vnorm(ldir + eyedir);     // bisect, Vec.hs:331-332
+    float ldotn = gmaxf(0, vdot(ldir, n));
+    float blinn = 0;
+    if (!(ks <= kDel)) {
+      float b = gmaxf(0, powf(vdot(half, n), shine) * ldotn);
+      blinn = (b != b) ? 0.0f : b;  // isNaN b
+    }
+    float diffuse = vdot(ldir, n);
+    float w = (blinn * ks) + (diffuse * kd);
+    dr = dr + (L.color[0] * fall) * w; dg = dg + (L.color[1] * fall) * w; db = db + (L.color[2] * fall) * w;
+  }
+  return ca(ar + dr, ag + dg, ab + db, m1.w);
+}
+GD Ray reflect_ray(const Ray& ray, const HitG& h) {  // Shader.hs:111-114: reflect (Vec.hs:340-342), origin p + out * delta
+  V3 outdir = vscaleadd(ray.d, h.n, (-2.0f) * vdot(ray.d, h.n));
+  Ray rr; rr.o = vscaleadd(h.p, outdir, kDel); rr.d = outdir;
+  return rr;
+}
+GD float refract_cs2(float ior, const Ray& ray, const HitG& h, float& eta, float& c1) {  // Shader.hs:128-136
+  eta = (vdot(h.n, vneg(ray.d)) > 0) ? ior : 1.0f / ior;
+  c1 = vdot(ray.d, h.n);
+  return 1 - (eta * eta) * (1 - (c1 * c1));
+}
 
-// mpostshade, Shader.hs:82-184 (Q17)
-template <int R, int MD, bool INL, class TIER>
-GD CA postshade_body(TIER& T, LightCache& lc, uint32_t mat, const Ray& ray, const HitG& h, int recurs) {
+// mpostshade of a lean kernel (TIER::FULL == false): launched only when no secondary trace can do work (maxdepth == 1 or no
+// Reflect / Refract material) and no material nests, so every child trace is `trace ... 0` = traceMiss (Trace.hs:60)
+template <class TIER>
+GD CA postshade_lean(TIER& T, LightCache& lc, uint32_t mat, const Ray& ray, const HitG& h, int recurs) {
   const DScene& S = T.S;
   F4 m0 = ld4(S.mats, 3 * mat), m1 = ld4(S.mats, 3 * mat + 1);
   uint32_t kind = as_u(m0.x);
-  V3 dir = ray.d, n = h.n, p = h.p;
-  V3 eyedir = vneg(dir);
   if (kind == DM_SURFACE) {
-    F4 m2 = ld4(S.mats, 3 * mat + 2);
-    float amb = m2.x, kd = m2.y, ks = m2.z, shine = m2.w;
-    if (!lc.done) { lc.mask = preshade<INL>(T, h); lc.done = true; }
-    float ar = m1.x * amb, ag = m1.y * amb, ab = m1.z * amb;  // cscale color amb
-    float dr = 0, dg = 0, db = 0;                             // foldl' cadd c_black
-    for (int i = 0; i < T.nlights; i++) {
-      if (!((lc.mask >> i) & 1u)) continue;
-      const DLight& L = T.lights[i];
-      V3 lvec = v3(L.pos[0], L.pos[1], L.pos[2]) - p;
-      float llen = sqrtf(vdot(lvec, lvec));
-      V3 ldir = lvec * (1.0f / llen);
-      float fall = 1.0f / (llen * llen);  // falloff, Shader.hs:23
-      V3 half = vnorm(ldir + eyedir);     // bisect, Vec.hs:331-332
-      float ldotn = gmaxf(0, vdot(ldir, n));
-      float blinn = 0;
-      if (!(ks <= kDel)) {
-        float b = gmaxf(0, powf(vdot(half, n), shine) * ldotn);
-        blinn = (b != b) ? 0.0f : b;  // isNaN b
-      }
-      float diffuse = vdot(ldir, n);
-      float w = (blinn * ks) + (diffuse * kd);
-      dr = dr + (L.color[0] * fall) * w; dg = dg + (L.color[1] * fall) * w; db = db + (L.color[2] * fall) * w;
-    }
-    return ca(ar + dr, ag + dg, ab + db, m1.w);
+    if (!lc.done) { lc.mask = preshade(T, h); lc.done = true; }
+    return surface_shade(T, m1, ld4(S.mats, 3 * mat + 2), lc.mask, ray, h);
   }
-  if (kind == DM_REFLECT) {  // Shader.hs:107-118; recurs > 0 always holds here (trace returns early at 0)
+  if (kind == DM_REFLECT) {  // Shader.hs:107-118
     float refl = m1.x;
-    if ((refl > 0) && (recurs > 0)) {
-      // lean kernels are only launched when no secondary trace can do work (maxdepth == 1 or no Reflect/Refract
-      // material): the child is `trace ... 0` = traceMiss
-      if constexpr (!TIER::FULL) return ca(0, 0, 0, 0 * refl);
-      V3 outdir = vscaleadd(dir, n, (-2.0f) * vdot(dir, n));  // reflect, Vec.hs:340-342
-      Ray rr; rr.o = vscaleadd(p, outdir, kDel); rr.d = outdir;
-      CA c = TraceFn<R - 1, TIER>::run(T, rr, kInf, recurs - 1);
-      return ca(c.r, c.g, c.b, c.a * refl);
-    }
-    return ca(0, 0, 0, 1);
+    return ((refl > 0) && (recurs > 0)) ? ca(0, 0, 0, 0 * refl) : ca(0, 0, 0, 1);
   }
-  if (kind == DM_REFRACT) {  // Shader.hs:120-155
-    float refl = m1.x, refr = m1.y, ior = m1.z;
-    if ((refl > 0 || refr > 0) && (recurs > 0)) {
-      if constexpr (!TIER::FULL) {  // both children are traceMiss, except total internal reflection -> ca_black
-        float eta0 = (vdot(n, eyedir) > 0) ? ior : 1.0f / ior;
-        float c10 = vdot(dir, n);
-        float cs20 = 1 - (eta0 * eta0) * (1 - (c10 * c10));
-        return ca(0, 0, 0, (cs20 < 0) ? (0 * refl + 1 * refr) : 0.0f);
-      }
-      V3 outdir = vscaleadd(dir, n, (-2.0f) * vdot(dir, n));
-      Ray rr; rr.o = vscaleadd(p, outdir, kDel); rr.d = outdir;
-      CA cr = TraceFn<R - 1, TIER>::run(T, rr, kInf, recurs - 1);
-      float eta = (vdot(n, eyedir) > 0) ? ior : 1.0f / ior;
-      float c1 = vdot(dir, n);
-      float cs2 = 1 - (eta * eta) * (1 - (c1 * c1));
-      CA ct = ca(0, 0, 0, 1);  // ca_black on total internal reflection
-      if (!(cs2 < 0)) {
-        V3 tv = (dir * eta) + (n * (eta * c1 - sqrtf(cs2)));  // unnormalised, as written
-        Ray tr; tr.o = vscaleadd(p, tv, kDel); tr.d = tv;
-        ct = TraceFn<R - 1, TIER>::run(T, tr, kInf, recurs - 1);
-      }
-      return ca(cr.r * refl + ct.r * refr, cr.g * refl + ct.g * refr, cr.b * refl + ct.b * refr, cr.a * refl + ct.a * refr);
-    }
+  if (kind == DM_REFRACT) {  // Shader.hs:120-155: both children are traceMiss, except total internal reflection -> ca_black
+    float refl = m1.x, refr = m1.y, eta, c1;
+    if ((refl > 0 || refr > 0) && (recurs > 0)) return ca(0, 0, 0, (refract_cs2(m1.z, ray, h, eta, c1) < 0) ? (0 * refl + 1 * refr) : 0.0f);
     return ca(0, 0, 0, 0);
-  }
-  if constexpr (MD > 0 && TIER::FULL) {
-    if (kind == DM_LAYERS) {  // casum, Clr.hs:93-103 (alphas :82-85)
-      uint32_t first = as_u(m0.y), count = as_u(m0.z);
-      float r = 0, g = 0, b = 0, prod = 1;
-      for (uint32_t k = 0; k < count; k++) {
-        CA c = PostFn<R, MD - 1, TIER>::run(T, lc, S.matkids[first + k], ray, h, recurs);
-        r = r + c.r * c.a; g = g + c.g * c.a; b = b + c.b * c.a;
-        prod = prod * (1 - aclamp(c.a));
-      }
-      return ca(r, g, b, 1 - prod);
-    }
-    if (kind == DM_BLEND) {  // Shader.hs:181-184
-      CA a = PostFn<R, MD - 1, TIER>::run(T, lc, as_u(m0.y), ray, h, recurs);
-      CA b = PostFn<R, MD - 1, TIER>::run(T, lc, as_u(m0.z), ray, h, recurs);
-      return caweight(a, b, tx_weight(as_u(m1.x), m0.w, m1.y, m1.z, m1.w, p));  // constant or a solid texture function of the hit point
-    }
   }
   return ca(0, 0, 0, 0);
 }
-template <int R, int MD, class TIER> struct PostFn {
-  static GDN CA run(TIER& T, LightCache& lc, uint32_t mat, const Ray& ray, const HitG& h, int recurs) {
-    return postshade_body<R, MD, false>(T, lc, mat, ray, h, recurs);
-  }
-};
-
-// trace, Trace.hs:59-82 (Q16): fold the hit's texture stack until opaque
-template <int R, bool INL, class TIER>
-GD CA shade_hit(TIER& T, const Ray& ray, const HitG& h, LightCache& lc, int recurs) {
+// trace's fold over the hit's texture stack until opaque (Trace.hs:67-80, Q16), lean kernels
+template <class TIER>
+GD CA shade_hit_lean(TIER& T, const Ray& ray, const HitG& h, LightCache& lc, int recurs) {
   CA acc = ca(0, 0, 0, 0);
   TexStack ts = h.tex;
   for (int k = 0; k < kMaxTexDepth; k++) {
     uint32_t id = (uint32_t)(ts & 0xffffu);
     if (id == 0) break;
     if (acc.a + kDel >= 1) break;  // opaque, Trace.hs:50-51
-    acc = cafold(acc, postshade_body<R, kMaxMatNest, INL>(T, lc, id - 1, ray, h, recurs));
+    acc = cafold(acc, postshade_lean(T, lc, id - 1, ray, h, recurs));
     ts >>= 16;
   }
   return acc;
 }
-template <int R, bool INL, class TIER>
-GD CA trace_body(TIER& T, const Ray& ray, float tmax, int recurs, HitG* hout) {
-  HitG h = INL ? T.closest(ray, tmax) : T.closest_ni(ray, tmax);
-  if (hout) *hout = h;
-  if (!h.hit) return ca(0, 0, 0, 0);  // mmissshade: transparent (Shader.hs:186-187)
-  LightCache lc; lc.done = false; lc.mask = 0;
-  return shade_hit<R, INL>(T, ray, h, lc, recurs);
+
+// ---- the general evaluation (TIER::FULL): trace (Trace.hs:59-82) and mpostshade (Shader.hs:82-184) as a state machine
+struct VMTrace {  // one `trace` in progress
+  Ray ray; int recurs; HitG h; LightCache lc; CA acc; TexStack ts; int k; int mbase;
+};
+struct VMMat {    // one material being evaluated: k = children done so far, tmp = what they have contributed
+  uint32_t mat; uint32_t k; CA tmp;
+};
+template <class TIER>
+GD CA shade_vm(TIER& T, const Ray& ray0, float tmax, int maxdepth, bool valid, HitG* hout) {
+  enum : int { S_NEED_HIT, S_HIT, S_TEX, S_MAT_NEW, S_NEED_LIGHTS, S_MAT_CHILD, S_MAT_TRACED, S_MAT_RET, S_TRACE_RET, S_DONE };
+  VMTrace tr[kMaxTraceDepth];
+  VMMat ms[kMaxTraceDepth * (kMaxMatNest + 1)];
+  const DScene& S = T.S;
+  int tl = 0, mi = 0, st = S_DONE;
+  CA ret = ca(0, 0, 0, 0);
+  *hout = hit_miss();
+  if (valid && maxdepth > 0) { tr[0].ray = ray0; tr[0].recurs = maxdepth; tr[0].mbase = 0; st = S_NEED_HIT; }
+  for (;;) {
+    // ---- the wave's requests: every lane that waits for a closest hit is traced now, together (so are the light lists)
+    const bool wh = st == S_NEED_HIT;
+    if (wave_any(wh)) {
+      const Ray r = wh ? tr[tl].ray : ray0;
+      const HitG h = T.closest_wave(r, tl == 0 ? tmax : kInf, wh);
+      if (wh) { tr[tl].h = h; if (tl == 0) *hout = h; st = S_HIT; }
+    }
+    const bool wl = st == S_NEED_LIGHTS;
+    if (wave_any(wl)) {
+      const uint32_t m = preshade_wave(T, tr[wl ? tl : 0].h, wl);
+      if (wl) { tr[tl].lc.mask = m; tr[tl].lc.done = true; st = S_MAT_NEW; }
+    }
+    if (!wave_any(st != S_DONE)) break;
+    // ---- this lane's own steps, until it needs the wave again
+    while (st != S_DONE && st != S_NEED_HIT && st != S_NEED_LIGHTS) {
+      VMTrace& t = tr[tl];
+      switch (st) {
+        case S_HIT:  // trace, after rayint (Trace.hs:62-66)
+          if (!t.h.hit) { ret = ca(0, 0, 0, 0); st = S_TRACE_RET; break; }  // mmissshade: transparent (Shader.hs:186-187)
+          t.lc.done = false; t.lc.mask = 0; t.acc = ca(0, 0, 0, 0); t.ts = t.h.tex; t.k = 0;
+          st = S_TEX;
+          break;
+        case S_TEX: {  // fold the texture stack head first until opaque (Trace.hs:67-80, Q16)
+          const uint32_t id = (uint32_t)(t.ts & 0xffffu);
+          if (t.k >= kMaxTexDepth || id == 0 || t.acc.a + kDel >= 1) { ret = t.acc; st = S_TRACE_RET; break; }
+          ms[mi].mat = id - 1; ms[mi].k = 0; mi++;
+          st = S_MAT_NEW;
+          break;
+        }
+        case S_MAT_NEW: {  // mpostshade of ms[mi - 1] (Shader.hs:82-184)
+          VMMat& m = ms[mi - 1];
+          const F4 m0 = ld4(S.mats, 3 * m.mat), m1 = ld4(S.mats, 3 * m.mat + 1);
+          const uint32_t kind = as_u(m0.x);
+          if (kind == DM_SURFACE) {
+            if (!t.lc.done) { st = S_NEED_LIGHTS; break; }  // the lazily evaluated light list (Trace.hs:63), forced here
+            ret = surface_shade(T, m1, ld4(S.mats, 3 * m.mat + 2), t.lc.mask, t.ray, t.h);
+            st = S_MAT_RET;
+          } else if (kind == DM_REFLECT || kind == DM_REFRACT) {  // Shader.hs:107-118, 120-155: the reflected ray comes first
+            const bool go = kind == DM_REFLECT ? (m1.x > 0) : (m1.x > 0 || m1.y > 0);
+            if (!(go && t.recurs > 0)) { ret = kind == DM_REFLECT ? ca(0, 0, 0, 1) : ca(0, 0, 0, 0); st = S_MAT_RET; break; }
+            m.k = 1;
+            if (t.recurs - 1 <= 0) { ret = ca(0, 0, 0, 0); st = S_MAT_TRACED; break; }  // `trace _ _ _ _ _ 0 = traceMiss` (Trace.hs:60)
+            VMTrace& c = tr[tl + 1];
+            c.ray = reflect_ray(t.ray, t.h); c.recurs = t.recurs - 1; c.mbase = mi;
+            T.cnt.secondary++;
+            tl++;
+            st = S_NEED_HIT;
+          } else if ((kind == DM_LAYERS || kind == DM_BLEND) && mi - t.mbase <= kMaxMatNest) {
+            m.k = 0; m.tmp = ca(0, 0, 0, 1);  // AdditiveLayers: (r, g, b) sums and the running product of (1 - alpha)
+            if (kind == DM_LAYERS && as_u(m0.z) == 0) { ret = ca(0, 0, 0, 1 - m.tmp.a); st = S_MAT_RET; break; }
+            ms[mi].mat = kind == DM_LAYERS ? S.matkids[as_u(m0.y)] : as_u(m0.y); ms[mi].k = 0; mi++;
+            st = S_MAT_NEW;
+          } else { ret = ca(0, 0, 0, 0); st = S_MAT_RET; }
+          break;
+        }
+        case S_MAT_CHILD: {  // a child material of ms[mi - 1] has been evaluated: `ret`
+          VMMat& m = ms[mi - 1];
+          const F4 m0 = ld4(S.mats, 3 * m.mat);
+          if (as_u(m0.x) == DM_LAYERS) {  // casum, Clr.hs:93-103 (alphas :82-85)
+            m.tmp.r = m.tmp.r + ret.r * ret.a; m.tmp.g = m.tmp.g + ret.g * ret.a; m.tmp.b = m.tmp.b + ret.b * ret.a;
+            m.tmp.a = m.tmp.a * (1 - aclamp(ret.a));
+            m.k++;
+            if (m.k < as_u(m0.z)) { ms[mi].mat = S.matkids[as_u(m0.y) + m.k]; ms[mi].k = 0; mi++; st = S_MAT_NEW; }
+            else { ret = ca(m.tmp.r, m.tmp.g, m.tmp.b, 1 - m.tmp.a); st = S_MAT_RET; }
+          } else {  // Blend, Shader.hs:181-184
+            if (m.k == 0) { m.tmp = ret; m.k = 1; ms[mi].mat = as_u(m0.z); ms[mi].k = 0; mi++; st = S_MAT_NEW; }
+            else {
+              const F4 m1 = ld4(S.mats, 3 * m.mat + 1);
+              ret = caweight(m.tmp, ret, tx_weight(as_u(m1.x), m0.w, m1.y, m1.z, m1.w, t.h.p));  // constant or a solid texture function of the hit point
+              st = S_MAT_RET;
+            }
+          }
+          break;
+        }
+        case S_MAT_TRACED: {  // a child trace of ms[mi - 1] (Reflect / Refract) has returned: `ret`
+          VMMat& m = ms[mi - 1];
+          const F4 m0 = ld4(S.mats, 3 * m.mat), m1 = ld4(S.mats, 3 * m.mat + 1);
+          if (as_u(m0.x) == DM_REFLECT) { ret = ca(ret.r, ret.g, ret.b, ret.a * m1.x); st = S_MAT_RET; break; }
+          const float refl = m1.x, refr = m1.y;
+          if (m.k == 1) {  // the reflected part is in; now the transmitted ray (unnormalised, as written, Shader.hs:141)
+            m.tmp = ret; m.k = 2;
+            float eta, c1;
+            const float cs2 = refract_cs2(m1.z, t.ray, t.h, eta, c1);
+            if (cs2 < 0) { ret = ca(0, 0, 0, 1); break; }  // total internal reflection: ca_black (state stays S_MAT_TRACED, k == 2)
+            if (t.recurs - 1 <= 0) { ret = ca(0, 0, 0, 0); break; }
+            const V3 tv = (t.ray.d * eta) + (t.h.n * (eta * c1 - sqrtf(cs2)));
+            VMTrace& c = tr[tl + 1];
+            c.ray.o = vscaleadd(t.h.p, tv, kDel); c.ray.d = tv; c.recurs = t.recurs - 1; c.mbase = mi;
+            T.cnt.secondary++;
+            tl++;
+            st = S_NEED_HIT;
+          } else {
+            const CA cr = m.tmp, ct = ret;
+            ret = ca(cr.r * refl + ct.r * refr, cr.g * refl + ct.g * refr, cr.b * refl + ct.b * refr, cr.a * refl + ct.a * refr);
+            st = S_MAT_RET;
+          }
+          break;
+        }
+        case S_MAT_RET:  // ms[mi - 1] is evaluated: `ret`
+          mi--;
+          if (mi == t.mbase) { t.acc = cafold(t.acc, ret); t.ts >>= 16; t.k++; st = S_TEX; }
+          else st = S_MAT_CHILD;
+          break;
+        case S_TRACE_RET:  // the trace of level tl is evaluated: `ret`
+          if (tl == 0) st = S_DONE;
+          else { tl--; st = S_MAT_TRACED; }
+          break;
+        default: st = S_DONE; break;
+      }
+    }
+  }
+  return ret;
 }
-template <int R, class TIER> struct TraceFn {
-  static GDN CA run(TIER& T, const Ray& ray, float tmax, int recurs) {
-    if (recurs <= 0) return ca(0, 0, 0, 0);  // `trace _ _ _ _ _ 0 = traceMiss`
-    T.cnt.secondary++;
-    return trace_body<R, false>(T, ray, tmax, recurs, (HitG*)0);
-  }
-};
-template <class TIER> struct TraceFn<0, TIER> {
-  static GD CA run(TIER&, const Ray&, float, int) { return ca(0, 0, 0, 0); }
-};
+
 // the pixel loop's entry: `Trace.trace lights shader sld ray infinity maxdepth` (Glome.hs:33), maxdepth <= kMaxTraceDepth.
-// Called by all lanes of a wave together (`valid` = the lane has a pixel): the primary rays and, where the first
-// material of the hit is a Surface -- which always forces the light list (Trace.hs:63, Shader.hs:96) -- the shadow rays
-// are traced wave-wide; every other case (lazy light lists under Reflect / Blend, secondary rays) stays per lane.
-// `coherent`: the wave's rays leave neighbouring pixels (an 8x8 block of a tile).  The adaptive sampler's compacted
-// sample lists are not -- 64 entries can span a whole tile -- and a packet over them visits nearly the sum of what
-// its rays visit, so those waves trace per lane.
-template <class TIER> GD CA trace_primary(TIER& T, const Ray& ray, float tmax, int maxdepth, bool valid, HitG* hout, bool coherent = true) {
-  if (maxdepth <= 0) { *hout = hit_miss(); return ca(0, 0, 0, 0); }
-  if (!coherent) {
-    if (!valid) { *hout = hit_miss(); return ca(0, 0, 0, 0); }
-    return trace_body<kMaxTraceDepth, true>(T, ray, tmax, maxdepth, hout);
+// Called by all lanes of a wave together (`valid` = the lane has a pixel).  Lean kernels: the primary rays and, where the
+// first material of the hit is a Surface -- which always forces the light list (Trace.hs:63, Shader.hs:96) -- the shadow
+// rays are traced wave-wide.  Full kernels: shade_vm.
+template <class TIER> GD CA trace_primary(TIER& T, const Ray& ray, float tmax, int maxdepth, bool valid, HitG* hout) {
+  if constexpr (TIER::FULL) return shade_vm(T, ray, tmax, maxdepth, valid, hout);
+  else {
+    if (maxdepth <= 0) { *hout = hit_miss(); return ca(0, 0, 0, 0); }
+    HitG h = T.closest_wave(ray, tmax, valid);
+    *hout = h;
+    LightCache lc; lc.done = false; lc.mask = 0;
+    bool eager = false;
+    if (valid && h.hit) {
+      uint32_t id = (uint32_t)(h.tex & 0xffffu);
+      if (id != 0) eager = as_u(ld4(T.S.mats, 3 * (id - 1)).x) == DM_SURFACE;
+    }
+    if (wave_any(eager)) {
+      uint32_t m = preshade_wave(T, h, eager);
+      if (eager) { lc.mask = m; lc.done = true; }
+    }
+    if (!(valid && h.hit)) return ca(0, 0, 0, 0);  // mmissshade: transparent (Shader.hs:186-187)
+    return shade_hit_lean(T, ray, h, lc, maxdepth);
   }
-  HitG h = T.closest_wave(ray, tmax, valid);
-  *hout = h;
-  LightCache lc; lc.done = false; lc.mask = 0;
-  bool eager = false;
-  if (valid && h.hit) {
-    uint32_t id = (uint32_t)(h.tex & 0xffffu);
-    if (id != 0) eager = as_u(ld4(T.S.mats, 3 * (id - 1)).x) == DM_SURFACE;
-  }
-  if (wave_any(eager)) {
-    uint32_t m = preshade_wave(T, h, eager);
-    if (eager) { lc.mask = m; lc.done = true; }
-  }
-  if (!(valid && h.hit)) return ca(0, 0, 0, 0);  // mmissshade: transparent (Shader.hs:186-187)
-  return shade_hit<kMaxTraceDepth, true>(T, ray, h, lc, maxdepth);
 }
 
 // ------------------------------------------------------------------ pixel mapping (Glome.hs:27-33, 119-140; Q19)

@@ -31,8 +31,6 @@ template <bool FAITHFUL, bool COUNT, bool FULL_> struct HostFlatTier {
   // on the host a wave is one lane: the packet code runs as a single-ray traversal
   HitG closest_wave(const Ray& r, float tmax, bool valid) { Cand c = closest_flat<FAITHFUL, COUNT, CLS_ALL, true>(S, r, tmax, stk, cnt, valid); return valid ? finalize_flat<CLS_ALL>(S, r, c) : hit_miss(); }
   bool occluded_wave(const Ray& r, float d, bool valid) { return occluded_flat<COUNT, CLS_ALL, true>(S, r, d, stk, cnt, valid); }
-  HitG closest_ni(const Ray& r, float tmax) { return closest(r, tmax); }
-  bool occluded_ni(const Ray& r, float d) { return occluded(r, d); }
 };
 struct HostGenericTier {
   static constexpr bool FULL = true;
@@ -43,8 +41,6 @@ struct HostGenericTier {
   unsigned int err = 0;
   HitG closest(const Ray& r, float tmax) { GPool pool; GCtx<true> g{S, cnt, err, pool}; HitG h = rayint_g<kGenericDepth>(g, S.recs[S.root_rec], r, tmax, (TexStack)0); err = g.err; return h; }
   bool occluded(const Ray& r, float d) { GPool pool; GCtx<true> g{S, cnt, err, pool}; bool o = shadow_g<kGenericDepth>(g, S.recs[S.root_rec], r, d); err = g.err; return o; }
-  HitG closest_ni(const Ray& r, float tmax) { return closest(r, tmax); }
-  bool occluded_ni(const Ray& r, float d) { return occluded(r, d); }
   HitG closest_wave(const Ray& r, float tmax, bool valid) { return valid ? closest(r, tmax) : hit_miss(); }
   bool occluded_wave(const Ray& r, float d, bool valid) { return valid && occluded(r, d); }
 };

@@ -202,3 +202,20 @@ def deep_and_clump(n=2500, seed=9, k=9):
     clump = sd.bih(sd.triangles_bulk(np.tile(tri, (k, 1))))
     root = sd.group([sd.tex(deep, scenes.matte(sd, (0.7, 0.6, 0.5))), sd.tex(clump, scenes.matte(sd, (0.2, 0.4, 0.9)))])
     return _finish(sd, root, nlights=1)
+
+
+def mirror_terrain(N=24):
+    """Secondary rays through the packet walk (north star: reflection rays compacted back into the wavefront traversal): a
+    heightfield of mirrors (Reflect 0.8, TestScene.hs:243) under `bih`, a glass-like Refract patch and matte spheres for the
+    mirrors to show; maxdepth 3 bounces between the terrain's own slopes."""
+    sd = SceneDesc()
+    m = scenes.materials(sd)
+    tri = scenes.heightfield_triangles(N) * np.array([0.6, 1.0, 0.6] * 3)
+    half = len(tri) // 2
+    terrain = sd.tex(sd.bih(sd.triangles_bulk(tri[:half])), m["mirror"])
+    glassy = sd.tex(sd.bih(sd.triangles_bulk(tri[half:])), sd.material_refract(0.3, 0.7, 1.3))
+    balls = sd.bih([sd.tex(sd.sphere((float(x), 2.2, float(z)), 0.5), scenes.matte(sd, (0.9, 0.3 + 0.1 * x, 0.2))) for x in (-3, 0, 3) for z in (-2, 2)])
+    return _finish(sd, sd.group([terrain, glassy, balls]))
+
+
+ALL["mirror_terrain"] = mirror_terrain
