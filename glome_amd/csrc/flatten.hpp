@@ -175,6 +175,23 @@ class Flattener {
     return p;
   }
 
+  // "CSG over primitives": what the flat tier evaluates without recursion (rt_device.hpp csg_item_rayint) -- a primitive, a
+  // Difference or Intersection whose operands are primitives, or an Instance of one of those (how `cylinder` / `cone` and
+  // TestScene.hs's transformed CSG shapes arrive); Tex / Tag / shadow-flag wrappers anywhere in between.
+  bool prim_under_wrappers(int id) const { return is_prim(G.at(peel(id).id).kind); }
+  bool csg_core(int id) const {
+    const Node& c = G.at(peel(id).id);
+    if (c.kind == K_DIFF) return prim_under_wrappers(c.a) && prim_under_wrappers(c.b);
+    if (c.kind == K_ISECT) { for (int k : c.kids) if (!prim_under_wrappers(k)) return false; return true; }
+    return false;
+  }
+  bool csg_simple(int id) const {
+    const Node& c = G.at(peel(id).id);
+    if (is_prim(c.kind)) return true;
+    if (c.kind == K_INSTANCE) return prim_under_wrappers(c.a) || csg_core(c.a);
+    return csg_core(id);
+  }
+
   // emit(id) -> the record VALUE for a reference to node id (children are written into F.recs / pools)
   U4 emit(int id) {
     auto it = memo.find(id);
@@ -235,7 +252,7 @@ class Flattener {
     const BihTree& T = *n.bih;
     F.max_bih_depth = std::max(F.max_bih_depth, T.depth);
     // classify
-    bool all_tri = true, all_sph = true, all_simple = true;
+    bool all_tri = true, all_sph = true, all_simple = true, all_csg = true;
     for (auto& bn : T.nodes) for (int it : bn.items) {
       Peeled p = peel(it);
       const Node& c = G.at(p.id);
@@ -243,8 +260,9 @@ class Flattener {
       all_simple &= simple;
       all_tri &= simple && c.kind == K_TRI && p.flags == 0;
       all_sph &= simple && c.kind == K_SPHERE && p.flags == 0;
+      all_csg &= csg_simple(it);
     }
-    uint32_t cls = all_tri ? BC_TRI : (all_sph ? BC_SPHERE : (all_simple ? BC_SIMPLE : BC_GENERIC));
+    uint32_t cls = all_tri ? BC_TRI : (all_sph ? BC_SPHERE : (all_simple ? BC_SIMPLE : (all_csg ? BC_CSG : BC_GENERIC)));
     uint32_t hdr = (uint32_t)(F.bihhdr.size() / 3);
     F.bihhdr.resize(F.bihhdr.size() + 3);  // reserved now: items of a generic BIH may emit nested BIHs before we fill it
     // Node slots: only branches (and leaves of 7+ items, whose extent lives in a slot) get one.  Branches are laid out
@@ -293,7 +311,7 @@ class Flattener {
       for (size_t q = 0; q < bn.items.size(); q++) {
         int it = bn.items[q];
         U4 rec;
-        if (cls == BC_GENERIC) rec = emit(it);
+        if (cls == BC_GENERIC || cls == BC_CSG) rec = emit(it);
         else {
           Peeled p = peel(it);
           rec = emit_prim(G.at(p.id));
@@ -410,6 +428,7 @@ class Flattener {
       case K_MESH: F.entries.push_back(U4{slot(emit(id)), incoming, flags, 0}); return;
       default:
         if (is_prim(n.kind) && n.kind != K_CYL && n.kind != K_CONE) { F.entries.push_back(U4{slot(emit(id)), incoming, flags, 0}); return; }
+        if (csg_simple(id)) { F.entries.push_back(U4{slot(emit(id)), incoming, flags, 0}); return; }  // a Difference / Intersection / Instance over primitives
         F.tier = 1; F.why_generic = std::string("root reaches a ") + kind_name(n.kind);
         return;
     }

@@ -44,39 +44,27 @@ struct FlatTier {
   int nlights;
   LaneStack stk;
   Cnt cnt;
+  unsigned int err = 0;  // a CSG item ran into the advance / frame cap (kernels with CLS_CSG)
   __device__ __forceinline__ HitG closest(const Ray& r, float tmax) {
-    Cand c = closest_flat<FAITHFUL, COUNT, CLS>(S, r, tmax, stk, cnt);
-    return finalize_flat<CLS>(S, r, c);
+    HitG ch;
+    Cand c = closest_flat<FAITHFUL, COUNT, CLS>(S, r, tmax, stk, cnt, true, &ch, &err);
+    return finalize_flat<CLS>(S, r, c, &ch);
   }
-  __device__ __forceinline__ bool occluded(const Ray& r, float d) { return occluded_flat<COUNT, CLS>(S, r, d, stk, cnt); }
+  __device__ __forceinline__ bool occluded(const Ray& r, float d) { return occluded_flat<COUNT, CLS>(S, r, d, stk, cnt, true, &err); }
   // wave-wide calls (every lane of the wave makes them together; `valid` = the lane holds a ray): triangle and sphere
   // BIHs are walked as packets, by primary, shadow and secondary rays alike
   static constexpr bool PACKETS = (CLS & (CLS_BIH_TRI | CLS_BIH_SPHERE)) != 0;
   __device__ __forceinline__ HitG closest_wave(const Ray& r, float tmax, bool valid) {
-#if defined(GLOME_EXP_TIMING)
-    unsigned long long t0 = __builtin_readcyclecounter();
-    Cand c0 = closest_flat<FAITHFUL, COUNT, CLS, true>(S, r, tmax, stk, cnt, valid);
-    unsigned long long t1 = __builtin_readcyclecounter();
-    HitG hh = valid ? finalize_flat<CLS>(S, r, c0) : hit_miss();
-    if ((threadIdx.x & 63) == 0) cnt.bih += (uint32_t)(t1 - t0);
-    return hh;
-#endif
     if constexpr (PACKETS) {
-      Cand c = closest_flat<FAITHFUL, COUNT, CLS, true>(S, r, tmax, stk, cnt, valid);
-      return valid ? finalize_flat<CLS>(S, r, c) : hit_miss();
+      HitG ch;
+      Cand c = closest_flat<FAITHFUL, COUNT, CLS, true>(S, r, tmax, stk, cnt, valid, &ch, &err);
+      return valid ? finalize_flat<CLS>(S, r, c, &ch) : hit_miss();
     } else {
       return valid ? closest(r, tmax) : hit_miss();
     }
   }
   __device__ __forceinline__ bool occluded_wave(const Ray& r, float d, bool valid) {
-#if defined(GLOME_EXP_TIMING)
-    unsigned long long t0 = __builtin_readcyclecounter();
-    bool oo = occluded_flat<COUNT, CLS, true>(S, r, d, stk, cnt, valid);
-    unsigned long long t1 = __builtin_readcyclecounter();
-    if ((threadIdx.x & 63) == 0) cnt.prim += (uint32_t)(t1 - t0);
-    return oo;
-#endif
-    if constexpr (PACKETS) return occluded_flat<COUNT, CLS, true>(S, r, d, stk, cnt, valid);
+    if constexpr (PACKETS) return occluded_flat<COUNT, CLS, true>(S, r, d, stk, cnt, valid, &err);
     else return valid && occluded(r, d);
   }
 };
@@ -262,7 +250,8 @@ __global__ void __launch_bounds__(64, LB) k_render_flat(DRenderArgs A, int stack
   extern __shared__ uint32_t lds[];
   FlatTier<FAITHFUL, COUNT, FULL, CLS> T{A.S, A.lights, A.nlights, lane_stack<TWO_ROWS>(lds, stack_cap, ovf, ovf_cap), Cnt()};
   render_loop(A, T);
-  if (A.want_counters) flush_counters(A.counters, T.cnt, 0);
+  if (A.want_counters) flush_counters(A.counters, T.cnt, T.err);
+  else if ((CLS & CLS_CSG) && __builtin_amdgcn_ballot_w64(T.err != 0) && (threadIdx.x & 63) == 0) atomicOr(&A.counters->error, 1u);
 }
 __global__ void __launch_bounds__(64) k_render_generic(DRenderArgs A) {
   GenericTier T{A.S, A.lights, A.nlights, Cnt()};
@@ -435,7 +424,8 @@ __global__ void __launch_bounds__(64, LB) k_ss_frame_flat(DRenderArgs A, int sta
   extern __shared__ uint32_t lds[];
   FlatTier<false, false, FULL, CLS> T{A.S, A.lights, A.nlights, lane_stack<TWO_ROWS>(lds, stack_cap, ovf, ovf_cap), Cnt()};
   ss_frame_loop(A, T);
-  if (A.want_counters) flush_counters(A.counters, T.cnt, 0);
+  if (A.want_counters) flush_counters(A.counters, T.cnt, T.err);
+  else if ((CLS & CLS_CSG) && __builtin_amdgcn_ballot_w64(T.err != 0) && (threadIdx.x & 63) == 0) atomicOr(&A.counters->error, 1u);
 }
 __global__ void __launch_bounds__(64) k_ss_frame_generic(DRenderArgs A) {
   GenericTier T{A.S, A.lights, A.nlights, Cnt()};
@@ -466,17 +456,19 @@ __device__ __forceinline__ Ray load_ray(const RayStream& R, size_t i) {
   return r;
 }
 template <bool FAITHFUL>
-__global__ void __launch_bounds__(64) k_rayint_batch_flat(DScene S, size_t n, RayStream R, HitStream H, int stack_cap, uint32_t* ovf, int ovf_cap) {
+__global__ void __launch_bounds__(64) k_rayint_batch_flat(DScene S, size_t n, RayStream R, HitStream H, int stack_cap, uint32_t* ovf, int ovf_cap, DCounters* c) {
   extern __shared__ uint32_t lds[];
-  FlatTier<FAITHFUL, false, false, CLS_ALL> T{S, nullptr, 0, lane_stack(lds, stack_cap, ovf, ovf_cap), Cnt()};
+  FlatTier<FAITHFUL, false, false, CLS_EVERY> T{S, nullptr, 0, lane_stack(lds, stack_cap, ovf, ovf_cap), Cnt()};
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     store_hit(H, i, T.closest(load_ray(R, i), R.tmax[i]));
+  if (T.err) atomicOr(&c->error, 1u);
 }
-__global__ void __launch_bounds__(64) k_shadow_batch_flat(DScene S, size_t n, RayStream R, uint8_t* occ, int stack_cap, uint32_t* ovf, int ovf_cap) {
+__global__ void __launch_bounds__(64) k_shadow_batch_flat(DScene S, size_t n, RayStream R, uint8_t* occ, int stack_cap, uint32_t* ovf, int ovf_cap, DCounters* c) {
   extern __shared__ uint32_t lds[];
-  FlatTier<false, false, false, CLS_ALL> T{S, nullptr, 0, lane_stack(lds, stack_cap, ovf, ovf_cap), Cnt()};
+  FlatTier<false, false, false, CLS_EVERY> T{S, nullptr, 0, lane_stack(lds, stack_cap, ovf, ovf_cap), Cnt()};
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     occ[i] = T.occluded(load_ray(R, i), R.tmax[i]) ? 1 : 0;
+  if (T.err) atomicOr(&c->error, 1u);
 }
 __global__ void __launch_bounds__(64) k_rayint_batch_generic(DScene S, size_t n, RayStream R, HitStream H, DCounters* c) {
   GenericTier T{S, nullptr, 0, Cnt()};
@@ -827,8 +819,9 @@ glome_scene* glome_scene_commit(glome_ctx* ctx, glome_sb* sb, int32_t root) {
     for (const U4& e : F.entries) {
       const U4& r = F.recs[e.x];
       uint32_t k = r.x & RF_KINDMASK;
-      if (k == R_BIH) { uint32_t c; memcpy(&c, &F.bihhdr[3 * r.y + 1].w, 4); m |= c == BC_TRI ? CLS_BIH_TRI : (c == BC_SPHERE ? CLS_BIH_SPHERE : CLS_BIH_SIMPLE); }
+      if (k == R_BIH) { uint32_t c; memcpy(&c, &F.bihhdr[3 * r.y + 1].w, 4); m |= c == BC_TRI ? CLS_BIH_TRI : (c == BC_SPHERE ? CLS_BIH_SPHERE : (c == BC_CSG ? CLS_CSG : CLS_BIH_SIMPLE)); }
       else if (k == R_MESH) m |= CLS_MESH;
+      else if (k > R_CONE) m |= CLS_CSG;  // a Difference / Intersection / Instance over primitives in the root list
       else if (k != R_VOID) m |= CLS_PRIMS;
     }
     s->cls_mask = m;
@@ -917,6 +910,7 @@ static int reset_counters(glome_ctx* ctx) {
 
 static int scene_class(const glome_scene* s) {  // scene class -> the smallest kernel instance that covers it (SPECIALIZE analogue, Bih.hs:370-374)
   int m = s->cls_mask;
+  if (m & CLS_CSG) return CLS_EVERY;
   return (m & ~CLS_BIH_TRI) == 0 ? CLS_BIH_TRI : ((m & ~(CLS_BIH_SPHERE | CLS_PRIMS)) == 0 ? (CLS_BIH_SPHERE | CLS_PRIMS) : ((m & ~CLS_MESH) == 0 ? CLS_MESH : CLS_ALL));
 }
 // every ray of the frame is walked as a packet (see k_render_flat): two stack rows per entry, six waves per SIMD
@@ -944,6 +938,7 @@ static void launch_render(glome_scene* s, const DRenderArgs& A, const glome_rend
       if (cls == CLS_BIH_TRI) GLOME_LAUNCH(F, C, U, CLS_BIH_TRI, 1);              \
       else if (cls == (CLS_BIH_SPHERE | CLS_PRIMS)) GLOME_LAUNCH(F, C, U, (CLS_BIH_SPHERE | CLS_PRIMS), 1); \
       else if (cls == CLS_MESH) GLOME_LAUNCH(F, C, U, CLS_MESH, 1);               \
+      else if (cls == CLS_EVERY) GLOME_LAUNCH(F, C, U, CLS_EVERY, 1);             \
       else GLOME_LAUNCH(F, C, U, CLS_ALL, 1);                                     \
     } while (0)
     if (use_two_rows(s, P, A.total_waves * (uint32_t)A.nframes)) {
@@ -952,8 +947,8 @@ static void launch_render(glome_scene* s, const DRenderArgs& A, const glome_rend
       if (cls == CLS_BIH_TRI) hipLaunchKernelGGL((k_render_flat<false, false, false, CLS_BIH_TRI, 6, true>), g, blk, lds2, st, A, s->stack_cap, ov, s->ovf_cap);
       else hipLaunchKernelGGL((k_render_flat<false, false, false, (CLS_BIH_SPHERE | CLS_PRIMS), 6, true>), g, blk, lds2, st, A, s->stack_cap, ov, s->ovf_cap);
     } else
-    if (faithful) { if (full) GLOME_LAUNCH(true, true, true, CLS_ALL, 1); else GLOME_LAUNCH(true, true, false, CLS_ALL, 1); }
-    else if (count) { if (full) GLOME_LAUNCH(false, true, true, CLS_ALL, 1); else GLOME_LAUNCH(false, true, false, CLS_ALL, 1); }
+    if (faithful) { if (full) GLOME_LAUNCH(true, true, true, CLS_EVERY, 1); else GLOME_LAUNCH(true, true, false, CLS_EVERY, 1); }
+    else if (count) { if (full) GLOME_LAUNCH(false, true, true, CLS_EVERY, 1); else GLOME_LAUNCH(false, true, false, CLS_EVERY, 1); }
     else if (full) GLOME_BY_CLS(false, false, true);
     else GLOME_BY_CLS(false, false, false);
 #undef GLOME_BY_CLS
@@ -1039,8 +1034,8 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
     else if (two_rows) hipLaunchKernelGGL((k_ss_frame_flat<false, CLS_BIH_TRI, 6, true>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
     else if (tri && !full) hipLaunchKernelGGL((k_ss_frame_flat<false, CLS_BIH_TRI>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
     else if (tri) hipLaunchKernelGGL((k_ss_frame_flat<true, CLS_BIH_TRI>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
-    else if (!full) hipLaunchKernelGGL((k_ss_frame_flat<false, CLS_ALL>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
-    else hipLaunchKernelGGL((k_ss_frame_flat<true, CLS_ALL>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
+    else if (!full) hipLaunchKernelGGL((k_ss_frame_flat<false, CLS_EVERY>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
+    else hipLaunchKernelGGL((k_ss_frame_flat<true, CLS_EVERY>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
   } else if (A.ntiles > 0) {
@@ -1143,7 +1138,7 @@ int glome_rayint_batch_dev(glome_scene* s, size_t n, const float* ox, const floa
     size_t lds = flat_lds_bytes(s->stack_cap);
     int grid = batch_grid(ctx, n, lds), rc;
     if (s->ovf_cap && (rc = ensure_overflow(ctx, grid, 1, s->ovf_cap))) return rc;
-    hipLaunchKernelGGL((k_rayint_batch_flat<false>), dim3(grid), dim3(64), lds, ctx->stream, s->dev, n, R, H, s->stack_cap, s->ovf_cap ? ctx->slot().d_ovf : nullptr, s->ovf_cap);
+    hipLaunchKernelGGL((k_rayint_batch_flat<false>), dim3(grid), dim3(64), lds, ctx->stream, s->dev, n, R, H, s->stack_cap, s->ovf_cap ? ctx->slot().d_ovf : nullptr, s->ovf_cap, ctx->slot().d_counters);
   } else {
     if (int rcc = reset_counters(ctx)) return rcc;
     hipLaunchKernelGGL(k_rayint_batch_generic, dim3(batch_grid(ctx, n, 0)), dim3(64), 0, ctx->stream, s->dev, n, R, H, ctx->slot().d_counters);
@@ -1163,7 +1158,7 @@ int glome_shadow_batch_dev(glome_scene* s, size_t n, const float* ox, const floa
     size_t lds = flat_lds_bytes(s->stack_cap);
     int grid = batch_grid(ctx, n, lds), rc;
     if (s->ovf_cap && (rc = ensure_overflow(ctx, grid, 1, s->ovf_cap))) return rc;
-    hipLaunchKernelGGL(k_shadow_batch_flat, dim3(grid), dim3(64), lds, ctx->stream, s->dev, n, R, occluded, s->stack_cap, s->ovf_cap ? ctx->slot().d_ovf : nullptr, s->ovf_cap);
+    hipLaunchKernelGGL(k_shadow_batch_flat, dim3(grid), dim3(64), lds, ctx->stream, s->dev, n, R, occluded, s->stack_cap, s->ovf_cap ? ctx->slot().d_ovf : nullptr, s->ovf_cap, ctx->slot().d_counters);
   } else {
     if (int rcc = reset_counters(ctx)) return rcc;
     hipLaunchKernelGGL(k_shadow_batch_generic, dim3(batch_grid(ctx, n, 0)), dim3(64), 0, ctx->stream, s->dev, n, R, occluded, ctx->slot().d_counters);
@@ -1205,7 +1200,7 @@ int glome_rayint_batch(glome_scene* s, size_t n, const float* ox, const float* o
   int rc = glome_rayint_batch_dev(s, n, din[0], din[1], din[2], din[3], din[4], din[5], din[6], dt, dprim, dnx, dny, dnz, dtex);
   if (rc) return rc;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  if (s->dev.tier != 0 && (rc = check_device_error(ctx))) return rc;
+  if ((rc = check_device_error(ctx))) return rc;
   if (t) HIPCHK(ctx, hipMemcpy(t, dt, n * 4, hipMemcpyDeviceToHost));
   if (prim) HIPCHK(ctx, hipMemcpy(prim, dprim, n * 4, hipMemcpyDeviceToHost));
   if (nx) HIPCHK(ctx, hipMemcpy(nx, dnx, n * 4, hipMemcpyDeviceToHost));
@@ -1229,7 +1224,7 @@ int glome_shadow_batch(glome_scene* s, size_t n, const float* ox, const float* o
   int rc = glome_shadow_batch_dev(s, n, din[0], din[1], din[2], din[3], din[4], din[5], din[6], docc);
   if (rc) return rc;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  if (s->dev.tier != 0 && (rc = check_device_error(ctx))) return rc;
+  if ((rc = check_device_error(ctx))) return rc;
   HIPCHK(ctx, hipMemcpy(occluded, docc, n, hipMemcpyDeviceToHost));
   return 0;
 }

@@ -1112,12 +1112,6 @@ GD void mesh_closest(const DScene& S, uint32_t mh, const Ray& ray, float depth, 
   }
 }
 
-// ------------------------------------------------------------------ flat tier
-// A candidate is (t, id, aux): id = record index of the primitive (or mesh-triangle index when aux has
-// CAND_MESH); aux = entry index.  Normals are derived after traversal (finalize_flat).
-struct Cand { float t; uint32_t id; uint32_t aux; };
-constexpr uint32_t CAND_NONE = 0xffffffffu;
-constexpr uint32_t CAND_MESH = 0x80000000u;
 
 struct HitG {  // a full Rayint (Solid.hs:20-28 minus riray / riuvw, which the shader never reads)
   bool hit;
@@ -1128,16 +1122,249 @@ struct HitG {  // a full Rayint (Solid.hs:20-28 minus riray / riuvw, which the s
 };
 GD HitG hit_miss() { HitG h; h.hit = false; h.t = kInf; h.p = v3(0, 0, 0); h.n = v3(0, 0, 0); h.tex = 0; h.uid = 0xffffffffu; return h; }
 
+
+// ------------------------------------------------------------------ CSG over primitives, without recursion (flat tier)
+// Difference / Intersection whose operands are primitives (under any Tex wrappers), and an Instance of a primitive or of
+// such a node: TestScene.hs's carved spheres and boxes, `sphereint`, plane-cut polyhedra, and every `cylinder` / `cone`
+// (Cone.hs:40-67 wraps the canonical quadric in an Instance).  The reference's class methods recurse through
+// dictionaries; with primitive operands each call bottoms out at once, so the methods are plain loops here, inlined into
+// the flat tier's kernels.  (Composites below composites go to the generic tier's interpreter, rt_generic.hpp.)
+// One explicit frame of rayint_intersection's list recursion (isect_rayint).  `from` holds the list position and, in
+// its top two bits, the frame's state; `aux` is the state's one live distance (state 1: the inside hit's depth, state 2:
+// the advance added back on return).
+struct IFrame { uint32_t from; float ox, oy, oz, d, aux; };
+GD HitG nearest_hit(const HitG& a, const HitG& b) {  // nearest, Solid.hs:37-44: ties -> b
+  if (!b.hit) return a;
+  if (!a.hit) return b;
+  return (a.t < b.t) ? a : b;
+}
+GD TexStack own_stack_rayint(uint32_t own) { return (TexStack)own; }  // innermost Tex first (Tex.hs:66)
+GD TexStack own_stack_meta(uint32_t own) {                             // get_metainfo: outermost Tex first (Tex.hs:73-74)
+  if (own >> 16) return (TexStack)((own >> 16) | ((own & 0xffffu) << 16));
+  return (TexStack)own;
+}
+
+struct Xf6 { F4 f0, f1, f2, i0, i1, i2; };
+GD Xf6 load_xf(const DScene& S, uint32_t x) {
+  Xf6 m;
+  m.f0 = ld4(S.xfms, 6 * x); m.f1 = ld4(S.xfms, 6 * x + 1); m.f2 = ld4(S.xfms, 6 * x + 2);
+  m.i0 = ld4(S.xfms, 6 * x + 3); m.i1 = ld4(S.xfms, 6 * x + 4); m.i2 = ld4(S.xfms, 6 * x + 5);
+  return m;
+}
+GD V3 mat_point(const F4& r0, const F4& r1, const F4& r2, V3 v) {  // xfm_point / invxfm_point, Vec.hs:502-519
+  return v3(r0.x * v.x + r0.y * v.y + r0.z * v.z + r0.w, r1.x * v.x + r1.y * v.y + r1.z * v.z + r1.w, r2.x * v.x + r2.y * v.y + r2.z * v.z + r2.w);
+}
+GD V3 mat_vec(const F4& r0, const F4& r1, const F4& r2, V3 v) {  // xfm_vec / invxfm_vec, Vec.hs:522-539
+  return v3(r0.x * v.x + r0.y * v.y + r0.z * v.z, r1.x * v.x + r1.y * v.y + r1.z * v.z, r2.x * v.x + r2.y * v.y + r2.z * v.z);
+}
+GD V3 mat_tvec(const F4& r0, const F4& r1, const F4& r2, V3 v) {  // invxfm_norm: transpose, Vec.hs:543-550
+  return v3(r0.x * v.x + r1.x * v.y + r2.x * v.z, r0.y * v.x + r1.y * v.y + r2.y * v.z, r0.z * v.x + r1.z * v.y + r2.z * v.z);
+}
+
+
+template <bool C> GD HitG leaf_rayint(const DScene& S, Cnt& cnt, U4 rec, const Ray& r, float d, TexStack tex) {  // a primitive under Tex records
+  for (;;) {  // Tex s tex: rayint s r d (tex:texs) tags, Tex.hs:66
+    if (rec.x & RF_NOVIS) return hit_miss();
+    if ((rec.x & RF_KINDMASK) != R_TEX) break;
+    tex = tex_push(tex, rec.z);
+    rec = ldu4(S.recs, rec.y);
+  }
+  HitG h = hit_miss();
+  if (C) cnt.prim++;
+  float t; V3 n;
+  if (!prim_test<true>(S, rec.x & RF_KINDMASK, rec.y, r, d, t, n)) return h;
+  h.hit = true; h.t = t; h.n = n; h.p = vscaleadd(r.o, r.d, t);
+  h.tex = tex_cat(own_stack_rayint(rec.z), tex); h.uid = rec.w;
+  return h;
+}
+GD U4 skip_tex(const DScene& S, U4 rec) {  // strip Tex records (and stop at the first non-Tex record)
+  while ((rec.x & RF_KINDMASK) == R_TEX) rec = ldu4(S.recs, rec.y);
+  return rec;
+}
+GD bool leaf_inside(const DScene& S, U4 rec, V3 p) { rec = skip_tex(S, rec); return prim_inside(S, rec.x & RF_KINDMASK, rec.y, p); }
+GD TexStack leaf_meta(const DScene& S, U4 rec) {  // get_metainfo of a primitive under Tex records: tex : texs, outermost first (Tex.hs:73-74)
+  TexStack pre = 0;
+  while ((rec.x & RF_KINDMASK) == R_TEX) { pre = tex_cat(pre, (TexStack)(rec.z + 1)); rec = ldu4(S.recs, rec.y); }
+  return tex_cat(pre, own_stack_meta(rec.z));
+}
+// rayint_difference, Csg.hs:33-54 (Q13); the self-recursion through rayint_advance (Solid.hs:85-91) is a loop
+template <bool C> GD HitG csg_diff(const DScene& S, Cnt& cnt, unsigned int& err, U4 rec, const Ray& r0, float d0, TexStack tex) {
+  const U4 ra = ldu4(S.recs, rec.y), rb = ldu4(S.recs, rec.z);
+  float adds[kCsgMaxAdvance];
+  int na = 0;
+  Ray r = r0;
+  float d = d0;
+  HitG res = hit_miss();
+  for (;;) {
+    const bool inb = leaf_inside(S, rb, r.o);
+    HitG ha = hit_miss();
+    if (!inb) { ha = leaf_rayint<C>(S, cnt, ra, r, d, tex); if (!ha.hit) break; }
+    HitG hb = leaf_rayint<C>(S, cnt, rb, r, d, tex);
+    if (inb) {
+      if (!hb.hit) break;
+      if (leaf_inside(S, ra, hb.p) && !leaf_inside(S, rb, vscaleadd(hb.p, r.d, kDel))) {
+        hb.n = vneg(hb.n);
+        hb.tex = leaf_meta(S, ra);  // `difference` = Difference a b True: textures of A at the carved point
+        res = hb;
+        break;
+      }
+    } else {
+      if (!hb.hit) { res = ha; break; }
+      if (ha.t < hb.t) { res = ha; break; }
+    }
+    if (na >= kCsgMaxAdvance) { err = 1; break; }
+    const float a = hb.t + kDel;
+    adds[na++] = a;
+    r.o = vscaleadd(r.o, r.d, a);  // ray_move
+    d = d - a;
+  }
+  if (res.hit) for (int k = na - 1; k >= 0; k--) res.t = res.t + adds[k];  // RayHit (depth+a) ..., innermost first
+  return res;
+}
+// rayint_intersection, Csg.hs:68-90 (Q14): the recursion on the list tail and on the advanced ray as explicit frames
+template <bool C> GD HitG csg_isect(const DScene& S, Cnt& cnt, unsigned int& err, U4 rec, const Ray& r0, float d0, TexStack tex) {
+  constexpr uint32_t kSt1 = 1u << 30, kSt2 = 2u << 30, kFrom = (1u << 30) - 1u;
+  const uint32_t n = rec.z;
+  IFrame fr[kIsectFrames];
+  int sp = 0;
+  auto push = [&](uint32_t from, V3 o, float d) { IFrame& c = fr[sp]; c.from = from; c.ox = o.x; c.oy = o.y; c.oz = o.z; c.d = d; c.aux = 0; };
+  push(0, r0.o, d0);
+  HitG ret = hit_miss();
+  bool returning = false;  // true: frame fr[sp] has completed with `ret`
+  for (;;) {
+    if (!returning) {
+      IFrame& f = fr[sp];
+      const uint32_t from = f.from & kFrom;
+      Ray r; r.o = v3(f.ox, f.oy, f.oz); r.d = r0.d;
+      if (from >= n || f.d < 0) { ret = hit_miss(); returning = true; continue; }  // null slds || d < 0
+      const U4 s = ldu4(S.recs, rec.y + from);
+      HitG hs = leaf_rayint<C>(S, cnt, s, r, f.d, tex);
+      if (from + 1 == n) { ret = hs; returning = true; continue; }  // [] -> rayint s r d t tags
+      if (leaf_inside(S, s, r.o)) {
+        if (!hs.hit) { f.from = from + 1; continue; }  // RayMiss -> rayint (Intersection ss) r d: a tail call
+        if (sp + 1 >= kIsectFrames) { err = 1; return hit_miss(); }
+        f.aux = hs.t; f.from = from | kSt1;  // rest = rayint (Intersection ss) r sd
+        sp++; push(from + 1, r.o, hs.t);
+        continue;
+      }
+      if (!hs.hit) { ret = hit_miss(); returning = true; continue; }
+      bool all = true;  // inside (Intersection ss) sp: foldl' (&&) True
+      for (uint32_t k = from + 1; k < n; k++) all = all && leaf_inside(S, ldu4(S.recs, rec.y + k), hs.p);
+      if (all) { ret = hs; returning = true; continue; }  // RayHit sd sp sn r vzero st stags
+      if (sp + 1 >= kIsectFrames) { err = 1; return hit_miss(); }
+      const float a = hs.t + kDel;  // rayint_advance (Intersection slds) r d t tags sd
+      f.from = from | kSt2; f.aux = a;
+      sp++; push(from, vscaleadd(r.o, r.d, a), f.d - a);
+      continue;
+    }
+    if (sp == 0) return ret;
+    sp--;
+    IFrame& p = fr[sp];
+    if ((p.from & ~kFrom) == kSt1) {
+      if (ret.hit) continue;  // hit -> hit
+      if (sp + 1 >= kIsectFrames) { err = 1; return hit_miss(); }
+      const float a = p.aux + kDel;
+      const uint32_t pf = p.from & kFrom;
+      p.from = pf | kSt2; p.aux = a;
+      const V3 po = v3(p.ox, p.oy, p.oz);
+      const float pd = p.d;
+      sp++; push(pf, vscaleadd(po, r0.d, a), pd - a);
+      returning = false;
+      continue;
+    }
+    if (ret.hit) ret.t = ret.t + p.aux;  // state 2: RayHit (depth+a) ...
+  }
+}
+// rayint of a flat-tier CSG item: primitive | Difference | Intersection, optionally inside one Instance (Solid.hs:388-403, Q8)
+template <bool C> GD HitG csg_item_rayint(const DScene& S, Cnt& cnt, unsigned int& err, U4 rec, const Ray& ray, float d, TexStack tex) {
+  for (;;) {  // Tex records over a composite
+    if (rec.x & RF_NOVIS) return hit_miss();
+    if ((rec.x & RF_KINDMASK) != R_TEX) break;
+    tex = tex_push(tex, rec.z);
+    rec = ldu4(S.recs, rec.y);
+  }
+  Ray r = ray;
+  float dd = d, invlenscale = 1.0f;
+  Xf6 x{};
+  const bool inst = (rec.x & RF_KINDMASK) == R_INSTANCE;
+  if (inst) {
+    x = load_xf(S, rec.z);
+    const V3 newdir = mat_vec(x.i0, x.i1, x.i2, ray.d), neworig = mat_point(x.i0, x.i1, x.i2, ray.o);
+    const float lenscale = sqrtf(vdot(newdir, newdir));
+    invlenscale = 1.0f / lenscale;
+    r.o = neworig; r.d = newdir * invlenscale;
+    dd = d * lenscale;
+    rec = ldu4(S.recs, rec.y);
+    for (;;) {  // Tex records between the Instance and a composite child
+      if (rec.x & RF_NOVIS) return hit_miss();
+      if ((rec.x & RF_KINDMASK) != R_TEX) break;
+      tex = tex_push(tex, rec.z);
+      rec = ldu4(S.recs, rec.y);
+    }
+  }
+  const uint32_t kind = rec.x & RF_KINDMASK;
+  HitG h;
+  if (kind == R_DIFF) h = csg_diff<C>(S, cnt, err, rec, r, dd, tex);
+  else if (kind == R_ISECT) h = csg_isect<C>(S, cnt, err, rec, r, dd, tex);
+  else h = leaf_rayint<C>(S, cnt, rec, r, dd, tex);
+  if (inst && h.hit) {
+    h.t = h.t * invlenscale;
+    h.p = mat_point(x.f0, x.f1, x.f2, h.p);
+    h.n = vnorm(mat_tvec(x.i0, x.i1, x.i2, h.n));
+  }
+  return h;
+}
+// shadow of a flat-tier CSG item: shadow_instance (Solid.hs:464-471), the primitives' own methods, and for Difference /
+// Intersection -- which have no shadow method -- the class default `rayint` (Solid.hs:218-221, Q15)
+template <bool C> GD bool csg_item_shadow(const DScene& S, Cnt& cnt, unsigned int& err, U4 rec, const Ray& ray, float d) {
+  for (;;) {  // shadow (Tex s _) = shadow s; NoShadow -> False (Tex.hs:69, 81)
+    if (rec.x & RF_NOSHADOW) return false;
+    if ((rec.x & RF_KINDMASK) != R_TEX) break;
+    rec = ldu4(S.recs, rec.y);
+  }
+  Ray r = ray;
+  float dd = d;
+  if ((rec.x & RF_KINDMASK) == R_INSTANCE) {
+    const Xf6 x = load_xf(S, rec.z);
+    const V3 newdir = mat_vec(x.i0, x.i1, x.i2, ray.d), neworig = mat_point(x.i0, x.i1, x.i2, ray.o);
+    const float lenscale = sqrtf(vdot(newdir, newdir)), invlenscale = 1.0f / lenscale;
+    r.o = neworig; r.d = newdir * invlenscale;
+    dd = d * lenscale;
+    rec = ldu4(S.recs, rec.y);
+    for (;;) {
+      if (rec.x & RF_NOSHADOW) return false;
+      if ((rec.x & RF_KINDMASK) != R_TEX) break;
+      rec = ldu4(S.recs, rec.y);
+    }
+  }
+  const uint32_t kind = rec.x & RF_KINDMASK;
+  // (the class default sees the node itself, so an OnlyShadow flag on it does not hide it here)
+  if (kind == R_DIFF) { U4 v = rec; v.x &= ~RF_NOVIS; return csg_diff<C>(S, cnt, err, v, r, dd, (TexStack)0).hit; }
+  if (kind == R_ISECT) { U4 v = rec; v.x &= ~RF_NOVIS; return csg_isect<C>(S, cnt, err, v, r, dd, (TexStack)0).hit; }
+  if (C) cnt.prim++;
+  return prim_shadow(S, kind, rec.y, r, dd);
+}
+
+// ------------------------------------------------------------------ flat tier
+// A candidate is (t, id, aux): id = record index of the primitive (or mesh-triangle index when aux has
+// CAND_MESH); aux = entry index.  Normals are derived after traversal (finalize_flat).
+struct Cand { float t; uint32_t id; uint32_t aux; };
+constexpr uint32_t CAND_NONE = 0xffffffffu;
+constexpr uint32_t CAND_MESH = 0x80000000u;
+
 // closest hit over the flat root program = the list instance's `foldl' nearest RayMiss` (Solid.hs:327) over
 // simple primitives, homogeneous BIHs and meshes.  Every entry is tested with the same d (Q9).
 // CLS is the set of entry classes the kernel instance is compiled for (the device analogue of the reference's
 // SPECIALIZE pragmas for Bih Triangle / Bih Sphere, Bih.hs:370-374): an all-triangle scene runs a kernel that contains
 // only the triangle loops, which keeps it small enough to stay in registers and in the instruction cache.
-constexpr int CLS_BIH_TRI = 1, CLS_BIH_SPHERE = 2, CLS_BIH_SIMPLE = 4, CLS_MESH = 8, CLS_PRIMS = 16, CLS_ALL = 31;
+constexpr int CLS_BIH_TRI = 1, CLS_BIH_SPHERE = 2, CLS_BIH_SIMPLE = 4, CLS_MESH = 8, CLS_PRIMS = 16, CLS_ALL = 31, CLS_CSG = 32, CLS_EVERY = 63;
+constexpr uint32_t CAND_CSG = 0x40000000u;  // aux flag: the candidate is a CSG item's hit, complete in the side record
 // WAVE: the call is made by all lanes of a wave together (`valid` = this lane holds a ray); triangle BIHs are then
 // walked as one packet (bih_tri_wave), everything else per lane as before.
+// CSGH: where the full hit of a CSG item goes (its normal, position and textures come out of the evaluation and cannot be
+// re-derived from a record like a primitive's); null in kernels without CLS_CSG.
 template <bool FAITHFUL, bool COUNT, int CLS, bool WAVE = false, class STK>
-GD Cand closest_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt, bool valid = true) {
+GD Cand closest_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt, bool valid = true, HitG* csgh = nullptr, unsigned int* err = nullptr) {
   Cand best; best.t = kInf; best.id = CAND_NONE; best.aux = 0;
   for (uint32_t e = 0; e < S.n_entries; e++) {
     U4 ent = ldu4(S.entries, e);
@@ -1168,6 +1395,15 @@ GD Cand closest_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt,
         if (WAVE) bih_tri_wave<FAITHFUL ? 0 : 1, COUNT, 1>(S, rec.y, r, dd, valid, stk, cnt, bt, brec);
         else bih_tri<FAITHFUL ? 0 : 1, COUNT, 1>(S, rec.y, r, dd, stk, cnt, bt, brec);
         if (brec != CAND_NONE) { best.t = bt; best.id = brec; best.aux = e; }
+      } else if ((CLS & CLS_CSG) && cls == BC_CSG) {  // primitives and CSG over primitives: every item evaluated in full
+        bih_traverse<FAITHFUL ? 0 : 1, COUNT>(S, rec.y, r, dd, stk, stk.total_cap(), cnt,
+          [&](uint32_t frec, uint32_t, uint32_t count, float tmax) {
+            for (uint32_t k = 0; k < count; k++) {
+              const HitG h = csg_item_rayint<COUNT>(S, cnt, *err, ldu4(S.recs, frec + k), r, tmax, (TexStack)ent.y);  // `rayint s r far`
+              if (h.hit && (best.id == CAND_NONE || !(best.t < h.t))) { best.t = h.t; best.id = frec + k; best.aux = e | CAND_CSG; *csgh = h; if (!FAITHFUL) tmax = gminf(tmax, best.t); }
+            }
+            return false;
+          }, bestt);
       } else if (CLS & CLS_BIH_SIMPLE) {  // BC_SIMPLE: mixed simple primitives, possibly with NoShadow / OnlyShadow flags
         bih_traverse<FAITHFUL ? 0 : 1, COUNT>(S, rec.y, r, dd, stk, stk.total_cap(), cnt,
           [&](uint32_t frec, uint32_t, uint32_t count, float tmax) {
@@ -1185,7 +1421,10 @@ GD Cand closest_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt,
       float mt; uint32_t mtri;
       mesh_closest<COUNT>(S, rec.y, r, d, stk, stk.total_cap(), cnt, mt, mtri);  // depth = the list's d (Q12)
       if (mtri != 0xffffffffu && (best.id == CAND_NONE || !(best.t < mt))) { best.t = mt; best.id = mtri; best.aux = e | CAND_MESH; }
-    } else if ((CLS & CLS_PRIMS) && kind != R_VOID && kind != R_MESH) {
+    } else if ((CLS & CLS_CSG) && (kind == R_DIFF || kind == R_ISECT || kind == R_INSTANCE || kind == R_TEX)) {  // a CSG item in the root list
+      const HitG h = csg_item_rayint<COUNT>(S, cnt, *err, rec, r, dd, (TexStack)ent.y);
+      if (h.hit && (best.id == CAND_NONE || !(best.t < h.t))) { best.t = h.t; best.id = ent.x; best.aux = e | CAND_CSG; *csgh = h; }
+    } else if ((CLS & CLS_PRIMS) && kind != R_VOID && kind != R_MESH && kind <= R_CONE) {
       float t; V3 n;
       if (COUNT) cnt.prim++;
       if (prim_test<false>(S, kind, rec.y, r, dd, t, n) && (best.id == CAND_NONE || !(best.t < t))) { best.t = t; best.id = ent.x; best.aux = e; }
@@ -1196,12 +1435,13 @@ GD Cand closest_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt,
 
 // Turn a candidate into a full hit: position (vscaleadd o dir t), normal, texture stack, primitive id.
 template <int CLS>
-GD HitG finalize_flat(const DScene& S, const Ray& r, const Cand& c) {
+GD HitG finalize_flat(const DScene& S, const Ray& r, const Cand& c, const HitG* csgh = nullptr) {
   HitG h = hit_miss();
   if (c.id == CAND_NONE) return h;
+  if ((CLS & CLS_CSG) && (c.aux & CAND_CSG)) return *csgh;
   h.hit = true; h.t = c.t;
   h.p = vscaleadd(r.o, r.d, c.t);
-  U4 ent = ldu4(S.entries, c.aux & ~CAND_MESH);
+  U4 ent = ldu4(S.entries, c.aux & ~(CAND_MESH | CAND_CSG));
   if ((CLS & CLS_MESH) && (c.aux & CAND_MESH)) {
     U4 rec = ldu4(S.recs, ent.x);
     uint32_t ti = c.id;
@@ -1235,7 +1475,7 @@ GD HitG finalize_flat(const DScene& S, const Ray& r, const Cand& c) {
 
 // shadow over the flat root program: `foldl' (||) False (map shadow xs)` (Solid.hs:330); Mesh casts none (Mesh.hs:210)
 template <bool COUNT, int CLS, bool WAVE = false, class STK>
-GD bool occluded_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt, bool valid = true) {
+GD bool occluded_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt, bool valid = true, unsigned int* err = nullptr) {
   bool result = false;  // WAVE: an occluded lane stays in the entry loop without a ray until the wave is through
   for (uint32_t e = 0; e < S.n_entries; e++) {
     U4 ent = ldu4(S.entries, e);
@@ -1260,6 +1500,13 @@ GD bool occluded_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt
         float bt = kNoBest; uint32_t brec = CAND_NONE;
         if (WAVE) occ = bih_tri_wave<2, COUNT, 1>(S, rec.y, r, d, valid, stk, cnt, bt, brec);
         else occ = bih_tri<2, COUNT, 1>(S, rec.y, r, d, stk, cnt, bt, brec);
+      } else if ((CLS & CLS_CSG) && cls == BC_CSG) {
+        bih_traverse<2, COUNT>(S, rec.y, r, d, stk, stk.total_cap(), cnt,
+          [&](uint32_t frec, uint32_t, uint32_t count, float tmax) {
+            float dd = gminf(d, tmax);
+            for (uint32_t k = 0; k < count; k++) if (csg_item_shadow<COUNT>(S, cnt, *err, ldu4(S.recs, frec + k), r, dd)) { occ = true; return true; }
+            return false;
+          }, nobest);
       } else if (CLS & CLS_BIH_SIMPLE) {
         bih_traverse<2, COUNT>(S, rec.y, r, d, stk, stk.total_cap(), cnt,
           [&](uint32_t frec, uint32_t, uint32_t count, float tmax) {
@@ -1274,7 +1521,9 @@ GD bool occluded_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt
           }, nobest);
       }
       if (occ) { if (!WAVE) return true; result = true; valid = false; }
-    } else if ((CLS & CLS_PRIMS) && kind != R_MESH && kind != R_VOID) {
+    } else if ((CLS & CLS_CSG) && (kind == R_DIFF || kind == R_ISECT || kind == R_INSTANCE || kind == R_TEX)) {
+      if (csg_item_shadow<COUNT>(S, cnt, *err, rec, r, d)) { if (!WAVE) return true; result = true; valid = false; }
+    } else if ((CLS & CLS_PRIMS) && kind != R_MESH && kind != R_VOID && kind <= R_CONE) {
       if (COUNT) cnt.prim++;
       if (prim_shadow(S, kind, rec.y, r, d)) { if (!WAVE) return true; result = true; valid = false; }
     }

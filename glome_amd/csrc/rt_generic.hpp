@@ -10,10 +10,6 @@
 
 namespace glome {
 
-// One explicit frame of rayint_intersection's list recursion (isect_rayint).  `from` holds the list position and, in
-// its top two bits, the frame's state; `aux` is the state's one live distance (state 1: the inside hit's depth, state 2:
-// the advance added back on return).
-struct IFrame { uint32_t from; float ox, oy, oz, d, aux; };
 // The interpreter's variable-length scratch lives in ONE pool per ray instead of one worst-case array per nesting level:
 // nested invocations stack their frames / advances on the same arrays (fr_top, adv_top), so the kernel's scratch frame
 // is sized by what a ray can have live at once, not by depth x worst case.  The pools are bounded (kIsectFrames,
@@ -29,34 +25,6 @@ template <bool COUNT> struct GCtx {
   GPool& pool;
   int fr_top = 0, adv_top = 0;
 };
-
-GD HitG nearest_hit(const HitG& a, const HitG& b) {  // nearest, Solid.hs:37-44: ties -> b
-  if (!b.hit) return a;
-  if (!a.hit) return b;
-  return (a.t < b.t) ? a : b;
-}
-GD TexStack own_stack_rayint(uint32_t own) { return (TexStack)own; }  // innermost Tex first (Tex.hs:66)
-GD TexStack own_stack_meta(uint32_t own) {                             // get_metainfo: outermost Tex first (Tex.hs:73-74)
-  if (own >> 16) return (TexStack)((own >> 16) | ((own & 0xffffu) << 16));
-  return (TexStack)own;
-}
-
-struct Xf6 { F4 f0, f1, f2, i0, i1, i2; };
-GD Xf6 load_xf(const DScene& S, uint32_t x) {
-  Xf6 m;
-  m.f0 = ld4(S.xfms, 6 * x); m.f1 = ld4(S.xfms, 6 * x + 1); m.f2 = ld4(S.xfms, 6 * x + 2);
-  m.i0 = ld4(S.xfms, 6 * x + 3); m.i1 = ld4(S.xfms, 6 * x + 4); m.i2 = ld4(S.xfms, 6 * x + 5);
-  return m;
-}
-GD V3 mat_point(const F4& r0, const F4& r1, const F4& r2, V3 v) {  // xfm_point / invxfm_point, Vec.hs:502-519
-  return v3(r0.x * v.x + r0.y * v.y + r0.z * v.z + r0.w, r1.x * v.x + r1.y * v.y + r1.z * v.z + r1.w, r2.x * v.x + r2.y * v.y + r2.z * v.z + r2.w);
-}
-GD V3 mat_vec(const F4& r0, const F4& r1, const F4& r2, V3 v) {  // xfm_vec / invxfm_vec, Vec.hs:522-539
-  return v3(r0.x * v.x + r0.y * v.y + r0.z * v.z, r1.x * v.x + r1.y * v.y + r1.z * v.z, r2.x * v.x + r2.y * v.y + r2.z * v.z);
-}
-GD V3 mat_tvec(const F4& r0, const F4& r1, const F4& r2, V3 v) {  // invxfm_norm: transpose, Vec.hs:543-550
-  return v3(r0.x * v.x + r1.x * v.y + r2.x * v.z, r0.y * v.x + r1.y * v.y + r2.y * v.z, r0.z * v.x + r1.z * v.y + r2.z * v.z);
-}
 
 template <int D, bool C> struct G;  // the four class methods at nesting budget D
 
@@ -99,11 +67,6 @@ template <int D, bool C> GD bool inside_g(GCtx<C>& g, U4 rec, V3 p) {
 }
 template <int D, bool C> GD TexStack meta_g(GCtx<C>& g, U4 rec, V3 p) { return G<D, C>::meta(g, rec, p); }
 
-// strip Tex records (and stop at the first non-Tex record)
-GD U4 skip_tex(const DScene& S, U4 rec) {
-  while ((rec.x & RF_KINDMASK) == R_TEX) rec = ldu4(S.recs, rec.y);
-  return rec;
-}
 
 template <int D, bool C> struct G {
   using Ctx = GCtx<C>;

@@ -37,7 +37,7 @@ constexpr uint32_t RF_KINDMASK = 0xffu;
 constexpr uint32_t RF_NOVIS = 1u << 8;     // OnlyShadow: rayint misses (Tex.hs:89)
 constexpr uint32_t RF_NOSHADOW = 1u << 9;  // NoShadow: shadow is False (Tex.hs:81)
 
-enum BihLeafClass : uint32_t { BC_GENERIC = 0, BC_TRI = 1, BC_SPHERE = 2, BC_SIMPLE = 3 };
+enum BihLeafClass : uint32_t { BC_GENERIC = 0, BC_TRI = 1, BC_SPHERE = 2, BC_SIMPLE = 3, BC_CSG = 4 /* primitives and CSG over primitives */ };
 constexpr uint32_t MESH_BRANCH = 0xffffffffu;  // count value marking "ref is a branch node"
 
 enum DMatKind : uint32_t { DM_SURFACE = 0, DM_REFLECT = 1, DM_REFRACT = 2, DM_LAYERS = 3, DM_BLEND = 4 };

@@ -26,11 +26,12 @@ template <bool FAITHFUL, bool COUNT, bool FULL_> struct HostFlatTier {
   int nlights;
   LaneStack stk;
   Cnt cnt;
-  HitG closest(const Ray& r, float tmax) { Cand c = closest_flat<FAITHFUL, COUNT, CLS_ALL>(S, r, tmax, stk, cnt); return finalize_flat<CLS_ALL>(S, r, c); }
-  bool occluded(const Ray& r, float d) { return occluded_flat<COUNT, CLS_ALL>(S, r, d, stk, cnt); }
+  unsigned int err = 0;
+  HitG closest(const Ray& r, float tmax) { HitG ch; Cand c = closest_flat<FAITHFUL, COUNT, CLS_EVERY>(S, r, tmax, stk, cnt, true, &ch, &err); return finalize_flat<CLS_EVERY>(S, r, c, &ch); }
+  bool occluded(const Ray& r, float d) { return occluded_flat<COUNT, CLS_EVERY>(S, r, d, stk, cnt, true, &err); }
   // on the host a wave is one lane: the packet code runs as a single-ray traversal
-  HitG closest_wave(const Ray& r, float tmax, bool valid) { Cand c = closest_flat<FAITHFUL, COUNT, CLS_ALL, true>(S, r, tmax, stk, cnt, valid); return valid ? finalize_flat<CLS_ALL>(S, r, c) : hit_miss(); }
-  bool occluded_wave(const Ray& r, float d, bool valid) { return occluded_flat<COUNT, CLS_ALL, true>(S, r, d, stk, cnt, valid); }
+  HitG closest_wave(const Ray& r, float tmax, bool valid) { HitG ch; Cand c = closest_flat<FAITHFUL, COUNT, CLS_EVERY, true>(S, r, tmax, stk, cnt, valid, &ch, &err); return valid ? finalize_flat<CLS_EVERY>(S, r, c, &ch) : hit_miss(); }
+  bool occluded_wave(const Ray& r, float d, bool valid) { return occluded_flat<COUNT, CLS_EVERY, true>(S, r, d, stk, cnt, valid, &err); }
 };
 struct HostGenericTier {
   static constexpr bool FULL = true;

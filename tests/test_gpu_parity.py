@@ -242,10 +242,13 @@ def test_pipeline_through_a_one_rank_rccl_group(gpu_ctx):
     assert r.returncode == 0 and "rccl one-rank pipeline ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
 
-def test_full_size_csg_generic_tier_vs_oracle_tile_sample(gpu_ctx):
-    sd = scenes.s4()
+@pytest.mark.parametrize("name,tier", [("S4", 0), ("csg", 1)])
+def test_full_size_csg_vs_oracle_tile_sample(gpu_ctx, name, tier):
+    """BASELINE configs[3] at 1920x1080, maxdepth 3: S4 (CSG over primitives: the flat tier's evaluator) and the zoo's CSG
+    scene (composites below composites: the generic tier's interpreter), a tile sample against the oracle."""
+    sd = SCENES[name]()
     b, nm, sc = commit(gpu_ctx, sd)
-    assert sc.info()["tier"] == 1
+    assert sc.info()["tier"] == tier
     cam, lights = product_camera_lights(sd)
     o, om, _ = oracle_for(sd)
     ref, _, rc = o.render(1920, 1080, maxdepth=3, tile_first=5, tile_stride=23, nthreads=8, want_packed=False)

@@ -104,11 +104,14 @@ def test_flatten_tiers_and_limits(built):
     sd = scenes.s1()
     nm, _ = sd.replay(b)
     assert HostSim(b, nm[sd.root]).info()["tier"] == 0
-    for name in ("csg", "nested", "quadrics"):
+    for name in ("csg", "nested"):  # composites below composites: the interpreter
         sd = zoo.ALL[name]()
         b = api.Builder(); nm, _ = sd.replay(b)
         assert HostSim(b, nm[sd.root]).info()["tier"] == 1, name
-    for name in ("flat_mixed", "mesh", "materials"):
+    sd = scenes.s4()  # CSG over primitives (and an Instance of one) stays flat: BASELINE configs[3]
+    b = api.Builder(); nm, _ = sd.replay(b)
+    assert HostSim(b, nm[sd.root]).info()["tier"] == 0
+    for name in ("flat_mixed", "mesh", "materials", "quadrics"):  # (a cylinder / cone is an Instance of a canonical quadric)
         sd = zoo.ALL[name]()
         b = api.Builder(); nm, _ = sd.replay(b)
         assert HostSim(b, nm[sd.root]).info()["tier"] == 0, name
