@@ -58,6 +58,13 @@ SYMBOLS = [
     ("glome_ctx_timing_begin_sampled", C.c_int, [vp, C.c_int, C.c_int]),
     ("glome_ctx_timing_end", C.c_int, [vp, c_fp, C.c_int]),
     ("glome_ctx_set_grid_per_cu", C.c_int, [vp, C.c_int]),
+    ("glome_multi_create", vp, [C.POINTER(vp), C.c_int, vp, C.c_int]),
+    ("glome_multi_destroy", None, [vp]),
+    ("glome_multi_render", C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp]),
+    ("glome_multi_synchronize", C.c_int, [vp]),
+    ("glome_multi_transport", C.c_char_p, [vp]),
+    ("glome_multi_last_error", C.c_char_p, [vp]),
+    ("glome_render_multi", C.c_int, [C.POINTER(vp), C.c_int, vp, vp, C.c_int, vp, vp]),
     ("glome_ctx_device_info", C.c_int, [vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("glome_xfm_translate", C.c_int, [c_dp, c_dp]),
     ("glome_xfm_scale", C.c_int, [c_dp, c_dp]),

@@ -397,3 +397,39 @@ class Scene:
         self._chk(self.lib.glome_render_dev(self.h, C.byref(cam), la, len(lights), C.byref(params), C.c_void_p(rgbad_ptr) if rgbad_ptr else None,
                                             C.c_void_p(packed_ptr) if packed_ptr else None, C.byref(st) if want_stats else None), "glome_render_dev")
         return _stats_dict(st) if want_stats else None
+
+
+class Multi:
+    """Several GPUs driven by this one process (glome_multi_*): scenes[i] is the scene committed on context i; frames land
+    on scenes[0]'s device.  The one-process counterpart of dist.ShardedFrame (one process per GPU)."""
+
+    def __init__(self, scenes, params, use_rccl=True):
+        self.lib = scenes[0].lib
+        self.scenes = list(scenes)
+        arr = (C.c_void_p * len(scenes))(*[s.h for s in scenes])
+        self.h = self.lib.glome_multi_create(arr, len(scenes), C.byref(params), 1 if use_rccl else 0)
+        if not self.h:
+            raise GlomeError("glome_multi_create: " + self.lib.glome_global_error().decode())
+        self.params = params
+
+    def transport(self):
+        return self.lib.glome_multi_transport(self.h).decode()
+
+    def render(self, cams, lights, packed_ptr):
+        """cams: one glome_camera or a list of up to 8; packed_ptr: device pointer on rank 0's GPU (frames back to back)"""
+        cams = list(cams) if isinstance(cams, (list, tuple)) else [cams]
+        ca = (L.Camera * len(cams))(*cams)
+        la = (L.Light * max(1, len(lights)))(*lights)
+        rc = self.lib.glome_multi_render(self.h, ca, len(cams), la, len(lights), C.c_void_p(packed_ptr))
+        if rc != 0:
+            raise GlomeError(f"glome_multi_render: {self.lib.glome_multi_last_error(self.h).decode()} (status {rc})")
+
+    def synchronize(self):
+        rc = self.lib.glome_multi_synchronize(self.h)
+        if rc != 0:
+            raise GlomeError(f"glome_multi_synchronize: {self.lib.glome_multi_last_error(self.h).decode()} (status {rc})")
+
+    def close(self):
+        if self.h:
+            self.lib.glome_multi_destroy(self.h)
+            self.h = None

@@ -938,7 +938,7 @@ static void launch_render(glome_scene* s, const DRenderArgs& A, const glome_rend
       if (cls == CLS_BIH_TRI) GLOME_LAUNCH(F, C, U, CLS_BIH_TRI, 1);              \
       else if (cls == (CLS_BIH_SPHERE | CLS_PRIMS)) GLOME_LAUNCH(F, C, U, (CLS_BIH_SPHERE | CLS_PRIMS), 1); \
       else if (cls == CLS_MESH) GLOME_LAUNCH(F, C, U, CLS_MESH, 1);               \
-      else if (cls == CLS_EVERY) GLOME_LAUNCH(F, C, U, CLS_EVERY, 1);             \
+      else if (cls == CLS_EVERY) GLOME_LAUNCH(F, C, U, CLS_EVERY, 2);  /* two waves per SIMD: S4 0.72 -> 0.52 ms; three spill */ \
       else GLOME_LAUNCH(F, C, U, CLS_ALL, 1);                                     \
     } while (0)
     if (use_two_rows(s, P, A.total_waves * (uint32_t)A.nframes)) {
@@ -1034,8 +1034,8 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
     else if (two_rows) hipLaunchKernelGGL((k_ss_frame_flat<false, CLS_BIH_TRI, 6, true>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
     else if (tri && !full) hipLaunchKernelGGL((k_ss_frame_flat<false, CLS_BIH_TRI>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
     else if (tri) hipLaunchKernelGGL((k_ss_frame_flat<true, CLS_BIH_TRI>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
-    else if (!full) hipLaunchKernelGGL((k_ss_frame_flat<false, CLS_EVERY>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
-    else hipLaunchKernelGGL((k_ss_frame_flat<true, CLS_EVERY>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
+    else if (!full) hipLaunchKernelGGL((k_ss_frame_flat<false, CLS_EVERY, 2>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
+    else hipLaunchKernelGGL((k_ss_frame_flat<true, CLS_EVERY, 2>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
   } else if (A.ntiles > 0) {
@@ -1337,3 +1337,208 @@ int glome_tiles_blit_dev(glome_ctx* ctx, const glome_render_params* P, int tile_
   return 0;
 }
 
+
+// ================================================================================================ several GPUs, one process
+// renderTiles' `runPar $ parMap` over tiles followed by `forM_ tiles (blitTile surf)` (Glome.hs:379-386) across the GPUs of a
+// node, for a host that drives all of them from one process (the Haskell host of INTEGRATION.md): scenes[i] is the scene
+// committed on context i, tile k of the frame belongs to rank k mod n, a rank renders its tiles of up to 8 frames in one
+// launch straight into a packed payload, the payloads travel to rank 0's GPU over xGMI, one launch there blits the frames.
+// The exchange is the path's only communication step.  Transport: RCCL send / recv in one group (librccl is opened at run
+// time, so the library carries no link-time dependency on it) when the ranks sit on distinct devices; peer copies on rank
+// 0's stream (hipMemcpyPeerAsync) when librccl cannot be loaded or two ranks share a device (how the path is tested on a
+// one-GPU box).  glome_amd/dist.py is the same data path with one process per GPU and torch.distributed's gather.
+#include <dlfcn.h>
+namespace {
+struct Rccl {  // the five entry points the gather needs, resolved from librccl.so on first use
+  typedef void* comm_t;
+  int (*CommInitAll)(comm_t*, int, const int*) = nullptr;
+  int (*CommDestroy)(comm_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok = false;
+  static Rccl& get() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+      void* h = nullptr;
+      for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+      if (!h) return;
+      r.CommInitAll = (decltype(r.CommInitAll))dlsym(h, "ncclCommInitAll");
+      r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+      r.GroupStart = (decltype(r.GroupStart))dlsym(h, "ncclGroupStart");
+      r.GroupEnd = (decltype(r.GroupEnd))dlsym(h, "ncclGroupEnd");
+      r.Send = (decltype(r.Send))dlsym(h, "ncclSend");
+      r.Recv = (decltype(r.Recv))dlsym(h, "ncclRecv");
+      r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+      r.ok = r.CommInitAll && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv;
+    });
+    return r;
+  }
+};
+constexpr int kNcclUint32 = 3;  // ncclUint32 (nccl.h: ncclInt8 0, ncclUint8 1, ncclInt32 2, ncclUint32 3)
+}  // namespace
+
+struct glome_multi {
+  int n = 0;
+  std::vector<glome_scene*> scenes;
+  glome_render_params P{}, P0{};           // the frame (work tiles in renderTile mode); P0 = P with rank 0's shard
+  std::vector<glome_render_params> Pl;     // rank i's shard: tiles i, i + n, ...
+  int64_t maxp = 0;                        // pixels of the largest shard: a frame's slot in every payload
+  std::vector<uint32_t*> payload;          // rank i's payload on device i: kMaxBatchFrames * maxp words (rank 0: its slab of `gathered`)
+  uint32_t* gathered = nullptr;            // device 0: n slabs of kMaxBatchFrames * maxp words
+  std::vector<hipEvent_t> rendered;        // rank i's launch is done
+  hipEvent_t consumed = nullptr;           // rank 0 has taken the payloads of the last call
+  bool used = false;
+  bool rccl = false;
+  std::vector<Rccl::comm_t> comms;
+  std::string err;
+};
+#define MHIP(m, call)                                                                 \
+  do {                                                                                \
+    hipError_t e_ = (call);                                                           \
+    if (e_ != hipSuccess) { (m)->err = std::string(#call) + ": " + hipGetErrorString(e_); return GLOME_E_HIP; } \
+  } while (0)
+
+glome_multi* glome_multi_create(glome_scene* const* scenes, int n, const glome_render_params* P, int use_rccl) {
+  if (!scenes || n < 1 || n > 64 || !P) { g_global_error = "glome_multi_create: bad argument"; return nullptr; }
+  for (int i = 0; i < n; i++) {
+    if (!scenes[i]) { g_global_error = "glome_multi_create: null scene"; return nullptr; }
+    for (int j = 0; j < i; j++) if (scenes[j]->ctx == scenes[i]->ctx) { g_global_error = "glome_multi_create: every rank needs a context (and scene) of its own"; return nullptr; }
+  }
+  if (check_params(scenes[0]->ctx, P)) { g_global_error = scenes[0]->ctx->err; return nullptr; }
+  glome_multi* m = new glome_multi();
+  m->n = n;
+  m->scenes.assign(scenes, scenes + n);
+  m->P = *P;
+  // renderTile's pixels do not depend on the tile map (the adaptive sampler's do, Q21): shard 64x64 work tiles then
+  if (P->mode == GLOME_MODE_TILE) m->P.blocksize = 64;
+  m->P.tile_first = 0; m->P.tile_stride = 1;
+  for (int i = 0; i < n; i++) {
+    glome_render_params q = m->P;
+    q.tile_first = i; q.tile_stride = n;
+    m->Pl.push_back(q);
+    m->maxp = std::max<int64_t>(m->maxp, glome_tiles_payload_floats(&q, i, n) / 5);
+  }
+  m->maxp = std::max<int64_t>(m->maxp, 1);
+  auto fail = [&](const std::string& what) { g_global_error = "glome_multi_create: " + what; glome_multi_destroy(m); return (glome_multi*)nullptr; };
+  const size_t slab = (size_t)kMaxBatchFrames * (size_t)m->maxp;
+  if (hipSetDevice(scenes[0]->ctx->device) != hipSuccess || hipMalloc((void**)&m->gathered, slab * n * sizeof(uint32_t)) != hipSuccess) return fail("device allocation failed");
+  m->payload.assign(n, nullptr);
+  m->rendered.assign(n, nullptr);
+  m->payload[0] = m->gathered;  // rank 0 renders into its own slab
+  for (int i = 0; i < n; i++) {
+    if (hipSetDevice(scenes[i]->ctx->device) != hipSuccess) return fail("hipSetDevice failed");
+    if (i > 0 && hipMalloc((void**)&m->payload[i], slab * sizeof(uint32_t)) != hipSuccess) return fail("device allocation failed");
+    if (hipEventCreateWithFlags(&m->rendered[i], hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
+  }
+  (void)hipSetDevice(scenes[0]->ctx->device);
+  if (hipEventCreateWithFlags(&m->consumed, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
+  // transport
+  bool distinct = true;
+  for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) distinct &= scenes[i]->ctx->device != scenes[j]->ctx->device;
+  if (use_rccl && n > 1 && distinct && Rccl::get().ok) {
+    std::vector<int> devs;
+    for (int i = 0; i < n; i++) devs.push_back(scenes[i]->ctx->device);
+    m->comms.assign(n, nullptr);
+    int rc = Rccl::get().CommInitAll(m->comms.data(), n, devs.data());
+    if (rc != 0) return fail(std::string("ncclCommInitAll: ") + (Rccl::get().GetErrorString ? Rccl::get().GetErrorString(rc) : "error"));
+    m->rccl = true;
+  } else if (n > 1) {
+    for (int i = 1; i < n; i++) {  // peer copies into rank 0's GPU: let it see the others' memory where they differ
+      if (scenes[i]->ctx->device == scenes[0]->ctx->device) continue;
+      int can = 0;
+      (void)hipDeviceCanAccessPeer(&can, scenes[0]->ctx->device, scenes[i]->ctx->device);
+      if (can) { (void)hipSetDevice(scenes[0]->ctx->device); hipError_t e = hipDeviceEnablePeerAccess(scenes[i]->ctx->device, 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError(); }
+    }
+  }
+  return m;
+}
+void glome_multi_destroy(glome_multi* m) {
+  if (!m) return;
+  for (int i = 0; i < m->n; i++) {
+    (void)hipSetDevice(m->scenes[i]->ctx->device);
+    (void)hipStreamSynchronize(m->scenes[i]->ctx->stream);
+    if (i > 0 && i < (int)m->payload.size() && m->payload[i]) (void)hipFree(m->payload[i]);
+    if (i < (int)m->rendered.size() && m->rendered[i]) (void)hipEventDestroy(m->rendered[i]);
+    if (m->rccl && i < (int)m->comms.size() && m->comms[i]) (void)Rccl::get().CommDestroy(m->comms[i]);
+  }
+  (void)hipSetDevice(m->scenes[0]->ctx->device);
+  if (m->gathered) (void)hipFree(m->gathered);
+  if (m->consumed) (void)hipEventDestroy(m->consumed);
+  delete m;
+}
+const char* glome_multi_last_error(const glome_multi* m) { return m ? m->err.c_str() : g_global_error.c_str(); }
+const char* glome_multi_transport(const glome_multi* m) { return !m ? "" : (m->n == 1 ? "none" : (m->rccl ? "rccl" : "peer-copy")); }
+
+int glome_multi_render(glome_multi* m, const glome_camera* cams, int nframes, const glome_light* lights, int nlights, uint32_t* packed_dev) {
+  if (!m || !cams || !packed_dev) return GLOME_E_INVALID;
+  if (nframes < 1 || nframes > kMaxBatchFrames || (m->P.mode != GLOME_MODE_TILE && nframes != 1)) { m->err = "a call carries 1..8 frames (one in adaptive mode)"; return GLOME_E_LIMIT; }
+  const int n = m->n;
+  glome_ctx* c0 = m->scenes[0]->ctx;
+  const size_t slab = (size_t)kMaxBatchFrames * (size_t)m->maxp;
+  // every rank renders its tiles of the nframes views into its payload (frame f at f * maxp)
+  for (int i = 0; i < n; i++) {
+    glome_ctx* c = m->scenes[i]->ctx;
+    MHIP(m, hipSetDevice(c->device));
+    if (m->used && i > 0 && !m->rccl) MHIP(m, hipStreamWaitEvent(c->stream, m->consumed, 0));  // rank 0 has read this payload's last contents
+    int rc = nframes > 1 ? render_impl(m->scenes[i], cams, lights, nlights, &m->Pl[i], nullptr, m->payload[i], nullptr, 2, nframes, m->maxp)
+                         : render_impl(m->scenes[i], cams, lights, nlights, &m->Pl[i], nullptr, m->payload[i], nullptr, 2);
+    if (rc) { m->err = "rank " + std::to_string(i) + ": " + c->err; return rc; }
+    if (i > 0) MHIP(m, hipEventRecord(m->rendered[i], c->stream));
+  }
+  // the exchange: rank i's payload -> slab i on rank 0's GPU
+  const size_t words = (size_t)nframes * (size_t)m->maxp;
+  if (n > 1 && m->rccl) {
+    Rccl& R = Rccl::get();
+    int rc = R.GroupStart();
+    for (int i = 1; i < n && rc == 0; i++) {
+      rc = R.Send(m->payload[i], words, kNcclUint32, 0, m->comms[i], m->scenes[i]->ctx->stream);
+      if (rc == 0) rc = R.Recv(m->gathered + (size_t)i * slab, words, kNcclUint32, i, m->comms[0], c0->stream);
+    }
+    int rc2 = R.GroupEnd();
+    if (rc || rc2) { m->err = std::string("RCCL send / recv: ") + (R.GetErrorString ? R.GetErrorString(rc ? rc : rc2) : "error"); return GLOME_E_HIP; }
+  } else if (n > 1) {
+    MHIP(m, hipSetDevice(c0->device));
+    for (int i = 1; i < n; i++) {
+      MHIP(m, hipStreamWaitEvent(c0->stream, m->rendered[i], 0));
+      MHIP(m, hipMemcpyPeerAsync(m->gathered + (size_t)i * slab, c0->device, m->payload[i], m->scenes[i]->ctx->device, words * sizeof(uint32_t), c0->stream));
+    }
+    MHIP(m, hipEventRecord(m->consumed, c0->stream));
+  }
+  m->used = true;
+  // blitTile for every tile of every frame, one launch on rank 0
+  MHIP(m, hipSetDevice(c0->device));
+  int rc = glome_tiles_blit_all_packed_batch_dev(c0, &m->P, n, m->gathered, (int64_t)slab, nframes, m->maxp, packed_dev, (int64_t)m->P.width * m->P.height);
+  if (rc) { m->err = c0->err; return rc; }
+  return 0;
+}
+int glome_multi_synchronize(glome_multi* m) {
+  if (!m) return GLOME_E_INVALID;
+  int rc = 0;
+  for (int i = m->n - 1; i >= 0; i--) {
+    MHIP(m, hipSetDevice(m->scenes[i]->ctx->device));
+    int r = glome_ctx_synchronize(m->scenes[i]->ctx);
+    if (r) { m->err = m->scenes[i]->ctx->err; rc = r; }
+  }
+  return rc;
+}
+// the one-call form SURVEY.md Appendix B names: host framebuffer out
+int glome_render_multi(glome_scene* const* scenes, int n, const glome_camera* cam, const glome_light* lights, int nlights, const glome_render_params* P, uint32_t* packed) {
+  if (!packed) { g_global_error = "glome_render_multi: null framebuffer"; return GLOME_E_INVALID; }
+  glome_multi* m = glome_multi_create(scenes, n, P, 1);
+  if (!m) return GLOME_E_INVALID;
+  uint32_t* d = nullptr;
+  const size_t np = (size_t)P->width * P->height;
+  int rc = 0;
+  if (hipSetDevice(scenes[0]->ctx->device) != hipSuccess || hipMalloc((void**)&d, np * 4) != hipSuccess) rc = GLOME_E_HIP;
+  if (!rc) rc = glome_multi_render(m, cam, 1, lights, nlights, d);
+  if (!rc) rc = glome_multi_synchronize(m);
+  if (!rc && hipMemcpy(packed, d, np * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = GLOME_E_HIP;
+  if (rc) g_global_error = std::string("glome_render_multi: ") + m->err;
+  if (d) (void)hipFree(d);
+  glome_multi_destroy(m);
+  return rc;
+}

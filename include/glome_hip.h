@@ -250,6 +250,24 @@ int glome_render_tiles_packed_batch_dev(glome_scene*, const glome_camera* cams, 
                                         const glome_render_params*, uint32_t* payload_dev, int64_t frame_stride_pixels, glome_stats*);
 int glome_render_packed_batch_dev(glome_scene*, const glome_camera* cams, int nframes, const glome_light* lights, int nlights,
                                   const glome_render_params*, uint32_t* packed_dev, int64_t frame_stride_pixels, glome_stats*);
+/* ---- the whole-frame seam on several GPUs driven by ONE process (renderTiles' parMap over tiles + blitTile, Glome.hs:379-386) ----
+ * scenes[i] = the same scene committed on context i (a context per GPU; rank 0's GPU receives the frame).  Tile k of the
+ * frame -- 64x64 work tiles in renderTile mode, the 65x65 reference tiles in adaptive mode (whose pixels depend on the tile
+ * map, Q21) -- belongs to rank k mod n.  A call renders nframes <= 8 views (one in adaptive mode): every rank renders its
+ * tiles of all of them in one launch into a packed 0x00RRGGBB payload, the payloads move to rank 0's GPU over xGMI -- RCCL
+ * send / recv in one group when use_rccl != 0, librccl.so can be opened and the ranks sit on distinct devices, peer copies
+ * otherwise (glome_multi_transport says which) -- and one launch there blits the frames into packed_dev (frame f at
+ * f * width * height words).  Asynchronous; glome_multi_synchronize waits for all ranks and reports device-side limits. */
+typedef struct glome_multi glome_multi;
+glome_multi* glome_multi_create(glome_scene* const* scenes, int n, const glome_render_params*, int use_rccl); /* NULL: glome_global_error() */
+void glome_multi_destroy(glome_multi*);
+int glome_multi_render(glome_multi*, const glome_camera* cams, int nframes, const glome_light* lights, int nlights, uint32_t* packed_dev);
+int glome_multi_synchronize(glome_multi*);
+const char* glome_multi_transport(const glome_multi*); /* "rccl", "peer-copy" or "none" (one rank) */
+const char* glome_multi_last_error(const glome_multi*);
+/* One frame into a host framebuffer (width * height words): create, render, synchronize, copy, destroy. */
+int glome_render_multi(glome_scene* const* scenes, int n, const glome_camera*, const glome_light* lights, int nlights,
+                       const glome_render_params*, uint32_t* packed);
 /* Tile payload transport for multi-GPU sharding (Tile = Rect + pixel vector, Glome.hs:153-154).
  * pack: copy this rank's owned tiles from a full frame into a dense payload (tiles in owned order, row major
  * inside a tile, 5 floats per pixel).  blit: scatter a payload of the tiles owned by (tile_first, tile_stride)

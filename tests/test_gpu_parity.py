@@ -685,3 +685,49 @@ def test_s5_as_a_mesh_of_a_million_triangles_4k_tile_sample_vs_oracle(s5_mesh, m
         assert 0.95 * rc["mesh_nodes"] <= st["mesh_nodes"] <= rc["mesh_nodes"] + 4, (st["mesh_nodes"], rc["mesh_nodes"])
     else:
         assert abs(int(st["rays_primary"]) - rc["rays_primary"]) <= max(8, rc["rays_primary"] // 500)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3])
+def test_multi_gpu_c_abi_frames_equal_the_single_gpu_frames(gpu_ctx, n):
+    """glome_multi_* (SURVEY.md Appendix B's glome_render_multi: the Haskell host's way to several GPUs): n ranks -- here n
+    contexts on the one GPU of the box, so the payloads move by peer copy; on distinct devices the same calls go through
+    RCCL send / recv -- render their tile shards of a batch of views, rank 0 gathers and blits: every frame equals the
+    single-context render bit for bit, in renderTile mode (a batch of three moving views) and in adaptive mode."""
+    import torch
+    sd = scenes.s3(48)
+    dev = torch.device("cuda:0")
+    ctxs = [gpu_ctx] + [api.Context(0) for _ in range(n - 1)]
+    scs = []
+    for c in ctxs:
+        b = api.Builder(); nm, _ = sd.replay(b)
+        scs.append(c.commit(b, nm[sd.root]))
+    pos, at, up, fov = sd.cam
+    cams = [api.camera((pos[0] + 2.0 * k, pos[1] + 0.5 * k, pos[2]), at, up, fov) for k in range(3)]
+    _, lights = product_camera_lights(sd)
+    W, H = 645, 390
+    for mode, views in ((0, cams), (1, cams[:1])):
+        P = api.render_params(width=W, height=H, mode=mode, maxdepth=1)
+        m = api.Multi(scs, P)
+        assert m.transport() == ("none" if n == 1 else "peer-copy")
+        out = torch.full((len(views), H, W), -1, dtype=torch.int32, device=dev)
+        for rep in range(2):  # a second call reuses the payload buffers: the first call's copies must have drained
+            m.render(views, lights, out.data_ptr())
+        m.synchronize()
+        for k, cam in enumerate(views):
+            want = torch.zeros((H, W), dtype=torch.int32, device=dev)
+            scs[0].render_dev(cam, lights, P, None, want.data_ptr())
+            gpu_ctx.synchronize()
+            assert torch.equal(out[k], want), (mode, k)
+        m.close()
+    # the one-call host-buffer form
+    P = api.render_params(width=W, height=H, maxdepth=1)
+    host = np.zeros((H, W), np.uint32)
+    arr = (C.c_void_p * n)(*[s.h for s in scs])
+    la = (L.Light * len(lights))(*lights)
+    assert gpu_ctx.lib.glome_render_multi(arr, n, C.byref(cams[0]), la, len(lights), C.byref(P), host.ctypes.data_as(L.c_up)) == 0
+    img, packed, _ = scs[0].render(cams[0], lights, P)
+    assert np.array_equal(host, packed)
+    for s_ in scs:
+        s_.release()
+    for c in ctxs[1:]:
+        c.close()
