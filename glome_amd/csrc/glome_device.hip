@@ -207,9 +207,6 @@ __device__ __forceinline__ void render_loop(const DRenderArgs& A, TIER& T) {
     if (w >= A.total_waves * (uint32_t)A.nframes) continue;  // padding of the last round of chunks
     const uint32_t frame = w / A.total_waves;  // wave-uniform
     w -= frame * A.total_waves;
-#if defined(GLOME_EXP_TIMING)
-    unsigned long long tw0 = __builtin_readcyclecounter();
-#endif
     int px = 0, py = 0;
     size_t dense_off = 0;
     const bool valid = work_to_pixel(A, w, lane, px, py, dense_off);  // lanes past the end of a leftover strip idle along
@@ -229,14 +226,6 @@ __device__ __forceinline__ void render_loop(const DRenderArgs& A, TIER& T) {
       out[0] = r; out[1] = c.g; out[2] = c.b; out[3] = c.a; out[4] = depth;
     }
     if (A.packed) A.packed[o] = rgbf(r * c.a, c.g * c.a, c.b * c.a);  // blitTile (Glome.hs:353-358)
-#if defined(GLOME_EXP_TIMING)
-    if (lane == 0) {
-      unsigned long long dtc = __builtin_readcyclecounter() - tw0;
-      T.cnt.mesh += (uint32_t)dtc;
-      atomicMax(&A.counters->rays_secondary, dtc);  // experiment only: the longest item
-    }
-    { unsigned int d32 = (unsigned int)(__builtin_readcyclecounter() - tw0); d32 = __shfl(d32, 0, 64); if (A.out5) A.out5[o * 5 + 4] = (float)d32; }
-#endif
   }
   if (lane == 0) Q.leave(A);
 }

@@ -4,11 +4,11 @@
 // of the reference are kept, because they decide NaN / +-0 behaviour (Q1, Q2).
 //
 // Two tiers share the primitive and shading code:
-//   flat tier    -- root = list of simple primitives / homogeneous BIHs / meshes.  Fully inlined, deferred
-//                   normals.  A wave walks a triangle / sphere BIH once for its 64 rays (bih_tri_wave:
-//                   wave-uniform node reference, scalar loads, per-lane intervals; the branch steps are
-//                   hand-scheduled, bih_descend_asm); everything else traverses per lane with its stack in
-//                   LDS (one column per lane, conflict-free).
+//   flat tier    -- root = list of simple primitives / homogeneous BIHs / meshes / CSG over primitives.  Fully
+//                   inlined, deferred normals.  A wave walks a triangle / sphere BIH once for its 64 rays
+//                   (bih_tri_wave: wave-uniform node reference, scalar loads, per-lane intervals; the production
+//                   triangle walk is hand-written, bih_packet_asm.hpp); everything else traverses per lane with its
+//                   stack in LDS (one column per lane, conflict-free).
 //   generic tier -- arbitrary nesting (Instance, CSG, Bound, nested BIH): an interpreter whose
 //                   recursion is unrolled at compile time (rayint_g<D> calls rayint_g<D-1>), so
 //                   the call graph is static and the stacks are fixed-size scratch.
@@ -22,30 +22,19 @@
 #define GDN __device__ __noinline__
 #define GHD __host__ __device__ inline
 #else
-#include <cmath>
-#include <cstring>
-#define GD inline
-#define GHD inline
-#define GDN
+// Host compilation exists for the CPU test suite only (tests/hostsim compiles these headers with g++ to check the
+// traversal / shading logic and the flattened layout without a GPU): the shim supplies GD / GHD, the bit casts, a one-lane
+// "wave" (wave_ballot, uni, ld4u, ...) and a host LaneStack.  Nothing in the product includes it.
+#include "host_shim.hpp"
 #endif
 
 namespace glome {
 
+#if defined(__HIPCC__)
 // ------------------------------------------------------------------ small helpers
-GD float as_f(uint32_t u) {
-#if defined(__HIPCC__)
-  return __uint_as_float(u);
-#else
-  float f; std::memcpy(&f, &u, 4); return f;
+GD float as_f(uint32_t u) { return __uint_as_float(u); }
+GD uint32_t as_u(float f) { return __float_as_uint(f); }
 #endif
-}
-GD uint32_t as_u(float f) {
-#if defined(__HIPCC__)
-  return __float_as_uint(f);
-#else
-  uint32_t u; std::memcpy(&u, &f, 4); return u;
-#endif
-}
 constexpr float kInf = 1000000.0f;  // Vec.hs:14 (Q0)
 constexpr float kDel = 0.0001f;     // Vec.hs:40
 
@@ -79,19 +68,13 @@ GD U4 ldu4(const U4* p, uint32_t i) { return p[i]; }
 
 // ------------------------------------------------------------------ wave-level helpers
 // The packet traversal below keeps its control flow uniform across the 64 lanes of a wave: votes decide where the wave
-// goes, every lane follows.  Compiled for the host (tests/hostsim) a "wave" is one lane, and the same code is a
-// single-ray traversal.
+// goes, every lane follows.
+#if defined(__HIPCC__)
 typedef unsigned long long LaneMask;  // one bit per lane of the wave
 // min / max of values that are known not to be NaN where it matters: one instruction, without the quieting moves the
 // compiler puts in front of fminf / fmaxf on values it cannot see the origin of
-#if defined(__HIPCC__)
 GD float min_nn(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 GD float max_nn(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-#else
-GD float min_nn(float a, float b) { return fminf(a, b); }
-GD float max_nn(float a, float b) { return fmaxf(a, b); }
-#endif
-#if defined(__HIPCC__)
 GD LaneMask wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 GD bool wave_any(bool p) { return __ballot(p) != 0ull; }
 GD bool lane_of(LaneMask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }  // this lane's bit (m is wave-uniform)
@@ -108,35 +91,13 @@ GD F4 ld4u(const F4* p, uint32_t i) {
   f32x4 v = *(cf32x4*)(b + (uint32_t)(uni(i) << 4));
   F4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r;
 }
-// the same uniform fetch through the vector memory path (every lane reads the same 16 bytes: one request)
-GD F4 ld4v(const F4* p, uint32_t i) { return p[uni(i)]; }
-#if defined(GLOME_EXP_NODE_VMEM)
-#define LD_NODE ld4v
-#else
-#define LD_NODE ld4u
-#endif
 // the 48-byte triangle record at a uniform index: one address, three loads at immediate offsets
 GD void ld_tri_u(const F4* p, uint32_t tri, F4& q0, F4& q1, F4& q2) {
-#if defined(GLOME_EXP_TRI_VMEM)
-  const F4* t = p + 3 * (size_t)uni(tri);
-  q0 = t[0]; q1 = t[1]; q2 = t[2];
-  return;
-#endif
   const char __attribute__((address_space(4)))* b = (const char __attribute__((address_space(4)))*)(uintptr_t)p;
   cf32x4* q = (cf32x4*)(b + (uint32_t)(uni(tri) * 48u));
   f32x4 a = q[0], c = q[1], e = q[2];
   q0.x = a.x; q0.y = a.y; q0.z = a.z; q0.w = a.w; q1.x = c.x; q1.y = c.y; q1.z = c.z; q1.w = c.w; q2.x = e.x; q2.y = e.y; q2.z = e.z; q2.w = e.w;
 }
-#else
-GD LaneMask wave_ballot(bool p) { return p ? 1ull : 0ull; }
-GD bool wave_any(bool p) { return p; }
-GD bool lane_of(LaneMask m) { return (m & 1ull) != 0; }
-GD uint32_t uni(uint32_t v) { return v; }
-GD LaneMask uni(LaneMask m) { return m; }
-GD uint32_t first_lane_value(LaneMask, uint32_t v) { return v; }
-GD F4 ld4u(const F4* p, uint32_t i) { return p[i]; }
-#define LD_NODE ld4u
-GD void ld_tri_u(const F4* p, uint32_t tri, F4& q0, F4& q1, F4& q2) { q0 = p[3 * tri]; q1 = p[3 * tri + 1]; q2 = p[3 * tri + 2]; }
 #endif
 
 // texture stacks: 4 x 16 bit, innermost first, id+1 (rt_types.h)
@@ -402,13 +363,9 @@ GD bool prim_inside(const DScene& S, uint32_t kind, uint32_t a, V3 p) {
 }
 
 // wave-wide vote: how many lanes of this wave hold `pred` (host build: one "lane", so all or nothing)
-GD int wave_count(bool pred) {
 #if defined(__HIPCC__)
-  return __popcll(__ballot(pred));
-#else
-  return pred ? 64 : 0;
+GD int wave_count(bool pred) { return __popcll(__ballot(pred)); }
 #endif
-}
 
 // ------------------------------------------------------------------ traversal stacks
 // Flat tier: one LDS column per lane -- entry e of lane l lives at base[e * 64 + l], so a wave's push or
@@ -416,23 +373,19 @@ GD int wave_count(bool pred) {
 // The LDS part holds `cap` entries (kept small: LDS per wave is what bounds occupancy); deeper pushes, which are
 // rare, spill to a per-lane column in global memory (`ovf`, same [entry][lane] layout), so any tree depth up to
 // kFlatStack is traversed correctly.
+#if defined(__HIPCC__)
 struct LaneStack {
   uint32_t* node; float* nearv; float* farv;  // pointers to this lane's column (stride 64)
   int cap;                                   // entries held in LDS
   uint32_t* ovf;                             // this lane's overflow column in global memory (3 words per entry), or null
   int ovf_cap;                               // entries available there
-#if defined(__HIPCC__)
   static constexpr int STRIDE = 64;
-#else
-  static constexpr int STRIDE = 1;
-#endif
   GD int total_cap() const { return cap + ovf_cap; }
-  // Packet entries (bih_tri_wave): the node reference and the mask of lanes that want the entry are wave-uniform.  On the
-  // device they live in three vector registers, entry k in lane k of each (a 64-entry scalar stack that costs no LDS:
-  // v_writelane / v_readlane with the stack pointer as the lane); only every lane's own (near, far) goes to the LDS rows.
-  // A kernel whose lanes never push on their own therefore needs two LDS rows per entry instead of three, which is what
-  // bounds its waves per CU.  On the host a wave is one lane and the mask is one bit, kept in bit 31 of the reference.
-#if defined(__HIPCC__)
+  // Packet entries (bih_tri_wave): the node reference and the mask of lanes that want the entry are wave-uniform.  They
+  // live in three vector registers, entry k in lane k of each (a 64-entry scalar stack that costs no LDS: v_writelane /
+  // v_readlane with the stack pointer as the lane); only every lane's own (near, far) goes to the LDS rows.  A kernel
+  // whose lanes never push on their own therefore needs two LDS rows per entry instead of three, which is what bounds
+  // its waves per CU.
   uint32_t ur, ulo, uhi;
   GD void push2(int sp, float a, float b) {
     if (__builtin_expect(sp < cap, 1)) { nearv[sp * STRIDE] = a; farv[sp * STRIDE] = b; }
@@ -457,11 +410,6 @@ struct LaneStack {
     ref = (uint32_t)__builtin_amdgcn_readlane((int)ur, sp);
     m = (LaneMask)(uint32_t)__builtin_amdgcn_readlane((int)ulo, sp) | ((LaneMask)(uint32_t)__builtin_amdgcn_readlane((int)uhi, sp) << 32);
   }
-#else
-  GD void push_wave(int sp, uint32_t ref, LaneMask m, float a, float b) { push(sp, ref | ((uint32_t)(m & 1ull) << 31), a, b); }
-  GD void pop_wave(int sp, uint32_t& ref, LaneMask& m, float& a, float& b) const { uint32_t w; pop(sp, w, a, b); ref = w & 0x7fffffffu; m = w >> 31; }
-#endif
-#if defined(__HIPCC__)
   // The overflow column is spill traffic (non-temporal).  The empty asm pins the overflow loads inside their branch:
   // without it the compiler sinks both branches' loads into one access through a generic (flat) pointer, and every
   // pop becomes three flat loads that wait on the LDS and the vector-memory counters.
@@ -480,17 +428,8 @@ struct LaneStack {
       asm volatile("" : "+v"(n), "+v"(a), "+v"(b));
     }
   }
-#else
-  GD void push(int sp, uint32_t n, float a, float b) {
-    if (sp < cap) { node[sp * STRIDE] = n; nearv[sp * STRIDE] = a; farv[sp * STRIDE] = b; }
-    else { uint32_t* o = ovf + (size_t)(sp - cap) * 3 * STRIDE; o[0] = n; o[STRIDE] = as_u(a); o[2 * STRIDE] = as_u(b); }
-  }
-  GD void pop(int sp, uint32_t& n, float& a, float& b) const {
-    if (sp < cap) { n = node[sp * STRIDE]; a = nearv[sp * STRIDE]; b = farv[sp * STRIDE]; }
-    else { const uint32_t* o = ovf + (size_t)(sp - cap) * 3 * STRIDE; n = o[0]; a = as_f(o[STRIDE]); b = as_f(o[2 * STRIDE]); }
-  }
-#endif
 };
+#endif
 // Generic tier: a fixed private array (scratch).
 struct PrivStack {
   uint32_t node[kGenericStack]; float nearv[kGenericStack]; float farv[kGenericStack];
@@ -573,10 +512,6 @@ GD void bih_traverse(const DScene& S, uint32_t hdr, const Ray& r, float d, STK& 
 // at the pop.  best_t / best_rec: running nearest hit (best_t = kNoBest when none); MODE 2 returns true at the first occluder.
 constexpr float kNoBest = 3.0e38f;
 constexpr uint32_t kNoRec = 0xffffffffu;  // == CAND_NONE below
-#if defined(GLOME_HOSTSIM_TRACE)
-#include <vector>
-static thread_local std::vector<uint32_t>* g_trace_nodes = nullptr; static thread_local std::vector<uint32_t>* g_trace_tris = nullptr;
-#endif
 // LEAFK: what the leaves hold -- 0 triangles (48-byte records), 1 spheres (16-byte records).
 GD bool leaf_item_test(const DScene& S, int leafk, bool shadow, uint32_t prim, const Ray& r, float tmax, float& t) {
   if (leafk == 0) {
@@ -605,9 +540,6 @@ GD bool bih_tri(const DScene& S, uint32_t hdr, const Ray& r, float d, STK& stk, 
     bool popit;
     if (!(ref & BREF_LEAF)) {
       if (COUNT) cnt.bih++;
-#if defined(GLOME_HOSTSIM_TRACE)
-      if (g_trace_nodes) g_trace_nodes->push_back(ref);
-#endif
       F4 n = ld4(S.bihnodes, ref);
       uint32_t w0 = as_u(n.z), right = as_u(n.w);
       uint32_t axis = w0 & 3u, left = w0 >> 2;
@@ -638,9 +570,6 @@ GD bool bih_tri(const DScene& S, uint32_t hdr, const Ray& r, float d, STK& stk, 
         popit = true;  // an empty root leaf, or a stale entry retired at the pop below
       } else {
         uint32_t a = first + delta;
-#if defined(GLOME_HOSTSIM_TRACE)
-        if (g_trace_tris) g_trace_tris->push_back(a);
-#endif
         float t;
         if (COUNT) cnt.prim++;
         // tmax = far (Bih.hs:339; shadow: `fmin d far`, Bih.hs:515 -- far <= d already); MODE 1: far <= best_t
@@ -674,143 +603,12 @@ GD bool bih_tri(const DScene& S, uint32_t hdr, const Ray& r, float d, STK& stk, 
 // when they do not (a block straddling an axis plane through the eye), or the root is a leaf, the lanes fall back to
 // bih_tri.  Results, tie order and work counters are identical to the per-lane traversal.
 // `valid`: the lane holds a ray.  All lanes of the wave must make this call together.
-// ------------------------------------------------------------------ the branch steps of a packet, hand-scheduled
-// The compiler turns the wave-uniform control flow of the branch step into ~60 instructions, two thirds of them scalar
-// bookkeeping (64-bit lane masks selected as pairs of 32-bit moves, branch conditions materialised as masks); the
-// kernel is bound by instruction issue, so the step is written out here: ~30 instructions, every decision one scalar
-// compare + branch, the three axes and the two directions as separate straight-line pieces.  Same arithmetic, same
-// order of operations as the C++ step in bih_tri_packet (which remains the reference implementation: the host
-// compile, the counting variants and every case this routine declines go through it).
-//   walks down from `ref` while it is a branch; returns 0 when it stands on a leaf (am != 0) or nothing is left
-//   (am == 0); returns 1 -- with the state untouched at that node -- when a push would not fit the LDS part of the stack.
-// Registers s[60:69] and vcc are scratch (m0 is used and restored) (named in the clobber list); the far row is `cap_lds` entries after the near row.
-#if defined(__HIPCC__)
-constexpr int kAsmLdsCap = 12;  // the default LDS part of the stack; the routine is instantiated for the caps the launches use
-template <int CAP>
-GD int bih_descend_asm(const F4* nodes, uint32_t& ref, LaneMask& am, int& sp, float& nearv, float& farv, uint32_t fwdbits, int cap_lds,
-                       V3 o, V3 rcp, uint32_t lds_row, uint32_t& g_asm_twait, uint32_t& g_asm_nstep, uint32_t& ur, uint32_t& ulo, uint32_t& uhi) {
-  int status;
-  float dl, dr, tv;
-  uint32_t av;
-  asm volatile(
-      "L_node_%=:\n"
-      "  s_bitcmp1_b32 %[ref], 29\n"
-      "  s_cbranch_scc1 L_done_%=\n"
-      "  s_lshl_b32 s68, %[ref], 4\n"
-#if defined(GLOME_EXP_ASM_TIMING)
-      "  s_memtime s[70:71]\n"
-      "  s_waitcnt lgkmcnt(0)\n"
-      "  s_load_dwordx4 s[60:63], %[nodes], s68\n"
-      "  s_waitcnt lgkmcnt(0)\n"
-      "  s_memtime s[72:73]\n"
-      "  s_waitcnt lgkmcnt(0)\n"
-      "  s_sub_u32 s72, s72, s70\n"
-      "  s_add_u32 %[twait], %[twait], s72\n"
-      "  s_add_u32 %[nstep], %[nstep], 1\n"
-#else
-      "  s_load_dwordx4 s[60:63], %[nodes], s68\n"
-      "  s_waitcnt lgkmcnt(0)\n"
-#endif
-      "  s_and_b32 s69, s62, 3\n"
-      "  s_lshr_b32 s62, s62, 2\n"
-      "  s_cmp_eq_u32 s69, 0\n"
-      "  s_cbranch_scc1 L_ax0_%=\n"
-      "  s_cmp_eq_u32 s69, 1\n"
-      "  s_cbranch_scc1 L_ax1_%=\n"
-      "  v_sub_f32 %[dl], s60, %[oz]\n"
-      "  v_sub_f32 %[dr], s61, %[oz]\n"
-      "  v_mul_f32 %[dl], %[dl], %[rz]\n"
-      "  v_mul_f32 %[dr], %[dr], %[rz]\n"
-      "  s_bitcmp1_b32 %[fwd], 2\n"
-      "  s_branch L_join_%=\n"
-      "L_ax0_%=:\n"
-      "  v_sub_f32 %[dl], s60, %[ox]\n"
-      "  v_sub_f32 %[dr], s61, %[ox]\n"
-      "  v_mul_f32 %[dl], %[dl], %[rx]\n"
-      "  v_mul_f32 %[dr], %[dr], %[rx]\n"
-      "  s_bitcmp1_b32 %[fwd], 0\n"
-      "  s_branch L_join_%=\n"
-      "L_ax1_%=:\n"
-      "  v_sub_f32 %[dl], s60, %[oy]\n"
-      "  v_sub_f32 %[dr], s61, %[oy]\n"
-      "  v_mul_f32 %[dl], %[dl], %[ry]\n"
-      "  v_mul_f32 %[dr], %[dr], %[ry]\n"
-      "  s_bitcmp1_b32 %[fwd], 1\n"
-      "L_join_%=:\n"
-      "  s_cbranch_scc1 L_fwd_%=\n"
-      "  v_swap_b32 %[dl], %[dr]\n"      // rays run towards -axis: the near child is the right one
-      "  s_mov_b32 s68, s62\n"
-      "  s_mov_b32 s62, s63\n"
-      "  s_mov_b32 s63, s68\n"
-      "L_fwd_%=:\n"                      // near child s62 ends at dl, far child s63 starts at dr
-      "  v_cmp_lt_f32 vcc, %[near], %[dl]\n"
-      "  s_and_b64 s[64:65], vcc, %[am]\n"
-      "  v_cmp_lt_f32 vcc, %[dr], %[far]\n"
-      "  s_and_b64 s[66:67], vcc, %[am]\n"
-      "  s_cmp_lg_u64 s[64:65], 0\n"
-      "  s_cbranch_scc0 L_no1_%=\n"
-      "  s_cmp_lg_u64 s[66:67], 0\n"
-      "  s_cbranch_scc0 L_nopush_%=\n"
-      "  s_cmp_ge_i32 %[sp], %[cap]\n"
-      "  s_cbranch_scc1 L_slow_%=\n"
-      "  v_max_f32 %[tv], %[dr], %[near]\n"
-      "  s_mov_b32 s69, m0\n"            // (m0 is restored below: the compiler does not track it through asm)
-      "  s_mov_b32 m0, %[sp]\n"          // the uniform part of the entry: lane `sp` of ur / ulo / uhi
-      "  s_lshl_b32 s68, %[sp], 8\n"
-      "  v_add_u32 %[av], s68, %[lds]\n"
-      "  v_writelane_b32 %[ur], s63, m0\n"
-      "  v_writelane_b32 %[ulo], s66, m0\n"
-      "  v_writelane_b32 %[uhi], s67, m0\n"
-      "  s_mov_b32 m0, s69\n"
-      "  ds_write_b32 %[av], %[tv]\n"    // this lane's (near, far) of the far child
-      "  ds_write_b32 %[av], %[far] offset:%[row1]\n"
-      "  s_add_i32 %[sp], %[sp], 1\n"
-      "L_nopush_%=:\n"
-      "  v_min_f32 %[far], %[dl], %[far]\n"
-      "  s_mov_b32 %[ref], s62\n"
-      "  s_mov_b64 %[am], s[64:65]\n"
-      "  s_branch L_node_%=\n"
-      "L_no1_%=:\n"
-      "  s_cmp_lg_u64 s[66:67], 0\n"
-      "  s_cbranch_scc0 L_none_%=\n"
-      "  v_max_f32 %[near], %[dr], %[near]\n"
-      "  s_mov_b32 %[ref], s63\n"
-      "  s_mov_b64 %[am], s[66:67]\n"
-      "  s_branch L_node_%=\n"
-      "L_none_%=:\n"
-      "  s_mov_b64 %[am], 0\n"
-      "L_done_%=:\n"
-      "  s_mov_b32 %[status], 0\n"
-      "  s_branch L_end_%=\n"
-      "L_slow_%=:\n"
-      "  s_mov_b32 %[status], 1\n"
-      "L_end_%=:\n"
-      : [ref] "+s"(ref), [am] "+s"(am), [sp] "+s"(sp), [near] "+v"(nearv), [far] "+v"(farv), [status] "=s"(status),
-        [dl] "=&v"(dl), [dr] "=&v"(dr), [tv] "=&v"(tv), [av] "=&v"(av), [ur] "+v"(ur), [ulo] "+v"(ulo), [uhi] "+v"(uhi)
-#if defined(GLOME_EXP_ASM_TIMING)
-        , [twait] "+s"(g_asm_twait), [nstep] "+s"(g_asm_nstep)
-#endif
-      : [fwd] "s"(fwdbits), [nodes] "s"(nodes), [cap] "s"(cap_lds), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [rx] "v"(rcp.x), [ry] "v"(rcp.y),
-        [rz] "v"(rcp.z), [lds] "v"(lds_row), [row1] "n"(CAP * 256)
-      : "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69",
-#if defined(GLOME_EXP_ASM_TIMING)
-        "s70", "s71", "s72", "s73",
-#endif
-        "vcc", "scc", "memory");
-  return status;
-}
-#endif
-
 // The packet loop proper.  Every branch in it is wave-uniform (the per-lane decisions are selects), and it takes and
 // returns everything by value, so it can be compiled as a function of its own with plain scalar control flow.
+constexpr int kAsmLdsCap = 12;  // entries of the LDS part of the flat tier's stack: the hand-written walk is instantiated for it
 struct PacketResult { float best_t; uint32_t best_rec; uint32_t occ_lo, occ_hi, n_bih, n_prim; };
-#if defined(GLOME_EXP_PACKET_NOINLINE)
-#define GPK GDN
-#else
-#define GPK GD
-#endif
 template <int MODE, bool COUNT, int LEAFK, class STK>
-GPK PacketResult bih_tri_packet(const F4* nodes, const F4* tris, uint32_t ref, uint32_t delta, uint32_t fwdbits, uint32_t am_lo, uint32_t am_hi,
+GD PacketResult bih_tri_packet(const F4* nodes, const F4* tris, uint32_t ref, uint32_t delta, uint32_t fwdbits, uint32_t am_lo, uint32_t am_hi,
                                 float nearv, float farv, V3 ro, V3 rd, V3 rcp, float best_t, STK stk) {
   ref = uni(ref); delta = uni(delta); fwdbits = uni(fwdbits);
   LaneMask am = uni((LaneMask)am_lo | ((LaneMask)am_hi << 32));
@@ -818,25 +616,11 @@ GPK PacketResult bih_tri_packet(const F4* nodes, const F4* tris, uint32_t ref, u
   PacketResult R; R.best_t = best_t; R.best_rec = kNoRec; R.n_bih = 0; R.n_prim = 0;
   int sp = 0;
   LaneMask occm = 0;  // MODE 2: lanes that found an occluder
-  uint32_t exp_twait = 0, exp_nstep = 0;  // GLOME_EXP_ASM_TIMING only
-  (void)exp_twait; (void)exp_nstep;
   for (;;) {
     // ---- branch steps: walk down while the reference is a branch
     while (!(ref & BREF_LEAF)) {
       ref = uni(ref); am = uni(am); sp = (int)uni((uint32_t)sp);  // wave-uniform by construction: keep them in SGPRs
-#if defined(__HIPCC__) && !defined(GLOME_EXP_NO_ASM)
-      if constexpr (!COUNT && std::is_same<STK, LaneStack>::value) {
-        // the hand-scheduled branch steps; they return 1 where a push has to go to the overflow columns
-        if (stk.cap == 12) {
-          if (bih_descend_asm<12>(nodes, ref, am, sp, nearv, farv, fwdbits, stk.cap, r.o, rcp, (uint32_t)(uintptr_t)stk.nearv, exp_twait, exp_nstep, stk.ur, stk.ulo,
-                                  stk.uhi) == 0) break;
-        } else if (stk.cap == 10) {
-          if (bih_descend_asm<10>(nodes, ref, am, sp, nearv, farv, fwdbits, stk.cap, r.o, rcp, (uint32_t)(uintptr_t)stk.nearv, exp_twait, exp_nstep, stk.ur, stk.ulo,
-                                  stk.uhi) == 0) break;
-        }
-      }
-#endif
-      F4 n = LD_NODE(nodes, ref);
+      F4 n = ld4u(nodes, ref);
       const uint32_t w0 = uni(as_u(n.z)), right = uni(as_u(n.w));
       const uint32_t axis = w0 & 3u, left = w0 >> 2;
       float dl, dr;  // distances to the two planes along the ray; the axis is wave-uniform: a scalar branch, no selects
@@ -899,9 +683,6 @@ GPK PacketResult bih_tri_packet(const F4* nodes, const F4* tris, uint32_t ref, u
     if (am == 0) break;
   }
   R.occ_lo = (uint32_t)occm; R.occ_hi = (uint32_t)(occm >> 32);
-#if defined(GLOME_EXP_ASM_TIMING)
-  R.n_bih = exp_nstep; R.n_prim = exp_twait;
-#endif
   return R;
 }
 
@@ -1031,7 +812,7 @@ GD bool bih_tri_wave(const DScene& S, uint32_t hdr, const Ray& r, float d, bool 
     const LaneMask am = todo & wave_ballot(oct == fwdbits);
     todo &= ~am;
     PacketResult R;
-#if defined(__HIPCC__) && !defined(GLOME_EXP_NO_ASM)
+#if defined(__HIPCC__)
     if constexpr (MODE != 0 && !COUNT && LEAFK == 0 && std::is_same<STK, LaneStack>::value) {
       if (stk.cap == kAsmLdsCap) R = bih_tri_packet_hw<MODE>(S.bihnodes, S.tris, ref, delta, fwdbits, am, nearv, farv, r.o, r.d, rcp, best_t, stk);
       else R = bih_tri_packet<MODE, COUNT, LEAFK, STK>(S.bihnodes, S.tris, ref, delta, fwdbits, (uint32_t)am, (uint32_t)(am >> 32), nearv, farv, r.o, r.d, rcp, best_t, stk);
@@ -1039,9 +820,6 @@ GD bool bih_tri_wave(const DScene& S, uint32_t hdr, const Ray& r, float d, bool 
 #endif
     R = bih_tri_packet<MODE, COUNT, LEAFK, STK>(S.bihnodes, LEAFK == 0 ? S.tris : S.spheres, ref, delta, fwdbits, (uint32_t)am, (uint32_t)(am >> 32),
                                                  nearv, farv, r.o, r.d, rcp, best_t, stk);
-#if defined(GLOME_EXP_ASM_TIMING)
-    if ((threadIdx.x & 63) == 0) { cnt.bih += R.n_bih; cnt.prim += R.n_prim; }
-#endif
     if (lane_of(am)) {
       if (COUNT) { cnt.bih += R.n_bih; cnt.prim += R.n_prim; }
       if (MODE != 2 && R.best_rec != kNoRec) { best_t = R.best_t; best_rec = R.best_rec; }

@@ -4,7 +4,6 @@
 // imports it, and bench.py never times it.  GPU parity tests (-m gpu) go through the real C ABI.
 #include <cstring>
 #include <set>
-#define GLOME_HOSTSIM_TRACE 1
 
 #include "../../glome_amd/csrc/capi_shared.hpp"
 #include "../../glome_amd/csrc/flatten.hpp"
@@ -182,43 +181,6 @@ int hostsim_block_work(void* sv, const float* cam, const float* light_pos, int w
         o[2] = (int)T2.cnt.bih; o[3] = (int)T2.cnt.prim;
       }
     }
-  }
-  return 0;
-}
-
-// EXPERIMENT: what a wave-wide packet would visit = the union of its lanes' visited nodes / tested triangles.
-// out[block][8]: primary: max_lane(nodes+tris), union nodes, union tris, sum nodes, sum tris ; shadow the same in a second row
-int hostsim_packet_union(void* sv, const float* cam, const float* light_pos, int width, int height, int bx0, int by0, int nbx, int nby, int* out) {
-  SimScene* s = (SimScene*)sv;
-  DCamera C; memcpy(&C, cam, sizeof(C));
-  HostStack hs;
-  for (int by = 0; by < nby; by++) for (int bx = 0; bx < nbx; bx++) {
-    std::set<uint32_t> un[2], ut[2]; long sn[2] = {0, 0}, st[2] = {0, 0}; int mx[2] = {0, 0}; int nsh = 0;
-    for (int lane = 0; lane < 64; lane++) {
-      int px = (bx0 + bx) * 8 + (lane & 7), py = (by0 + by) * 8 + (lane >> 3);
-      float xc, yc; get_coordsf(width, height, (float)px, (float)py, xc, yc);
-      Ray ray = primary_ray(C, xc, yc);
-      std::vector<uint32_t> vn, vt; g_trace_nodes = &vn; g_trace_tris = &vt;
-      HostFlatTier<false, false, false> T{s->D, nullptr, 0, hs.lane(kFlatStack), Cnt()};
-      HitG h = T.closest(ray, kInf);
-      un[0].insert(vn.begin(), vn.end()); ut[0].insert(vt.begin(), vt.end()); sn[0] += vn.size(); st[0] += vt.size();
-      mx[0] = std::max(mx[0], (int)(vn.size() + vt.size()));
-      if (h.hit) {
-        V3 lvec = v3(light_pos[0], light_pos[1], light_pos[2]) - h.p;
-        if (!(vdot(lvec, h.n) < 0)) {
-          float llen = sqrtf(vdot(lvec, lvec));
-          Ray sr; sr.o = vscaleadd(h.p, h.n, kDel); sr.d = lvec * (1.0f / llen);
-          vn.clear(); vt.clear();
-          HostFlatTier<false, false, false> T2{s->D, nullptr, 0, hs.lane(kFlatStack), Cnt()};
-          T2.occluded(sr, llen - 2 * kDel);
-          un[1].insert(vn.begin(), vn.end()); ut[1].insert(vt.begin(), vt.end()); sn[1] += vn.size(); st[1] += vt.size();
-          mx[1] = std::max(mx[1], (int)(vn.size() + vt.size())); nsh++;
-        }
-      }
-      g_trace_nodes = nullptr; g_trace_tris = nullptr;
-    }
-    int* o = out + (size_t)(by * nbx + bx) * 12;
-    for (int k = 0; k < 2; k++) { o[k * 6 + 0] = mx[k]; o[k * 6 + 1] = (int)un[k].size(); o[k * 6 + 2] = (int)ut[k].size(); o[k * 6 + 3] = (int)sn[k]; o[k * 6 + 4] = (int)st[k]; o[k * 6 + 5] = k ? nsh : 64; }
   }
   return 0;
 }
