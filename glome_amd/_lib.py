@@ -103,6 +103,7 @@ SYMBOLS = [
     ("glome_sb_material_layers", C.c_int32, [vp, c_ip, C.c_int]),
     ("glome_sb_material_blend", C.c_int32, [vp, C.c_int32, C.c_int32, C.c_double]),
     ("glome_sb_material_blend_fn", C.c_int32, [vp, C.c_int32, C.c_int32, C.c_int32, c_dp]),
+    ("glome_sb_material_warp", C.c_int32, [vp, C.c_int32, C.c_int32, vp, C.c_int, c_dp]),
     ("glome_sb_load_nff", C.c_int32, [vp, C.c_char_p, c_dp, c_dp, C.c_int32, c_ip, c_dp]),
     ("glome_sb_bih_dev", C.c_int32, [vp, vp, c_ip, C.c_int32, C.POINTER(C.c_float)]),
     ("glome_sb_mesh_dev", C.c_int32, [vp, vp, c_dp, C.c_int, c_dp, C.c_int, c_ip, C.c_int, c_ip, C.c_int, C.POINTER(C.c_float)]),

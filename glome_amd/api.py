@@ -240,6 +240,14 @@ class Builder:
         wp = (C.c_double * 4)(*([float(x) for x in params] + [0.0] * (4 - len(params))))
         return self._chk(self.lib.glome_sb_material_blend_fn(self.h, int(a), int(b), int(fn), wp), "glome_sb_material_blend_fn")
 
+    def material_warp(self, frame, scene, lights, xfm):
+        """Warp frame scene' lights' xfm (Shader.hs:47-50): scene = a node or None (the root the scene is committed with);
+        lights = glome_light structs (api.light); xfm = the 24 doubles of the transform M of the closure
+        \\ray hit -> xfm_ray M (Ray (pos hit) (vnorm (dir ray))) (the portal, TestScene.hs:166-172)."""
+        la = (L.Light * max(1, len(lights)))(*lights)
+        x = np.ascontiguousarray(np.asarray(xfm, dtype=np.float64).ravel())
+        return self._chk(self.lib.glome_sb_material_warp(self.h, int(frame), -1 if scene is None else int(scene), la, len(lights), x.ctypes.data_as(L.c_dp)), "glome_sb_material_warp")
+
     # host-side inspection
     def primcount(self, node):
         out = (C.c_long * 3)()

@@ -139,6 +139,22 @@ int32_t glome_sb_material_blend_fn(glome_sb* sb, int32_t a, int32_t b, int32_t w
   });
 }
 
+int32_t glome_sb_material_warp(glome_sb* sb, int32_t frame, int32_t scene, const glome_light* lights, int nlights, const double xfm[24]) {
+  return guard(sb, [&] {
+    if (nlights < 0 || nlights > 8 || (nlights > 0 && !lights) || !xfm) throw std::invalid_argument("bad Warp lights / transform");
+    sb->graph.at(frame);
+    if (scene >= 0) sb->graph.at(scene);
+    Mat m; m.kind = MAT_WARP; m.wframe = frame; m.wscene = scene < 0 ? -1 : scene; m.wxf = xf_from(xfm);
+    for (int k = 0; k < nlights; k++) {
+      WarpLight L;
+      for (int q = 0; q < 3; q++) { L.pos[q] = lights[k].pos[q]; L.color[q] = lights[k].color[q]; }
+      L.rad = lights[k].rad; L.shadow = lights[k].shadow != 0;
+      m.wlights.push_back(L);
+    }
+    return sb->graph.add_mat(m);
+  });
+}
+
 int glome_sb_primcount(glome_sb* sb, int32_t id, long out3[3]) {
   return guard(sb, [&] { out3[0] = out3[1] = out3[2] = 0; sb->graph.primcount(id, out3); return 0; });
 }

@@ -14,7 +14,7 @@ namespace glome {
 
 struct FlatScene {
   std::vector<U4> recs;
-  std::vector<F4> spheres, tris, trinorms, boxes, planes, discs, quadrics, xfms, bihhdr, bihnodes, meshhdr, meshnodes, mtris, mats;
+  std::vector<F4> spheres, tris, trinorms, boxes, planes, discs, quadrics, xfms, bihhdr, bihnodes, meshhdr, meshnodes, mtris, mats, wlights;
   std::vector<U4> mtrimeta, entries;
   std::vector<uint32_t> matkids;
   uint32_t root_rec = 0;
@@ -45,9 +45,11 @@ class Flattener {
     F.root_rec = (uint32_t)F.recs.size();
     F.recs.push_back(r);
     F.nesting_depth = depth_of(root);
+    const bool warps = bind_warps();  // Warp materials refer to records: the frame's, and the scene's they look into
     if (F.nesting_depth > kGenericDepth) throw limit_error("scene nests composites deeper than the device interpreter supports (" + std::to_string(F.nesting_depth) + " > " + std::to_string(kGenericDepth) + ")");
     // flat tier: root program of simple entries
     F.tier = 0;
+    if (warps) { F.tier = 1; F.why_generic = "a Warp material traces other roots than the scene's"; }
     collect_entries(root, 0, 0, 0);
     if (F.tier == 0 && F.max_bih_depth > kFlatStack) { F.tier = 1; F.why_generic = "BIH deeper than the LDS stack"; }
     if (F.tier == 0 && F.max_mesh_depth > kFlatStack) { F.tier = 1; F.why_generic = "Mesh BVH deeper than the LDS stack"; }
@@ -68,7 +70,7 @@ class Flattener {
   void pad() {  // never hand a null pool to a kernel
     auto p4 = [](std::vector<F4>& v) { if (v.empty()) v.push_back(F4{0, 0, 0, 0}); };
     p4(F.spheres); p4(F.tris); p4(F.trinorms); p4(F.boxes); p4(F.planes); p4(F.discs); p4(F.quadrics); p4(F.xfms);
-    p4(F.bihhdr); p4(F.bihnodes); p4(F.meshhdr); p4(F.meshnodes); p4(F.mtris); p4(F.mats);
+    p4(F.bihhdr); p4(F.bihnodes); p4(F.meshhdr); p4(F.meshnodes); p4(F.mtris); p4(F.mats); p4(F.wlights);
     if (F.mtrimeta.empty()) F.mtrimeta.push_back(U4{0, 0, 0, 0});
     if (F.entries.empty()) F.entries.push_back(U4{0, 0, 0, 0});
     if (F.matkids.empty()) F.matkids.push_back(0);
@@ -88,6 +90,7 @@ class Flattener {
           a = (uint32_t)m.a; b = (uint32_t)m.b; w = f32(m.weight);
           m1 = F4{as_float_bits((uint32_t)m.wfn), f32(m.wp[0]), f32(m.wp[1]), f32(m.wp[2])};  // weight function + parameters
           break;
+        case MAT_WARP: break;  // filled in by bind_warps once the records exist
       }
       F.mats.push_back(F4{as_float_bits((uint32_t)m.kind), as_float_bits(a), as_float_bits(b), w});
       F.mats.push_back(m1);
@@ -95,6 +98,29 @@ class Flattener {
     }
     if (mat_nest_max() > kMaxMatNest) throw limit_error("material Blend/AdditiveLayers nesting deeper than the device shader supports");
     if (G.mats.size() > 65534) throw limit_error("more than 65534 materials");
+  }
+  // Warp materials: (kind, frame record, scene record, transform) (first light, light count, -, -)
+  bool bind_warps() {
+    bool any = false;
+    for (size_t k = 0; k < G.mats.size(); k++) {
+      const Mat& m = G.mats[k];
+      if (m.kind != MAT_WARP) continue;
+      any = true;
+      const uint32_t frame = slot(emit(m.wframe)), scene = m.wscene < 0 ? F.root_rec : slot(emit(m.wscene));
+      F.nesting_depth = std::max(F.nesting_depth, std::max(depth_of(m.wframe), m.wscene < 0 ? 0 : depth_of(m.wscene)));
+      if (F.nesting_depth > kGenericDepth) throw limit_error("a Warp material's frame / scene nests composites deeper than the device interpreter supports");
+      const uint32_t xf = (uint32_t)(F.xfms.size() / 6);
+      for (int q = 0; q < 3; q++) F.xfms.push_back(mk4(m.wxf.f.m[4 * q], m.wxf.f.m[4 * q + 1], m.wxf.f.m[4 * q + 2], m.wxf.f.m[4 * q + 3]));
+      for (int q = 0; q < 3; q++) F.xfms.push_back(mk4(m.wxf.i.m[4 * q], m.wxf.i.m[4 * q + 1], m.wxf.i.m[4 * q + 2], m.wxf.i.m[4 * q + 3]));
+      const uint32_t first = (uint32_t)(F.wlights.size() / 2);
+      for (const WarpLight& L : m.wlights) {  // the layout of DLight: pos, color, rad, shadow
+        F.wlights.push_back(mk4(L.pos[0], L.pos[1], L.pos[2], L.color[0]));
+        F.wlights.push_back(F4{f32(L.color[1]), f32(L.color[2]), f32(L.rad), as_float_bits(L.shadow ? 1u : 0u)});
+      }
+      F.mats[3 * k] = F4{as_float_bits((uint32_t)MAT_WARP), as_float_bits(frame), as_float_bits(scene), as_float_bits(xf)};
+      F.mats[3 * k + 1] = F4{as_float_bits(first), as_float_bits((uint32_t)m.wlights.size()), 0, 0};
+    }
+    return any;
   }
   int mat_nest(int m, int guard) const {
     if (guard > 64) throw scene_error("material graph is cyclic");

@@ -38,7 +38,8 @@ using namespace glome;
 // The production variant traverses with early-out and counts rays only.
 template <bool FAITHFUL, bool COUNT, bool FULL_, int CLS = CLS_ALL>
 struct FlatTier {
-  static constexpr bool FULL = FULL_;  // false: lean kernel -- no out-of-line calls at all (no secondary rays, no Blend/Layers)
+  static constexpr bool FULL = FULL_;  // false: lean kernel (no secondary rays, no Blend / Layers)
+  static constexpr bool WARP = false;  // scenes with a Warp material (traces over other roots, Shader.hs:157-175) render on the generic tier
   const DScene& S;
   const DLight* lights;
   int nlights;
@@ -50,11 +51,11 @@ struct FlatTier {
     Cand c = closest_flat<FAITHFUL, COUNT, CLS>(S, r, tmax, stk, cnt, true, &ch, &err);
     return finalize_flat<CLS>(S, r, c, &ch);
   }
-  __device__ __forceinline__ bool occluded(const Ray& r, float d) { return occluded_flat<COUNT, CLS>(S, r, d, stk, cnt, true, &err); }
+  __device__ __forceinline__ bool occluded(const Ray& r, float d, uint32_t = 0) { return occluded_flat<COUNT, CLS>(S, r, d, stk, cnt, true, &err); }
   // wave-wide calls (every lane of the wave makes them together; `valid` = the lane holds a ray): triangle and sphere
   // BIHs are walked as packets, by primary, shadow and secondary rays alike
   static constexpr bool PACKETS = (CLS & (CLS_BIH_TRI | CLS_BIH_SPHERE)) != 0;
-  __device__ __forceinline__ HitG closest_wave(const Ray& r, float tmax, bool valid) {
+  __device__ __forceinline__ HitG closest_wave(const Ray& r, float tmax, bool valid, uint32_t = 0) {
     if constexpr (PACKETS) {
       HitG ch;
       Cand c = closest_flat<FAITHFUL, COUNT, CLS, true>(S, r, tmax, stk, cnt, valid, &ch, &err);
@@ -70,25 +71,29 @@ struct FlatTier {
 };
 struct GenericTier {
   static constexpr bool FULL = true;
+  static constexpr bool WARP = true;
   const DScene& S;
   const DLight* lights;
   int nlights;
   Cnt cnt;
   unsigned int err = 0;
   GPool pool;  // the interpreter's frame / advance pools: one per lane for the whole kernel
-  __device__ __forceinline__ HitG closest(const Ray& r, float tmax) {
+  // `root`: the record the trace runs over -- the scene's, or the frame / scene of a Warp material
+  __device__ __forceinline__ HitG closest(const Ray& r, float tmax, uint32_t root) {
     GCtx<true> g{S, cnt, err, pool};
-    HitG h = rayint_g<kGenericDepth>(g, ldu4(S.recs, S.root_rec), r, tmax, (TexStack)0);
+    HitG h = rayint_g<kGenericDepth>(g, ldu4(S.recs, root), r, tmax, (TexStack)0);
     err = g.err;
     return h;
   }
-  __device__ __forceinline__ bool occluded(const Ray& r, float d) {
+  __device__ __forceinline__ bool occluded(const Ray& r, float d, uint32_t root) {
     GCtx<true> g{S, cnt, err, pool};
-    bool o = shadow_g<kGenericDepth>(g, ldu4(S.recs, S.root_rec), r, d);
+    bool o = shadow_g<kGenericDepth>(g, ldu4(S.recs, root), r, d);
     err = g.err;
     return o;
   }
-  __device__ __forceinline__ HitG closest_wave(const Ray& r, float tmax, bool valid) { return valid ? closest(r, tmax) : hit_miss(); }
+  __device__ __forceinline__ HitG closest(const Ray& r, float tmax) { return closest(r, tmax, S.root_rec); }
+  __device__ __forceinline__ bool occluded(const Ray& r, float d) { return occluded(r, d, S.root_rec); }
+  __device__ __forceinline__ HitG closest_wave(const Ray& r, float tmax, bool valid, uint32_t root) { return valid ? closest(r, tmax, root) : hit_miss(); }
   __device__ __forceinline__ bool occluded_wave(const Ray& r, float d, bool valid) { return valid && occluded(r, d); }
 };
 
@@ -788,7 +793,7 @@ glome_scene* glome_scene_commit(glome_ctx* ctx, glome_sb* sb, int32_t root) {
   rc |= upload(s, F.quadrics, &D.quadrics); rc |= upload(s, F.xfms, &D.xfms);
   rc |= upload(s, F.bihhdr, &D.bihhdr); rc |= upload(s, F.bihnodes, &D.bihnodes);
   rc |= upload(s, F.meshhdr, &D.meshhdr); rc |= upload(s, F.meshnodes, &D.meshnodes); rc |= upload(s, F.mtris, &D.mtris);
-  rc |= upload(s, F.mtrimeta, &D.mtrimeta); rc |= upload(s, F.mats, &D.mats); rc |= upload(s, F.matkids, &D.matkids);
+  rc |= upload(s, F.mtrimeta, &D.mtrimeta); rc |= upload(s, F.mats, &D.mats); rc |= upload(s, F.wlights, &D.wlights); rc |= upload(s, F.matkids, &D.matkids);
   rc |= upload(s, F.entries, &D.entries);
   if (rc) { glome_scene_release(s); return nullptr; }
   D.n_entries = F.tier == 0 ? (uint32_t)F.entries.size() : 0;
@@ -800,7 +805,7 @@ glome_scene* glome_scene_commit(glome_ctx* ctx, glome_sb* sb, int32_t root) {
   I.n_other_prims = F.n_other_prims; I.n_xfms = (int64_t)F.xfms.size() / 6; I.n_materials = D.n_mats;
   I.max_bih_depth = F.max_bih_depth; I.max_mesh_depth = F.max_mesh_depth;
   for (const Mat& m : sb_graph(sb).mats) {
-    if (m.kind == MAT_REFLECT || m.kind == MAT_REFRACT) s->has_secondary_mats = true;
+    if (m.kind == MAT_REFLECT || m.kind == MAT_REFRACT || m.kind == MAT_WARP) s->has_secondary_mats = true;
     if (m.kind == MAT_LAYERS || m.kind == MAT_BLEND) s->has_nested_mats = true;
   }
   if (F.tier == 0) {

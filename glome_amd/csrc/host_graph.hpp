@@ -171,14 +171,21 @@ struct Node {
   std::shared_ptr<MeshData> mesh;
 };
 
-enum MatKind : int { MAT_SURFACE = 0, MAT_REFLECT, MAT_REFRACT, MAT_LAYERS, MAT_BLEND };
-struct Mat {  // Material, Shader.hs:43-52 (Warp excluded: closure + second scene)
+enum MatKind : int { MAT_SURFACE = 0, MAT_REFLECT, MAT_REFRACT, MAT_LAYERS, MAT_BLEND, MAT_WARP };
+struct WarpLight { double pos[3], color[3], rad; bool shadow; };
+struct Mat {  // Material, Shader.hs:43-52
   int kind = MAT_SURFACE;
   double color[3] = {0, 0, 0}, alpha = 1, amb = 0, kd = 0, ks = 0, shine = 0, refl = 0, refr = 0, ior = 1, weight = 0;
   std::vector<int> kids;
   int a = -1, b = -1;
   int wfn = 0;                 // Blend weight: 0 constant, else a solid texture function of the hit position (GLOME_WEIGHT_*)
   double wp[4] = {0, 0, 0, 0};
+  // Warp frame scene' lights' xfm (Shader.hs:47-50): nodes of the frame and of the scene looked into (-1: the root the
+  // scene is committed with -- the portal of TestScene.hs:152-181 looks into the scene it stands in), that scene's lights,
+  // and the matrix of the closure's one shape in the reference, \ray hit -> xfm_ray M (Ray (pos hit) (vnorm (dir ray)))
+  int wframe = -1, wscene = -1;
+  std::vector<WarpLight> wlights;
+  Xf wxf;
 };
 
 struct Graph {

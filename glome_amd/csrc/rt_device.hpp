@@ -891,14 +891,17 @@ GD void mesh_closest(const DScene& S, uint32_t mh, const Ray& ray, float depth, 
 }
 
 
-struct HitG {  // a full Rayint (Solid.hs:20-28 minus riray / riuvw, which the shader never reads)
+struct HitCore {  // a Rayint (Solid.hs:20-28) as the shader reads it
   bool hit;
   float t;
   V3 p, n;
   TexStack tex;
   uint32_t uid;
 };
-GD HitG hit_miss() { HitG h; h.hit = false; h.t = kInf; h.p = v3(0, 0, 0); h.n = v3(0, 0, 0); h.tex = 0; h.uid = 0xffffffffu; return h; }
+struct HitG : HitCore {  // ... plus riray: the ray as the primitive that was hit saw it (local inside Instances, advanced inside CSG).
+  V3 lo, ld;            // Only a Warp material reads it, so only the generic tier (where Warp scenes render) fills it in.
+};
+GD HitG hit_miss() { HitG h; h.hit = false; h.t = kInf; h.p = v3(0, 0, 0); h.n = v3(0, 0, 0); h.tex = 0; h.uid = 0xffffffffu; h.lo = v3(0, 0, 0); h.ld = v3(0, 0, 0); return h; }
 
 
 // ------------------------------------------------------------------ CSG over primitives, without recursion (flat tier)
@@ -1380,11 +1383,18 @@ GD float tx_weight(uint32_t fn, float constant, float p0, float p1, float p2, V3
 // of line, and the kernel's registers are those of one traversal plus one shading step, not a nest of call frames.
 struct LightCache { bool done; uint32_t mask; };  // the lazily evaluated ctxb of Trace.hs:63: visibility per light
 
+struct LightSet { const DLight* p; int n; };  // the [Light] of the trace in progress: the call's, or a Warp material's own
+template <class TIER> GD LightSet light_set(const TIER& T, uint32_t warp_mat) {
+  if (warp_mat == 0xffffffffu) return LightSet{T.lights, T.nlights};
+  const F4 m1 = ld4(T.S.mats, 3 * warp_mat + 1);
+  return LightSet{(const DLight*)(T.S.wlights + 2 * as_u(m1.x)), (int)as_u(m1.y)};
+}
 template <class TIER>
-GD uint32_t preshade(TIER& T, const HitG& h) {  // mpreshade, Shader.hs:65-80 (Q18)
+GD uint32_t preshade(TIER& T, const HitCore& h, LightSet ls = LightSet{nullptr, -1}, uint32_t root = 0) {  // mpreshade, Shader.hs:65-80 (Q18)
+  if (ls.n < 0) ls = LightSet{T.lights, T.nlights};
   uint32_t mask = 0;
-  for (int i = 0; i < T.nlights; i++) {
-    const DLight& L = T.lights[i];
+  for (int i = 0; i < ls.n; i++) {
+    const DLight& L = ls.p[i];
     V3 lvec = v3(L.pos[0], L.pos[1], L.pos[2]) - h.p;
     if (vdot(lvec, h.n) < 0) continue;
     float llen = sqrtf(vdot(lvec, lvec));
@@ -1393,7 +1403,7 @@ GD uint32_t preshade(TIER& T, const HitG& h) {  // mpreshade, Shader.hs:65-80 (Q
     if (L.shadow) {
       T.cnt.shadow++;
       Ray sr; sr.o = vscaleadd(h.p, h.n, kDel); sr.d = ldir;
-      if (T.occluded(sr, llen - (2 * kDel))) continue;
+      if (T.occluded(sr, llen - (2 * kDel), root)) continue;
     }
     mask |= 1u << i;
   }
@@ -1403,7 +1413,7 @@ GD uint32_t preshade(TIER& T, const HitG& h) {  // mpreshade, Shader.hs:65-80 (Q
 // mpreshade for the lanes of a wave at once (`want` = this lane's hit needs its light list): the light loop is uniform,
 // so the shadow rays of one light leave together and can be walked as a packet (TIER::occluded_wave).
 template <class TIER>
-GD uint32_t preshade_wave(TIER& T, const HitG& h, bool want) {
+GD uint32_t preshade_wave(TIER& T, const HitCore& h, bool want) {
   uint32_t mask = 0;
   for (int i = 0; i < T.nlights; i++) {
     const DLight& L = T.lights[i];
@@ -1424,14 +1434,15 @@ GD uint32_t preshade_wave(TIER& T, const HitG& h, bool want) {
 
 // Surface, Shader.hs:90-105 (Q17): ambient + sum over the visible lights of lcolor * (blinn * ks + (l . n) * kd)
 template <class TIER>
-GD CA surface_shade(TIER& T, const F4& m1, const F4& m2, uint32_t lightmask, const Ray& ray, const HitG& h) {
+GD CA surface_shade(TIER& T, const F4& m1, const F4& m2, uint32_t lightmask, const Ray& ray, const HitCore& h, LightSet ls = LightSet{nullptr, -1}) {
+  if (ls.n < 0) ls = LightSet{T.lights, T.nlights};
   const float amb = m2.x, kd = m2.y, ks = m2.z, shine = m2.w;
   const V3 eyedir = vneg(ray.d), n = h.n, p = h.p;
   float ar = m1.x * amb, ag = m1.y * amb, ab = m1.z * amb;  // cscale color amb
   float dr = 0, dg = 0, db = 0;                             // foldl' cadd c_black
-  for (int i = 0; i < T.nlights; i++) {
+  for (int i = 0; i < ls.n; i++) {
     if (!((lightmask >> i) & 1u)) continue;
-    const DLight& L = T.lights[i];
+    const DLight& L = ls.p[i];
     V3 lvec = v3(L.pos[0], L.pos[1], L.pos[2]) - p;
     float llen = sqrtf(vdot(lvec, lvec));
     V3 ldir = lvec * (1.0f / llen);
@@ -1449,12 +1460,12 @@ GD CA surface_shade(TIER& T, const F4& m1, const F4& m2, uint32_t lightmask, con
   }
   return ca(ar + dr, ag + dg, ab + db, m1.w);
 }
-GD Ray reflect_ray(const Ray& ray, const HitG& h) {  // Shader.hs:111-114: reflect (Vec.hs:340-342), origin p + out * delta
+GD Ray reflect_ray(const Ray& ray, const HitCore& h) {  // Shader.hs:111-114: reflect (Vec.hs:340-342), origin p + out * delta
   V3 outdir = vscaleadd(ray.d, h.n, (-2.0f) * vdot(ray.d, h.n));
   Ray rr; rr.o = vscaleadd(h.p, outdir, kDel); rr.d = outdir;
   return rr;
 }
-GD float refract_cs2(float ior, const Ray& ray, const HitG& h, float& eta, float& c1) {  // Shader.hs:128-136
+GD float refract_cs2(float ior, const Ray& ray, const HitCore& h, float& eta, float& c1) {  // Shader.hs:128-136
   eta = (vdot(h.n, vneg(ray.d)) > 0) ? ior : 1.0f / ior;
   c1 = vdot(ray.d, h.n);
   return 1 - (eta * eta) * (1 - (c1 * c1));
@@ -1463,7 +1474,7 @@ GD float refract_cs2(float ior, const Ray& ray, const HitG& h, float& eta, float
 // mpostshade of a lean kernel (TIER::FULL == false): launched only when no secondary trace can do work (maxdepth == 1 or no
 // Reflect / Refract material) and no material nests, so every child trace is `trace ... 0` = traceMiss (Trace.hs:60)
 template <class TIER>
-GD CA postshade_lean(TIER& T, LightCache& lc, uint32_t mat, const Ray& ray, const HitG& h, int recurs) {
+GD CA postshade_lean(TIER& T, LightCache& lc, uint32_t mat, const Ray& ray, const HitCore& h, int recurs) {
   const DScene& S = T.S;
   F4 m0 = ld4(S.mats, 3 * mat), m1 = ld4(S.mats, 3 * mat + 1);
   uint32_t kind = as_u(m0.x);
@@ -1484,7 +1495,7 @@ GD CA postshade_lean(TIER& T, LightCache& lc, uint32_t mat, const Ray& ray, cons
 }
 // trace's fold over the hit's texture stack until opaque (Trace.hs:67-80, Q16), lean kernels
 template <class TIER>
-GD CA shade_hit_lean(TIER& T, const Ray& ray, const HitG& h, LightCache& lc, int recurs) {
+GD CA shade_hit_lean(TIER& T, const Ray& ray, const HitCore& h, LightCache& lc, int recurs) {
   CA acc = ca(0, 0, 0, 0);
   TexStack ts = h.tex;
   for (int k = 0; k < kMaxTexDepth; k++) {
@@ -1498,11 +1509,12 @@ GD CA shade_hit_lean(TIER& T, const Ray& ray, const HitG& h, LightCache& lc, int
 }
 
 // ---- the general evaluation (TIER::FULL): trace (Trace.hs:59-82) and mpostshade (Shader.hs:82-184) as a state machine
-struct VMTrace {  // one `trace` in progress
-  Ray ray; int recurs; HitG h; LightCache lc; CA acc; TexStack ts; int k; int mbase;
+struct VMTrace {  // one `trace` in progress: over `root` (a record; the scene's unless a Warp material chose another) with the lights `lset`
+  Ray ray; float tmax; int recurs; HitCore h; LightCache lc; CA acc; TexStack ts; int k; int mbase; uint32_t root, lset;
+  V3 lo, ld;  // the hit's riray (written in Warp-capable kernels only)
 };
-struct VMMat {    // one material being evaluated: k = children done so far, tmp = what they have contributed
-  uint32_t mat; uint32_t k; CA tmp;
+struct VMMat {    // one material being evaluated: k = children done so far, tmp (and aux) = what they have contributed
+  uint32_t mat; uint32_t k; CA tmp; float aux;
 };
 template <class TIER>
 GD CA shade_vm(TIER& T, const Ray& ray0, float tmax, int maxdepth, bool valid, HitG* hout) {
@@ -1512,19 +1524,22 @@ GD CA shade_vm(TIER& T, const Ray& ray0, float tmax, int maxdepth, bool valid, H
   const DScene& S = T.S;
   int tl = 0, mi = 0, st = S_DONE;
   CA ret = ca(0, 0, 0, 0);
+  float vm_depth = kInf;
   *hout = hit_miss();
-  if (valid && maxdepth > 0) { tr[0].ray = ray0; tr[0].recurs = maxdepth; tr[0].mbase = 0; st = S_NEED_HIT; }
+  if (valid && maxdepth > 0) { tr[0].ray = ray0; tr[0].tmax = tmax; tr[0].recurs = maxdepth; tr[0].mbase = 0; tr[0].root = S.root_rec; tr[0].lset = 0xffffffffu; st = S_NEED_HIT; }
   for (;;) {
     // ---- the wave's requests: every lane that waits for a closest hit is traced now, together (so are the light lists)
     const bool wh = st == S_NEED_HIT;
     if (wave_any(wh)) {
       const Ray r = wh ? tr[tl].ray : ray0;
-      const HitG h = T.closest_wave(r, tl == 0 ? tmax : kInf, wh);
-      if (wh) { tr[tl].h = h; if (tl == 0) *hout = h; st = S_HIT; }
+      const HitG h = T.closest_wave(r, wh ? tr[tl].tmax : tmax, wh, wh ? tr[tl].root : S.root_rec);
+      if (wh) { tr[tl].h = h; if constexpr (TIER::WARP) { tr[tl].lo = h.lo; tr[tl].ld = h.ld; } if (tl == 0) *hout = h; st = S_HIT; }
     }
     const bool wl = st == S_NEED_LIGHTS;
     if (wave_any(wl)) {
-      const uint32_t m = preshade_wave(T, tr[wl ? tl : 0].h, wl);
+      uint32_t m;
+      if constexpr (TIER::WARP) m = wl ? preshade(T, tr[tl].h, light_set(T, tr[tl].lset), tr[tl].root) : 0u;  // lights and root may differ lane by lane
+      else m = preshade_wave(T, tr[wl ? tl : 0].h, wl);
       if (wl) { tr[tl].lc.mask = m; tr[tl].lc.done = true; st = S_MAT_NEW; }
     }
     if (!wave_any(st != S_DONE)) break;
@@ -1550,15 +1565,24 @@ GD CA shade_vm(TIER& T, const Ray& ray0, float tmax, int maxdepth, bool valid, H
           const uint32_t kind = as_u(m0.x);
           if (kind == DM_SURFACE) {
             if (!t.lc.done) { st = S_NEED_LIGHTS; break; }  // the lazily evaluated light list (Trace.hs:63), forced here
-            ret = surface_shade(T, m1, ld4(S.mats, 3 * m.mat + 2), t.lc.mask, t.ray, t.h);
+            if constexpr (TIER::WARP) ret = surface_shade(T, m1, ld4(S.mats, 3 * m.mat + 2), t.lc.mask, t.ray, t.h, light_set(T, t.lset));
+            else ret = surface_shade(T, m1, ld4(S.mats, 3 * m.mat + 2), t.lc.mask, t.ray, t.h);
             st = S_MAT_RET;
+          } else if (TIER::WARP && kind == DM_WARP) {  // Shader.hs:157-175: the frame through the hit's own ray first
+            m.k = 1;
+            if (t.recurs - 1 <= 0) { ret = ca(0, 0, 0, 0); vm_depth = kInf; st = S_MAT_TRACED; break; }  // traceMiss: RayMiss, depth = infinity
+            VMTrace& c = tr[tl + 1];
+            c.ray.o = t.lo; c.ray.d = t.ld; c.tmax = kInf; c.recurs = t.recurs - 1; c.mbase = mi; c.root = as_u(m0.y); c.lset = t.lset;
+            T.cnt.secondary++;
+            tl++;
+            st = S_NEED_HIT;
           } else if (kind == DM_REFLECT || kind == DM_REFRACT) {  // Shader.hs:107-118, 120-155: the reflected ray comes first
             const bool go = kind == DM_REFLECT ? (m1.x > 0) : (m1.x > 0 || m1.y > 0);
             if (!(go && t.recurs > 0)) { ret = kind == DM_REFLECT ? ca(0, 0, 0, 1) : ca(0, 0, 0, 0); st = S_MAT_RET; break; }
             m.k = 1;
             if (t.recurs - 1 <= 0) { ret = ca(0, 0, 0, 0); st = S_MAT_TRACED; break; }  // `trace _ _ _ _ _ 0 = traceMiss` (Trace.hs:60)
             VMTrace& c = tr[tl + 1];
-            c.ray = reflect_ray(t.ray, t.h); c.recurs = t.recurs - 1; c.mbase = mi;
+            c.ray = reflect_ray(t.ray, t.h); c.tmax = kInf; c.recurs = t.recurs - 1; c.mbase = mi; c.root = t.root; c.lset = t.lset;
             T.cnt.secondary++;
             tl++;
             st = S_NEED_HIT;
@@ -1593,6 +1617,20 @@ GD CA shade_vm(TIER& T, const Ray& ray0, float tmax, int maxdepth, bool valid, H
           VMMat& m = ms[mi - 1];
           const F4 m0 = ld4(S.mats, 3 * m.mat), m1 = ld4(S.mats, 3 * m.mat + 1);
           if (as_u(m0.x) == DM_REFLECT) { ret = ca(ret.r, ret.g, ret.b, ret.a * m1.x); st = S_MAT_RET; break; }
+          if (TIER::WARP && as_u(m0.x) == DM_WARP) {
+            if (m.k == 1) {  // the frame is in (colour `ret`, depth `vm_depth`); now the other scene, up to that depth, through the warped ray
+              m.tmp = ret; m.aux = vm_depth; m.k = 2;
+              if (t.recurs - 1 <= 0) { ret = ca(0, 0, 0, 0); vm_depth = kInf; break; }
+              const Xf6 x = load_xf(S, as_u(m0.w));
+              VMTrace& c = tr[tl + 1];
+              c.ray.o = mat_point(x.f0, x.f1, x.f2, t.h.p); c.ray.d = vnorm(mat_vec(x.f0, x.f1, x.f2, vnorm(t.ray.d)));  // xfm_ray M (Ray pos (vnorm dir)), Vec.hs:553-555
+              c.tmax = m.aux; c.recurs = t.recurs - 1; c.mbase = mi; c.root = as_u(m0.z); c.lset = m.mat;
+              T.cnt.secondary++;
+              tl++;
+              st = S_NEED_HIT;
+            } else { ret = (m.aux < vm_depth) ? m.tmp : ret; st = S_MAT_RET; }  // if ridepth fint < ridepth wint then fcolor else wcolor
+            break;
+          }
           const float refl = m1.x, refr = m1.y;
           if (m.k == 1) {  // the reflected part is in; now the transmitted ray (unnormalised, as written, Shader.hs:141)
             m.tmp = ret; m.k = 2;
@@ -1602,7 +1640,7 @@ GD CA shade_vm(TIER& T, const Ray& ray0, float tmax, int maxdepth, bool valid, H
             if (t.recurs - 1 <= 0) { ret = ca(0, 0, 0, 0); break; }
             const V3 tv = (t.ray.d * eta) + (t.h.n * (eta * c1 - sqrtf(cs2)));
             VMTrace& c = tr[tl + 1];
-            c.ray.o = vscaleadd(t.h.p, tv, kDel); c.ray.d = tv; c.recurs = t.recurs - 1; c.mbase = mi;
+            c.ray.o = vscaleadd(t.h.p, tv, kDel); c.ray.d = tv; c.tmax = kInf; c.recurs = t.recurs - 1; c.mbase = mi; c.root = t.root; c.lset = t.lset;
             T.cnt.secondary++;
             tl++;
             st = S_NEED_HIT;
@@ -1618,7 +1656,8 @@ GD CA shade_vm(TIER& T, const Ray& ray0, float tmax, int maxdepth, bool valid, H
           if (mi == t.mbase) { t.acc = cafold(t.acc, ret); t.ts >>= 16; t.k++; st = S_TEX; }
           else st = S_MAT_CHILD;
           break;
-        case S_TRACE_RET:  // the trace of level tl is evaluated: `ret`
+        case S_TRACE_RET:  // the trace of level tl is evaluated: `ret`; vm_depth = ridepth of its Rayint (Warp compares those)
+          vm_depth = (t.recurs > 0 && t.h.hit) ? t.h.t : kInf;
           if (tl == 0) st = S_DONE;
           else { tl--; st = S_MAT_TRACED; }
           break;

@@ -43,7 +43,7 @@ template <int D, bool C> GD HitG rayint_g(GCtx<C>& g, U4 rec, const Ray& r, floa
     if (C) g.cnt.prim++;
     float t; V3 n;
     if (!prim_test<true>(g.S, kind, rec.y, r, d, t, n)) return h;
-    h.hit = true; h.t = t; h.n = n; h.p = vscaleadd(r.o, r.d, t);
+    h.hit = true; h.t = t; h.n = n; h.p = vscaleadd(r.o, r.d, t); h.lo = r.o; h.ld = r.d;
     h.tex = tex_cat(own_stack_rayint(rec.z), tex); h.uid = rec.w;
     return h;
   }
@@ -87,7 +87,7 @@ template <int D, bool C> struct G {
       if (C) g.cnt.prim++;
       float t; V3 n;
       if (!prim_test<true>(S, kind, rec.y, r, d, t, n)) return h;
-      h.hit = true; h.t = t; h.n = n; h.p = vscaleadd(r.o, r.d, t);
+      h.hit = true; h.t = t; h.n = n; h.p = vscaleadd(r.o, r.d, t); h.lo = r.o; h.ld = r.d;
       h.tex = tex_cat(own_stack_rayint(rec.z), tex); h.uid = rec.w;
       return h;
     }
@@ -266,7 +266,7 @@ template <int D, bool C> struct G {
     mesh_closest<C>(S, rec.y, r, d, stk, kGenericStack, g.cnt, mt, ti);
     HitG h = hit_miss();
     if (ti == 0xffffffffu) return h;
-    h.hit = true; h.t = mt; h.p = vscaleadd(r.o, r.d, mt); h.uid = rec.w;
+    h.hit = true; h.t = mt; h.p = vscaleadd(r.o, r.d, mt); h.uid = rec.w; h.lo = r.o; h.ld = r.d;
     U4 meta = ldu4(S.mtrimeta, ti);
     F4 q0 = ld4(S.mtris, 3 * ti), q1 = ld4(S.mtris, 3 * ti + 1), q2 = ld4(S.mtris, 3 * ti + 2);
     if (meta.x == 0) h.n = v3(q0.w, q1.w, q2.w);

@@ -21,7 +21,9 @@
 //   meshnodes float4  x4: (lbb.min, lref) (lbb.max, lcnt) (rbb.min, rref) (rbb.max, rcnt)
 //   mtris     float4  x3 per mesh triangle in leaf order, same layout as `tris`
 //   mtrimeta  uint4   per mesh triangle: (normal base+1 or 0, material+1 or 0, -, -)
-//   mats      float4  x3: (kind, a, b, w) (r, g, b, alpha | refl, refr, ior) (amb, kd, ks, shine)
+//   mats      float4  x3: (kind, a, b, w) (r, g, b, alpha | refl, refr, ior) (amb, kd, ks, shine);
+//                     Warp: (kind, frame record, scene record, transform) (first light, light count, -, -)
+//   wlights   float4  x2 per light of a Warp material, laid out as DLight (pos, color, rad, shadow)
 //   matkids   uint    AdditiveLayers children
 //   entries   uint4   flat-tier root program: (rec, incoming tex stack, flags, -)
 #pragma once
@@ -40,7 +42,7 @@ constexpr uint32_t RF_NOSHADOW = 1u << 9;  // NoShadow: shadow is False (Tex.hs:
 enum BihLeafClass : uint32_t { BC_GENERIC = 0, BC_TRI = 1, BC_SPHERE = 2, BC_SIMPLE = 3, BC_CSG = 4 /* primitives and CSG over primitives */ };
 constexpr uint32_t MESH_BRANCH = 0xffffffffu;  // count value marking "ref is a branch node"
 
-enum DMatKind : uint32_t { DM_SURFACE = 0, DM_REFLECT = 1, DM_REFRACT = 2, DM_LAYERS = 3, DM_BLEND = 4 };
+enum DMatKind : uint32_t { DM_SURFACE = 0, DM_REFLECT = 1, DM_REFRACT = 2, DM_LAYERS = 3, DM_BLEND = 4, DM_WARP = 5 };
 
 // A texture stack is at most 4 material ids, innermost first, 16 bits each, stored as id+1 (0 = end).
 typedef uint64_t TexStack;
@@ -75,6 +77,7 @@ struct DScene {
   const F4* mtris;
   const U4* mtrimeta;
   const F4* mats;
+  const F4* wlights;
   const uint32_t* matkids;
   const U4* entries;
   uint32_t n_entries;

@@ -14,7 +14,7 @@ def r32(x):
 NODE_OPS = {"sphere", "triangle", "trianglenorm", "box", "plane", "plane_offset", "disc", "cylinder", "cone", "group",
             "transform", "difference", "intersection", "bih", "mesh", "tex", "tag", "noshadow", "onlyshadow", "bound_object",
             "innerbound", "flatten_transform", "tolist", "triangles_bulk"}
-MAT_OPS = {"material_surface", "material_reflect", "material_refract", "material_layers", "material_blend", "material_blend_fn"}
+MAT_OPS = {"material_surface", "material_reflect", "material_refract", "material_layers", "material_blend", "material_blend_fn", "material_warp"}
 
 
 class SceneDesc:
@@ -83,9 +83,23 @@ class SceneDesc:
     def material_blend(self, a, b, w): return self._mat("material_blend", a, b, self._q(w))
     def material_blend_fn(self, a, b, fn, params): return self._mat("material_blend_fn", a, b, int(fn), self._q(list(params)))
 
+    def material_warp(self, frame, scene, lights, xfm):
+        """Warp frame scene' lights' xfm (Shader.hs:47-50).  scene: a node or None = the scene's own root; lights: [(pos, color)]
+        or [(pos, color, rad, shadow)]; xfm: the 24 doubles of the closure's transform (api.compose of api.rotate / translate ...)."""
+        ls = [(self._q(l[0]), self._q(l[1]), float(l[2]) if len(l) > 2 else 1000000.0, bool(l[3]) if len(l) > 3 else True) for l in lights]
+        return self._mat("material_warp", frame, scene, ls, np.asarray(xfm, dtype=np.float64).ravel().copy())
+
     def set_root(self, node): self.root = node
     def add_light(self, pos, color, rad=1000000.0, shadow=True): self.lights.append((self._q(pos), self._q(color), float(rad), bool(shadow)))
     def set_camera(self, pos, at, up, angle): self.cam = (self._q(pos), self._q(at), self._q(up), float(angle))
+
+    @staticmethod
+    def _warp_lights(backend, ls):
+        """the product builder takes glome_light structs (fp32 fields, like the render call's lights); a checker takes the tuples"""
+        if hasattr(backend, "lib") and hasattr(backend.lib, "glome_sb_material_warp"):
+            from . import api
+            return [api.light(p, c, r, s) for (p, c, r, s) in ls]
+        return ls
 
     # --- replay ---
     def replay(self, backend):
@@ -100,6 +114,8 @@ class SceneDesc:
                     mmap.append(backend.material_blend(mmap[args[0]], mmap[args[1]], args[2]))
                 elif name == "material_blend_fn":
                     mmap.append(backend.material_blend_fn(mmap[args[0]], mmap[args[1]], args[2], args[3]))
+                elif name == "material_warp":
+                    mmap.append(backend.material_warp(N(args[0]), None if args[1] is None else N(args[1]), self._warp_lights(backend, args[2]), args[3]))
                 else:
                     mmap.append(getattr(backend, name)(*args))
             elif kind == "N":

@@ -144,6 +144,15 @@ int32_t glome_sb_material_blend(glome_sb*, int32_t a, int32_t b, double weight);
 #define GLOME_WEIGHT_STRIPE_TRIANGLE 3
 #define GLOME_WEIGHT_STRIPE_SINE 4
 int32_t glome_sb_material_blend_fn(glome_sb*, int32_t a, int32_t b, int32_t weight_fn, const double* params4);
+/* Warp frame scene' lights' xfm (Shader.hs:47-50, 157-175): a hit on this material traces `frame` with the hit's own ray (the
+ * ray as the primitive saw it -- local coordinates inside a `transform`, Solid.hs:388-403) and the other scene with the
+ * warped ray, up to the frame's depth, and shows whichever is nearer.  `scene` is a node, or -1 for the root the scene
+ * is committed with (the portal of TestScene.hs:152-181 looks into the scene it stands in: in Haskell laziness ties that
+ * knot).  `lights` are that scene's lights.  The closure `Ray -> Rayint -> Ray` crosses the ABI as its one shape in the
+ * reference, \ray hit -> xfm_ray M (Ray (pos hit) (vnorm (dir ray))) (TestScene.hs:166-172): xfm = M, 24 doubles like
+ * every transform here.  Scenes with a Warp material render on the generic tier. */
+struct glome_light;
+int32_t glome_sb_material_warp(glome_sb*, int32_t frame, int32_t scene, const struct glome_light* lights, int nlights, const double xfm[24]);
 /* host-side inspection (no GPU needed) */
 int glome_sb_primcount(glome_sb*, int32_t id, long out3[3]);  /* primcount, Solid.hs:197,251 */
 int glome_sb_bound(glome_sb*, int32_t id, double out6[6]);    /* bound, Solid.hs:171 */

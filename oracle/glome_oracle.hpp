@@ -172,6 +172,11 @@ template <class R> Vec<R> xfm_vec(const Xfm<R>& x, Vec<R> v) {  // Vec.hs:522-52
   return {m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z,
           m[8] * v.x + m[9] * v.y + m[10] * v.z};
 }
+template <class R> Vec<R> invxfm_vec(const Xfm<R>& x, Vec<R> v);
+template <class R> Vec<R> xfm_vec(const Xfm<R>& x, Vec<R> v);
+template <class R> Vec<R> xfm_point(const Xfm<R>& x, Vec<R> v);
+template <class R> Vec<R> vnorm(Vec<R> v);
+template <class R> Ray<R> xfm_ray(const Xfm<R>& x, const Ray<R>& r) { return Ray<R>{xfm_point(x, r.o), vnorm(xfm_vec(x, r.d))}; }  // Vec.hs:553-555
 template <class R> Vec<R> invxfm_vec(const Xfm<R>& x, Vec<R> v) {  // Vec.hs:532-539
   const R* m = x.i.m;
   return {m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z,
@@ -304,10 +309,11 @@ struct TexList {
   }
 };
 
-template <class R> struct Rayint {  // Solid.hs:20-28 (riray / riuvw are never read by the shader; omitted)
+template <class R> struct Rayint {  // Solid.hs:20-28 (riuvw is never read by anything; omitted)
   bool hit = false;
   R depth = 0;
   Vec<R> pos{0, 0, 0}, norm{0, 0, 0};
+  Ray<R> riray{{0, 0, 0}, {0, 0, 0}};  // the ray as the primitive that was hit saw it (local inside Instances, advanced inside CSG); Warp reads it
   TexList tex;
   int prim = -1;  // id of the constructor call that made the primitive (not in the reference)
 };
@@ -492,7 +498,7 @@ template <class R> struct Sphere : Solid<R> {
     R hitdist = ((v - d) > 0) ? (v - d) : (v + d);
     if ((hitdist < 0) || (hitdist > dist)) return {};
     Rayint<R> h;
-    h.hit = true; h.depth = hitdist;
+    h.hit = true; h.riray = ray; h.depth = hitdist;
     h.pos = vscaleadd(ray.o, ray.d, hitdist);
     h.norm = vnorm(vsub(h.pos, c));
     h.tex = t; h.prim = this->uid;
@@ -554,7 +560,7 @@ template <class R> struct Triangle : Solid<R> {
     R t, b1, b2;
     if (!mt_core(p1, p2, p3, ray, dist, t, b1, b2)) return {};
     Rayint<R> h;
-    h.hit = true; h.depth = t;
+    h.hit = true; h.riray = ray; h.depth = t;
     h.pos = vscaleadd(ray.o, ray.d, t);
     h.norm = vnorm(vcross(vsub(p2, p1), vsub(p3, p1)));  // not flipped toward the viewer
     h.tex = tex; h.prim = this->uid;
@@ -582,7 +588,7 @@ template <class R> struct TriangleNorm : Solid<R> {
     R t, b1, b2;
     if (!mt_core(p1, p2, p3, ray, dist, t, b1, b2)) return {};
     Rayint<R> h;
-    h.hit = true; h.depth = t;
+    h.hit = true; h.riray = ray; h.depth = t;
     h.pos = vscaleadd(ray.o, ray.d, t);
     h.norm = vnorm(vadd3(vscale(n1, 1 - (b1 + b2)), vscale(n2, b1), vscale(n3, b2)));
     h.tex = tex; h.prim = this->uid;
@@ -621,7 +627,7 @@ template <class R> struct Box : Solid<R> {
     R lastin = M::fmax3(inx, iny, inz), firstout = M::fmin3(outx, outy, outz);
     if (lastin > firstout || firstout < 0 || lastin > d) return {};
     Rayint<R> h;
-    h.hit = true; h.tex = t; h.prim = this->uid;
+    h.hit = true; h.riray = r; h.tex = t; h.prim = this->uid;
     if (lastin < 0) {  // origin is inside
       Vec<R> n;
       if (outx == firstout) n = (dx > 0) ? Vec<R>{1, 0, 0} : Vec<R>{-1, 0, 0};
@@ -658,7 +664,7 @@ template <class R> struct Plane : Solid<R> {
     R hit = -((vdot(n, r.o) - off) / vdot(n, r.d));
     if (hit < 0 || hit > d) return {};
     Rayint<R> h;
-    h.hit = true; h.depth = hit; h.pos = vscaleadd(r.o, r.d, hit); h.norm = n; h.tex = t; h.prim = this->uid;
+    h.hit = true; h.riray = r; h.depth = hit; h.pos = vscaleadd(r.o, r.d, hit); h.norm = n; h.tex = t; h.prim = this->uid;
     return h;
   }
   bool inside(Vec<R> p) const override {  // Plane.hs:34-38
@@ -680,7 +686,7 @@ template <class R> Rayint<R> rayint_disc(Vec<R> point, Vec<R> norm, R radius_sqr
   R dist; Vec<R> pos;
   if (!disc_hit(point, norm, radius_sqr, r, d, dist, pos)) return {};
   Rayint<R> h;
-  h.hit = true; h.depth = dist; h.pos = pos; h.norm = norm; h.tex = t; h.prim = uid;
+  h.hit = true; h.riray = r; h.depth = dist; h.pos = pos; h.norm = norm; h.tex = t; h.prim = uid;
   return h;
 }
 template <class R> struct Disc : Solid<R> {
@@ -719,7 +725,7 @@ template <class R> struct Cylinder : Solid<R> {  // radius height1 height2, Cone
     Vec<R> pos = vscaleadd(ray.o, ray.d, dist);
     if (pos.z > h1 && pos.z < h2) {
       Rayint<R> h;
-      h.hit = true; h.depth = dist; h.pos = pos; h.norm = Vec<R>{pos.x / r, pos.y / r, 0}; h.tex = t; h.prim = this->uid;
+      h.hit = true; h.riray = ray; h.depth = dist; h.pos = pos; h.norm = Vec<R>{pos.x / r, pos.y / r, 0}; h.tex = t; h.prim = this->uid;
       return h;
     }
     if (dz > 0) {  // ray pointing up from bottom
@@ -768,7 +774,7 @@ template <class R> struct Cone : Solid<R> {  // r clip1 clip2 height, Cone.hs:23
       R r_ = std::sqrt(pos.x * pos.x + pos.y * pos.y);
       R correction = out / r_;
       Rayint<R> h;
-      h.hit = true; h.depth = dist; h.pos = pos; h.norm = Vec<R>{pos.x * correction, pos.y * correction, up}; h.tex = t; h.prim = this->uid;
+      h.hit = true; h.riray = ray; h.depth = dist; h.pos = pos; h.norm = Vec<R>{pos.x * correction, pos.y * correction, up}; h.tex = t; h.prim = this->uid;
       return h;
     }
     if (ray.d.z > 0) {
@@ -1172,7 +1178,7 @@ template <class R> struct Mesh : Solid<R> {
     R t, b1, b2;
     if (!mt_core(a, b, c, ray, farv, t, b1, b2)) return {};
     Rayint<R> h;
-    h.hit = true; h.depth = t; h.pos = vscaleadd(ray.o, ray.d, t); h.tex = tex; h.prim = this->uid;
+    h.hit = true; h.riray = ray; h.depth = t; h.pos = vscaleadd(ray.o, ray.d, t); h.tex = tex; h.prim = this->uid;
     if (T.na == -1) h.norm = vnorm(vcross(vsub(b, a), vsub(c, a)));
     else h.norm = vnorm(vadd3(vscale(norms[T.na], 1 - (b1 + b2)), vscale(norms[T.nb], b1), vscale(norms[T.nc], b2)));
     return h;
@@ -1266,8 +1272,8 @@ template <class R> R tx_weight(int fn, const R* wp, R constant, Vec<R> pos) {
   return tx_wave(fn, vdot(pos, Vec<R>{wp[0], wp[1], wp[2]}));
 }
 
-enum MatKind { M_SURFACE = 0, M_REFLECT = 1, M_REFRACT = 2, M_LAYERS = 3, M_BLEND = 4 };
-template <class R> struct Material {  // Shader.hs:43-52 (Warp is out of scope: closure + second scene)
+enum MatKind { M_SURFACE = 0, M_REFLECT = 1, M_REFRACT = 2, M_LAYERS = 3, M_BLEND = 4, M_WARP = 5 };
+template <class R> struct Material {  // Shader.hs:43-52
   int kind = M_SURFACE;
   Color<R> color{0, 0, 0};
   R alpha = 1, amb = 0, kd = 0, ks = 0, shine = 0;  // Surface
@@ -1275,6 +1281,12 @@ template <class R> struct Material {  // Shader.hs:43-52 (Warp is out of scope: 
   std::vector<int> kids;                            // AdditiveLayers
   int ma = -1, mb = -1; R weight = 0;               // Blend
   int wfn = W_CONST; R wp[4] = {0, 0, 0, 0};        // Blend weight as a solid texture function of the hit position
+  // Warp frame scene' lights' xfm (Shader.hs:47-50).  The closure `xfm :: Ray -> Rayint -> Ray` in its one shape in the
+  // reference (the portal, TestScene.hs:166-172): \ray hit -> xfm_ray M (Ray (pos hit) (vnorm (dir ray))).
+  // wscene == nullptr: the scene the material is used in (the portal looks into geom'' itself, TestScene.hs:181).
+  SP<R> wframe, wscene;
+  std::vector<Light<R>> wlights;
+  Xfm<R> wxfm;
 };
 template <class R> struct Camera { Vec<R> pos, fwd, up, right; };  // Scene.hs:35
 template <class R> Camera<R> camera(Vec<R> pos, Vec<R> at, Vec<R> up, R angle) {  // Scene.hs:48-57
@@ -1297,12 +1309,13 @@ template <class R> struct Tracer {
   const Scene<R>& S;
   explicit Tracer(const Scene<R>& s) : S(s) {}
   using M = Math<R>;
+  typedef std::vector<Light<R>> Lights;
 
-  // mpreshade, Shader.hs:65-80 (Q18)
-  std::vector<LightSample<R>> preshade(const Rayint<R>& ri) const {
+  // mpreshade, Shader.hs:65-80 (Q18): `ls` and `sld` are the lights and the solid of the trace in progress
+  std::vector<LightSample<R>> preshade(const Lights& ls, const Solid<R>& sld, const Rayint<R>& ri) const {
     std::vector<LightSample<R>> out;
     if (!ri.hit) return out;
-    for (auto& L : S.lights) {
+    for (auto& L : ls) {
       Vec<R> lvec = vsub(L.pos, ri.pos);
       if (vdot(lvec, ri.norm) < 0) continue;
       R llen = vlen(lvec);
@@ -1310,7 +1323,7 @@ template <class R> struct Tracer {
       if (llen > L.rad) continue;
       if (L.shadow) {
         tls_counters().rays_shadow++;
-        if (S.root->shadow(Ray<R>{vscaleadd(ri.pos, ri.norm, M::delta()), ldir}, llen - (2 * M::delta()))) continue;
+        if (sld.shadow(Ray<R>{vscaleadd(ri.pos, ri.norm, M::delta()), ldir}, llen - (2 * M::delta()))) continue;
       }
       out.push_back({cscale(L.col, 1 / (llen * llen)), ldir});
     }
@@ -1318,27 +1331,27 @@ template <class R> struct Tracer {
   }
   // mpostshade, Shader.hs:82-184 (Q17).  `lights` is evaluated lazily like ctxb in Trace.hs:63.
   struct Lazy { bool done = false; std::vector<LightSample<R>> v; };
-  ColorA<R> postshade(Lazy& lz, int mat, const Ray<R>& ray, const Rayint<R>& ri, int recurs) const {
+  ColorA<R> postshade(const Lights& ls, const Solid<R>& sld, Lazy& lz, int mat, const Ray<R>& ray, const Rayint<R>& ri, int recurs) const {
     if (!ri.hit) return {0, 0, 0, 0};
     const Material<R>& m = S.mats.at(mat);
     Vec<R> dir = ray.d, n = ri.norm, p = ri.pos;
     Vec<R> eyedir = vinvert(dir);
     switch (m.kind) {
       case M_SURFACE: {
-        if (!lz.done) { lz.v = preshade(ri); lz.done = true; }
+        if (!lz.done) { lz.v = preshade(ls, sld, ri); lz.done = true; }
         Color<R> ambient = cscale(m.color, m.amb);
         Color<R> direct{0, 0, 0};
-        for (auto& ls : lz.v) {
-          Vec<R> halfangle = bisect(ls.dir, eyedir);
-          R ldotn = M::fmax(0, vdot(ls.dir, n));
+        for (auto& l : lz.v) {
+          Vec<R> halfangle = bisect(l.dir, eyedir);
+          R ldotn = M::fmax(0, vdot(l.dir, n));
           R blinn;
           if (m.ks <= M::delta()) blinn = 0;
           else {
             R b = M::fmax(0, std::pow(vdot(halfangle, n), m.shine) * ldotn);
             blinn = std::isnan(b) ? R(0) : b;
           }
-          R diffuse = vdot(ls.dir, n);
-          direct = cadd(direct, cscale(ls.c, (blinn * m.ks) + (diffuse * m.kd)));
+          R diffuse = vdot(l.dir, n);
+          direct = cadd(direct, cscale(l.c, (blinn * m.ks) + (diffuse * m.kd)));
         }
         Color<R> c = cadd(ambient, direct);
         return {c.r, c.g, c.b, m.alpha};
@@ -1347,7 +1360,7 @@ template <class R> struct Tracer {
         if ((m.refl > 0) && (recurs > 0)) {
           Vec<R> outdir = reflect(dir, n);
           tls_counters().rays_secondary += (recurs - 1 > 0);
-          ColorA<R> c = trace(Ray<R>{vscaleadd(p, outdir, M::delta()), outdir}, M::infinity(), recurs - 1);
+          ColorA<R> c = trace(ls, sld, Ray<R>{vscaleadd(p, outdir, M::delta()), outdir}, M::infinity(), recurs - 1);
           return {c.r, c.g, c.b, c.a * m.refl};
         }
         return {0, 0, 0, 1};
@@ -1356,7 +1369,7 @@ template <class R> struct Tracer {
         if ((m.refl > 0 || m.refr > 0) && (recurs > 0)) {
           Vec<R> outdir = reflect(dir, n);
           tls_counters().rays_secondary += (recurs - 1 > 0);
-          ColorA<R> cr = trace(Ray<R>{vscaleadd(p, outdir, M::delta()), outdir}, M::infinity(), recurs - 1);
+          ColorA<R> cr = trace(ls, sld, Ray<R>{vscaleadd(p, outdir, M::delta()), outdir}, M::infinity(), recurs - 1);
           R eta = (vdot(n, eyedir) > 0) ? m.ior : 1 / m.ior;
           R c1 = vdot(dir, n);
           R cs2 = 1 - (eta * eta) * (1 - (c1 * c1));
@@ -1364,39 +1377,50 @@ template <class R> struct Tracer {
           if (!(cs2 < 0)) {
             Vec<R> t = vadd(vscale(dir, eta), vscale(n, eta * c1 - std::sqrt(cs2)));
             tls_counters().rays_secondary += (recurs - 1 > 0);
-            ct = trace(Ray<R>{vscaleadd(p, t, M::delta()), t}, M::infinity(), recurs - 1);
+            ct = trace(ls, sld, Ray<R>{vscaleadd(p, t, M::delta()), t}, M::infinity(), recurs - 1);
           }
           return {cr.r * m.refl + ct.r * m.refr, cr.g * m.refl + ct.g * m.refr, cr.b * m.refl + ct.b * m.refr, cr.a * m.refl + ct.a * m.refr};
         }
         return {0, 0, 0, 0};
       }
+      case M_WARP: {  // Shader.hs:157-175: the frame through the hit's own (local) ray, then the other scene up to the frame's depth
+        Rayint<R> fint, wint;
+        tls_counters().rays_secondary += (recurs - 1 > 0);
+        ColorA<R> fcolor = trace(ls, *m.wframe, ri.riray, M::infinity(), recurs - 1, &fint);
+        Ray<R> wray = xfm_ray(m.wxfm, Ray<R>{ri.pos, vnorm(ray.d)});  // the portal's closure (TestScene.hs:166-172)
+        tls_counters().rays_secondary += (recurs - 1 > 0);
+        ColorA<R> wcolor = trace(m.wlights, m.wscene ? *m.wscene : *S.root, wray, ridepth(fint), recurs - 1, &wint);
+        return (ridepth(fint) < ridepth(wint)) ? fcolor : wcolor;
+      }
       case M_LAYERS: {
         std::vector<ColorA<R>> cs;
-        for (int k : m.kids) cs.push_back(postshade(lz, k, ray, ri, recurs));
+        for (int k : m.kids) cs.push_back(postshade(ls, sld, lz, k, ray, ri, recurs));
         return casum(cs);
       }
       case M_BLEND: {
-        ColorA<R> ca = postshade(lz, m.ma, ray, ri, recurs);
-        ColorA<R> cb = postshade(lz, m.mb, ray, ri, recurs);
+        ColorA<R> ca = postshade(ls, sld, lz, m.ma, ray, ri, recurs);
+        ColorA<R> cb = postshade(ls, sld, lz, m.mb, ray, ri, recurs);
         return caweight(ca, cb, tx_weight<R>(m.wfn, m.wp, m.weight, ri.pos));
       }
     }
     return {0, 0, 0, 0};
   }
-  // trace, Trace.hs:59-82 (Q16); *ri_out receives the primary Rayint
-  ColorA<R> trace(const Ray<R>& ray, R depth, int recurs, Rayint<R>* ri_out = nullptr) const {
+  // trace, Trace.hs:59-82 (Q16); *ri_out receives the trace's Rayint
+  ColorA<R> trace(const Lights& ls, const Solid<R>& sld, const Ray<R>& ray, R depth, int recurs, Rayint<R>* ri_out = nullptr) const {
     if (recurs == 0) { if (ri_out) *ri_out = Rayint<R>(); return {0, 0, 0, 0}; }
-    Rayint<R> ri = S.root->rayint(ray, depth, TexList());
+    Rayint<R> ri = sld.rayint(ray, depth, TexList());
     if (ri_out) *ri_out = ri;
     if (!ri.hit) return {0, 0, 0, 0};  // mmissshade, Shader.hs:186-187
     Lazy lz;
     ColorA<R> acc{0, 0, 0, 0};
     for (int k = 0; k < ri.tex.n; k++) {
       if (acc.a + M::delta() >= 1) break;  // opaque, Trace.hs:50-51
-      acc = cafold(acc, postshade(lz, ri.tex.v[k], ray, ri, recurs));
+      acc = cafold(acc, postshade(ls, sld, lz, ri.tex.v[k], ray, ri, recurs));
     }
     return acc;
   }
+  // `Trace.trace lights shader sld ray depth maxdepth` over the scene's own root and lights (Glome.hs:33)
+  ColorA<R> trace(const Ray<R>& ray, R depth, int recurs, Rayint<R>* ri_out = nullptr) const { return trace(S.lights, *S.root, ray, depth, recurs, ri_out); }
 };
 
 // ---------------------------------------------------------------------------------------

@@ -40,6 +40,7 @@ struct IOracle {
   virtual int mat_layers(const int* ids, int n) = 0;
   virtual int mat_blend(int a, int b, double w) = 0;
   virtual int mat_blend_fn(int a, int b, int fn, const double* wp) = 0;
+  virtual int mat_warp(int frame, int scene, const double* lights8, int nl, const double* xfm24) = 0;
   virtual void set_root(int id) = 0;
   virtual void set_camera(const double* c12) = 0;
   virtual void clear_lights() = 0;
@@ -232,6 +233,11 @@ template <class R> struct Impl : IOracle {
     for (int k = 0; k < 4; k++) m.wp[k] = R(wp[k]);
     return addmat(m);
   }
+  int mat_warp(int frame, int scn, const double* l8, int nl, const double* xfm24) override {  // Shader.hs:47-50; scn < 0: the scene the material is used in
+    Material<R> m; m.kind = M_WARP; m.wframe = get(frame); m.wscene = scn < 0 ? nullptr : get(scn); m.wxfm = X(xfm24);
+    for (int k = 0; k < nl; k++) { Light<R> L; L.pos = V(l8 + 8 * k); L.col = {R(l8[8 * k + 3]), R(l8[8 * k + 4]), R(l8[8 * k + 5])}; L.rad = R(l8[8 * k + 6]); L.shadow = l8[8 * k + 7] != 0; m.wlights.push_back(L); }
+    return addmat(m);
+  }
   void set_root(int id) override { scene.root = get(id); }
   void set_camera(const double* c) override { scene.cam = {V(c), V(c + 3), V(c + 6), V(c + 9)}; }
   void clear_lights() override { scene.lights.clear(); }
@@ -347,6 +353,7 @@ int glo_material_refract(void* h, double refl, double refr, double ior) { return
 int glo_material_layers(void* h, const int* ids, int n) { return guard(h, [&](IOracle* o) { return o->mat_layers(ids, n); }); }
 int glo_material_blend(void* h, int a, int b, double w) { return guard(h, [&](IOracle* o) { return o->mat_blend(a, b, w); }); }
 int glo_material_blend_fn(void* h, int a, int b, int fn, const double* wp) { return guard(h, [&](IOracle* o) { return o->mat_blend_fn(a, b, fn, wp); }); }
+int glo_material_warp(void* h, int frame, int scene, const double* lights8, int nl, const double* xfm24) { return guard(h, [&](IOracle* o) { return o->mat_warp(frame, scene, lights8, nl, xfm24); }); }
 // the scalar field alone (tests): fn as in WeightFn, wp[4], n points
 int glo_weight_fn(int fn, const double* wp, int n, const double* xyz, double* out) {
   for (int i = 0; i < n; i++) out[i] = tx_weight<double>(fn, wp, 0.0, Vec<double>{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]});

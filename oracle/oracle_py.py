@@ -133,6 +133,19 @@ class Oracle:
         wp = (C.c_double * 4)(*([float(x) for x in params] + [0.0] * (4 - len(params))))
         return self._chk(self.L.glo_material_blend_fn(self.h, C.c_int(int(a)), C.c_int(int(b)), C.c_int(int(fn)), wp), "glo_material_blend_fn")
 
+    def material_warp(self, frame, scene, lights, xfm):
+        """lights: [(pos, color, rad, shadow)] or glome_light structs"""
+        rows = []
+        for l in lights:
+            if isinstance(l, (tuple, list)):
+                pos, col, rad, sh = l
+            else:
+                pos, col, rad, sh = list(l.pos), list(l.color), l.rad, l.shadow
+            rows += [float(x) for x in pos] + [float(x) for x in col] + [float(rad), 1.0 if sh else 0.0]
+        l8 = _d(rows if rows else [0.0] * 8)
+        x = _d(np.asarray(xfm, dtype=np.float64).ravel())
+        return self._chk(self.L.glo_material_warp(self.h, C.c_int(int(frame)), C.c_int(-1 if scene is None else int(scene)), _dp(l8), C.c_int(len(lights)), _dp(x)), "glo_material_warp")
+
     # ---- scene state ----
     def set_root(self, node): self._chk(self.L.glo_set_root(self.h, C.c_int(int(node))), "glo_set_root")
     def set_camera_vectors(self, pos, fwd, up, right):

@@ -20,6 +20,7 @@ struct SimScene {
 
 template <bool FAITHFUL, bool COUNT, bool FULL_> struct HostFlatTier {
   static constexpr bool FULL = FULL_;
+  static constexpr bool WARP = false;
   const DScene& S;
   const DLight* lights;
   int nlights;
@@ -27,21 +28,24 @@ template <bool FAITHFUL, bool COUNT, bool FULL_> struct HostFlatTier {
   Cnt cnt;
   unsigned int err = 0;
   HitG closest(const Ray& r, float tmax) { HitG ch; Cand c = closest_flat<FAITHFUL, COUNT, CLS_EVERY>(S, r, tmax, stk, cnt, true, &ch, &err); return finalize_flat<CLS_EVERY>(S, r, c, &ch); }
-  bool occluded(const Ray& r, float d) { return occluded_flat<COUNT, CLS_EVERY>(S, r, d, stk, cnt, true, &err); }
+  bool occluded(const Ray& r, float d, uint32_t = 0) { return occluded_flat<COUNT, CLS_EVERY>(S, r, d, stk, cnt, true, &err); }
   // on the host a wave is one lane: the packet code runs as a single-ray traversal
-  HitG closest_wave(const Ray& r, float tmax, bool valid) { HitG ch; Cand c = closest_flat<FAITHFUL, COUNT, CLS_EVERY, true>(S, r, tmax, stk, cnt, valid, &ch, &err); return valid ? finalize_flat<CLS_EVERY>(S, r, c, &ch) : hit_miss(); }
+  HitG closest_wave(const Ray& r, float tmax, bool valid, uint32_t = 0) { HitG ch; Cand c = closest_flat<FAITHFUL, COUNT, CLS_EVERY, true>(S, r, tmax, stk, cnt, valid, &ch, &err); return valid ? finalize_flat<CLS_EVERY>(S, r, c, &ch) : hit_miss(); }
   bool occluded_wave(const Ray& r, float d, bool valid) { return occluded_flat<COUNT, CLS_EVERY, true>(S, r, d, stk, cnt, valid, &err); }
 };
 struct HostGenericTier {
   static constexpr bool FULL = true;
+  static constexpr bool WARP = true;
   const DScene& S;
   const DLight* lights;
   int nlights;
   Cnt cnt;
   unsigned int err = 0;
-  HitG closest(const Ray& r, float tmax) { GPool pool; GCtx<true> g{S, cnt, err, pool}; HitG h = rayint_g<kGenericDepth>(g, S.recs[S.root_rec], r, tmax, (TexStack)0); err = g.err; return h; }
-  bool occluded(const Ray& r, float d) { GPool pool; GCtx<true> g{S, cnt, err, pool}; bool o = shadow_g<kGenericDepth>(g, S.recs[S.root_rec], r, d); err = g.err; return o; }
-  HitG closest_wave(const Ray& r, float tmax, bool valid) { return valid ? closest(r, tmax) : hit_miss(); }
+  HitG closest(const Ray& r, float tmax, uint32_t root) { GPool pool; GCtx<true> g{S, cnt, err, pool}; HitG h = rayint_g<kGenericDepth>(g, S.recs[root], r, tmax, (TexStack)0); err = g.err; return h; }
+  bool occluded(const Ray& r, float d, uint32_t root) { GPool pool; GCtx<true> g{S, cnt, err, pool}; bool o = shadow_g<kGenericDepth>(g, S.recs[root], r, d); err = g.err; return o; }
+  HitG closest(const Ray& r, float tmax) { return closest(r, tmax, S.root_rec); }
+  bool occluded(const Ray& r, float d) { return occluded(r, d, S.root_rec); }
+  HitG closest_wave(const Ray& r, float tmax, bool valid, uint32_t root) { return valid ? closest(r, tmax, root) : hit_miss(); }
   bool occluded_wave(const Ray& r, float d, bool valid) { return valid && occluded(r, d); }
 };
 
@@ -69,7 +73,7 @@ void* hostsim_commit(glome_sb* sb, int root, char* errbuf, int cap) {
   D.recs = F.recs.data(); D.spheres = F.spheres.data(); D.tris = F.tris.data(); D.trinorms = F.trinorms.data(); D.boxes = F.boxes.data();
   D.planes = F.planes.data(); D.discs = F.discs.data(); D.quadrics = F.quadrics.data(); D.xfms = F.xfms.data(); D.bihhdr = F.bihhdr.data();
   D.bihnodes = F.bihnodes.data(); D.meshhdr = F.meshhdr.data(); D.meshnodes = F.meshnodes.data(); D.mtris = F.mtris.data();
-  D.mtrimeta = F.mtrimeta.data(); D.mats = F.mats.data(); D.matkids = F.matkids.data(); D.entries = F.entries.data();
+  D.mtrimeta = F.mtrimeta.data(); D.mats = F.mats.data(); D.wlights = F.wlights.data(); D.matkids = F.matkids.data(); D.entries = F.entries.data();
   D.n_entries = F.tier == 0 ? (uint32_t)F.entries.size() : 0; D.root_rec = F.root_rec; D.tier = F.tier; D.n_mats = (uint32_t)sb_graph(sb).mats.size();
   return s;
 }

@@ -195,6 +195,31 @@ def test_trace_recursion_and_empty_stack(o):
     assert np.allclose(img[0, 0, :4], [0, 0, 0, 0]) and img[0, 0, 4] == pytest.approx(2)
 
 
+def test_warp_known_answers(o):
+    """Warp frame scene' lights' xfm (Shader.hs:157-175), hand-derived.  A wall at z = 0 textured with Warp, seen from
+    (0, 0, -5) looking along +z, inside `transform [translate (10, 0, 0)]` so that the hit's own ray (riray) is LOCAL:
+      * the frame is traced with the local ray (o = (-10, 0, -5) + ..., d = +z): a red ambient-only sphere at the LOCAL origin
+        (0, 0, 3) lies on it, 8 - 1 = 7 away; the world ray would miss it by 10 -- so a red pixel proves riray is local;
+      * the other scene is traced from xfm_ray M (Ray pos (vnorm dir)) with M = translate (0, 100, 0): origin (10, 100, 0),
+        direction +z, up to the frame's depth: a blue sphere at (10, 100, 4) is 3 away -> nearer than the frame (7): blue;
+        moved to (10, 100, 12) it is 11 away -> beyond the frame's depth: the frame's red stays.
+      * recurs: Warp's traces run with recurs - 1; at maxdepth 1 both are traceMiss: transparent."""
+    from glome_amd import api
+    red = o.material_surface([1, 0, 0], 1, 1.0, 0, 0, 0)
+    blue = o.material_surface([0, 0, 1], 1, 1.0, 0, 0, 0)
+    frame = o.tex(o.sphere([0, 0, 3], 1), red)                     # local coordinates of the wall
+    for zs, want in ((4.0, [0, 0, 1, 1]), (12.0, [1, 0, 0, 1])):
+        other = o.tex(o.sphere([10, 100, zs], 1), blue)
+        warp = o.material_warp(frame, other, [], api.translate((0, 100, 0)))
+        wall = o.transform(o.tex(o.plane([0, 0, 0], [0, 0, -1]), warp), [api.translate((10, 0, 0))])  # (a plane: an axis-parallel ray misses a Box, Q1)
+        o.set_root(wall)
+        o.set_camera_vectors([10, 0, -5], [0, 0, 1], [0, 0, 0], [0, 0, 0])
+        img, _, c = o.render(1, 1, maxdepth=2, want_packed=False)
+        assert np.allclose(img[0, 0, :4], want) and img[0, 0, 4] == pytest.approx(5) and c["rays_secondary"] == 2, (zs, img[0, 0], c)
+        img, _, c = o.render(1, 1, maxdepth=1, want_packed=False)
+        assert np.allclose(img[0, 0, :4], [0, 0, 0, 0]) and c["rays_secondary"] == 0
+
+
 # ------------------------------------------------------------------ solid texture functions (GlomeVec Texture.hs)
 def _weight(fn, params, pts):
     import ctypes as C

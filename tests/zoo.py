@@ -219,3 +219,28 @@ def mirror_terrain(N=24):
 
 
 ALL["mirror_terrain"] = mirror_terrain
+
+
+def portal():
+    """The portal of TestScene.hs:152-181: a door frame (a Difference of boxes) and, filling it, a box textured with
+    `Warp frame scene lights xfm` (Shader.hs:47-50, 157-175) -- a hit traces the frame through the hit's own local ray
+    (the portal stands inside a `transform`), then the scene itself through the warped ray (rotated to look down from
+    above), and shows the nearer.  The scene looked into is the scene the portal stands in, so views nest until `recurs`
+    runs out."""
+    sd = SceneDesc()
+    m = scenes.materials(sd)
+    w, h, th, dl = 2.0, 5.0, 1.0 / 3.0, 1e-4
+    frame = sd.tag(sd.tex(sd.difference(sd.box((-w, 0, -th), (w, h, th)), sd.box((th - w, th, -(th + dl)), (w - th, h - th, th + dl))), scenes.matte(sd, (0.4, 0.4, 0.8))), "door frame")
+    surface = sd.box((-w, 0, -dl), (w, h - dl, dl))
+    xfm = api.compose([api.rotate((1, 0, 0), api.deg(-85)), api.translate((8, 40, -4))])  # TestScene.hs:167-169
+    warp = sd.material_warp(frame, None, scenes.LIGHTS, xfm)
+    door = sd.transform(sd.group([frame, sd.tex(surface, warp)]), [api.rotate((0, 1, 0), api.deg(8)), api.translate((-3, 0.5, -5))])  # TestScene.hs:193-194
+    pl = sd.tex(sd.plane((0, 0, 0), (0, 1, 0)), scenes.matte(sd, (0, 0.8, 0.3)))
+    items = [door,
+             sd.tex(sd.sphere((2.5, 1.0, 0.5), 1.0), m["shiny_red"]),
+             sd.tex(sd.sphere((-1.0, 0.7, 2.5), 0.7), m["mirror"]),
+             sd.tex(sd.box((4, 0, -4), (5.5, 2.5, -2.5)), m["shiny_white"])]
+    return _finish(sd, sd.group([pl, sd.bih(items)]))
+
+
+ALL["portal"] = portal
