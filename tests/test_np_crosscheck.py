@@ -124,3 +124,72 @@ def test_colour_pixel_helpers(built):
     for size in (1, 64, 65, 66, 130, 720, 1919):
         k = L.glo_chunk(C.c_int(size), C.c_int(65), buf.ctypes.data_as(O.c_ip), C.c_int(200))
         assert [(int(buf[2 * i]), int(buf[2 * i + 1])) for i in range(k)] == NP.chunk(size, 65)
+
+
+# ------------------------------------------------------------------ composites and whole frames (oracle/np_scene.py)
+def _frames(sd, w, h, maxdepth):
+    """The same scene through the C++ oracle and through the independent Python restatement, same fp32-rounded camera."""
+    from helpers import oracle_for, product_camera_lights
+    from oracle import np_scene as NS
+    o, om, _ = oracle_for(sd)
+    ref, _, rc = o.render(w, h, maxdepth=maxdepth, want_packed=False)
+    sc, nm = NS.load(sd)
+    cam, _ = product_camera_lights(sd)
+    sc.set_camera_vectors([float(x) for x in cam.pos], [float(x) for x in cam.fwd], [float(x) for x in cam.up], [float(x) for x in cam.right])
+    got = np.array(sc.render(w, h, maxdepth))
+    return ref, rc, got, sc
+
+
+@pytest.mark.parametrize("name,w,h,md", [("S1", 48, 32, 1), ("S3small", 40, 24, 1), ("S3mesh_small", 40, 24, 1), ("S4", 48, 27, 3), ("materials", 40, 30, 3)])
+def test_whole_frames_of_two_independent_restatements_agree(built, name, w, h, md):
+    """BIH builder + rayint_bih + shadow_bih (S1, S3small), Mesh builder + rayint_mesh (S3mesh_small), Instance / Difference /
+    Intersection / get_metainfo and the trace / mpreshade / mpostshade recursion with Reflect (S4), Refract / Blend /
+    AdditiveLayers (materials): the C++ oracle and oracle/np_scene.py -- written separately from the Haskell text -- give the
+    same frame to rounding, pixel for pixel, and trace the same number of rays."""
+    import zoo
+    from glome_amd import scenes
+    mk = {"S1": lambda: scenes.s1(nlights=2), "S3small": lambda: scenes.s3(12), "S3mesh_small": lambda: scenes.s3(12, as_mesh=True), "S4": scenes.s4,
+          "materials": zoo.materials}[name]
+    ref, rc, got, sc = _frames(mk(), w, h, md)
+    assert got.shape == ref.shape
+    assert np.array_equal(got[..., 4] < 1e6, ref[..., 4] < 1e6)          # the same pixels hit
+    assert np.allclose(got[..., 4], ref[..., 4], rtol=1e-11, atol=1e-11)  # at the same depth
+    assert np.allclose(got[..., :4], ref[..., :4], rtol=1e-10, atol=1e-12), float(np.abs(got[..., :4] - ref[..., :4]).max())
+    assert sc.rays == [rc["rays_primary"], rc["rays_shadow"], rc["rays_secondary"]]
+
+
+def test_bih_trees_of_two_independent_builders_are_the_same(built):
+    """build_rec (Bih.hs:211-285) twice: the oracle's tree (through the product's host builder, which test_host_builder pins
+    to the oracle's) against np_scene's, node for node -- split planes, axes, leaf contents in order."""
+    from glome_amd import api, scenes
+    from oracle import np_scene as NS
+    import zoo
+    for sd in (scenes.s1(nlights=1), scenes.s3(10), zoo.soup(150, 3, floor=False)):
+        sc, nm = NS.load(sd)
+        b = api.Builder()
+        pm, _ = sd.replay(b)
+        # the scene's bih node: the last `bih` op
+        nid, bih_sd = 0, None
+        for kind, opname, args in sd.ops:
+            if kind == "N": nid += args[0].shape[0]
+            elif kind == "n":
+                if opname == "bih": bih_sd = nid
+                nid += 1
+        ls, rs, ax, nl, lp = b.bih_dump(pm[bih_sd])
+        tree = sc.nodes[nm[bih_sd]].root
+        # preorder walk of np_scene's tree in the dump's order
+        inv = {pm[i]: i for i in range(len(pm))}
+        k = [0]; off = [0]
+        def walk(n):
+            i = k[0]; k[0] += 1
+            if n[0] == "leaf":
+                assert ax[i] == -1 and nl[i] == len(n[1]), (i, n[1])
+                items = [inv[int(x)] for x in lp[off[0]:off[0] + nl[i]]]
+                assert items == [sc_uid_to_sd[s.uid] for s in n[1]]
+                off[0] += nl[i]
+            else:
+                assert ax[i] == n[3] and ls[i] == n[1] and rs[i] == n[2], (i, ax[i], n[3], ls[i], n[1])
+                walk(n[4]); walk(n[5])
+        sc_uid_to_sd = {nm[i]: i for i in range(len(nm))}
+        walk(tree)
+        assert k[0] == len(ax)
