@@ -124,7 +124,9 @@ def main():
         if args.mode != 0 or args.product != "packed":
             args.group = 1
         elif world == 1:
-            args.group = max(1, min(4, args.steps // 24))
+            # (tools/short_run_sweep.sh, profiles/r02_short_run_sweep.log: a 20-step run takes 0.206 ms per step with four frames per
+            # launch against 0.253 with one -- a launch cannot be shorter than its slowest work items, whatever it carries)
+            args.group = 4 if args.steps >= 8 else 1
         elif world == 2:
             args.group = 1 if args.steps < 8 else (4 if args.steps < 64 else 8)
         elif world <= 4:

@@ -1,29 +1,35 @@
 #!/bin/bash
-# The measurement set committed under profiles/ at the end of a round: every configuration, the default bench line, the
-# rocprofv3 kernel stats of the same command, the PMC passes, the multi-GPU rehearsal.  Run on the GPU box.
+# The measurement set committed under profiles/ at the end of a round.  Run on the GPU box:  tools/final_measure.sh r02_d
 tag=${1:-final}
 out=gpurun_out/$tag
-mkdir -p $out gpurun_out/configs
-bash tools/run_configs.sh > $out/configs.log 2>&1
-cp gpurun_out/configs/*.json $out/ 2>/dev/null
-timeout -k 10 300 python bench.py > $out/bench_S3.json 2> $out/bench_S3.err || exit 1
-tools/pmc_pass.sh $out/pmc "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVES" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum" "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES" || exit 1
-python tools/pmc_summary.py $out/pmc > $out/pmc_summary.json
-GPU_MAX_HW_QUEUES=8 timeout -k 10 600 python tools/shard_timing.py > $out/shard_timing.log 2>&1
-GPU_MAX_HW_QUEUES=8 WORK_TILES=64,64 timeout -k 10 600 python tools/shard_balance.py > $out/shard_balance.log 2>&1
-timeout -k 10 300 python tools/bih_build_timing.py > $out/bih_build.log 2>&1
 root=$(pwd)
+mkdir -p $out
+# 1. counter passes behind the roofline, for the launch shapes bench.py times alone
+for spec in "S3 0 8" "S5 0 8" "S4 0 8" "S3 1 1"; do set -- $spec
+  tools/pmc_roofline.sh $tag $1 $2 $3 > $out/pmc_$1_mode$2.log 2>&1 || echo "pmc $1 $2 failed"
+  cp gpurun_out/${tag}_pmc_$1_mode$2.json profiles/r02_pmc_$1_mode$2.json 2>/dev/null
+  cp gpurun_out/${tag}_pmc_$1_mode$2.json $out/ 2>/dev/null
+done
+# 2. the bench line (default invocation) and the driver's invocation
+timeout -k 10 300 python bench.py > $out/bench_S3.json 2> $out/bench_S3.err || echo "bench failed"
+timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_S3_driver.json 2>> $out/bench_S3.err
+# 3. rocprofv3 kernel stats of the same command
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $root/$out/prof --output-format csv -- python3 $root/bench.py --steps 200 --warmup 20 --no-cpu > $root/$out/prof.log 2>&1
 cd $root
-cp $(find $out/prof -name "*kernel_stats.csv" | head -1) $out/bench_S3_kernel_stats.csv
-tail -10 $out/configs.log | cut -c1-200
-head -3 $out/bench_S3_kernel_stats.csv
+cp $(find $out/prof -name "*kernel_stats.csv" | head -1) $out/bench_S3_kernel_stats.csv 2>/dev/null
+rm -rf $out/prof
+# 4. every configuration
+bash tools/run_configs.sh > $out/configs.log 2>&1
+mkdir -p $out/configs; cp gpurun_out/configs/*.json $out/configs/
+# 5. the multi-GPU rehearsal on one GPU
+GPU_MAX_HW_QUEUES=8 timeout -k 10 600 python tools/shard_timing.py > $out/shard_timing.log 2>&1
+tail -12 $out/configs.log | cut -c1-330
+head -4 $out/bench_S3_kernel_stats.csv
 python - <<PY
 import json
-j=json.loads(open("$out/bench_S3.json").read().strip().splitlines()[-1])
-print("bench", j["ms_per_step"], j["value"], j["fps"], j["roofline"]["kernel_ms_avg"], j["roofline"]["launches_timed"], j["roofline"]["frac"], j["cpu_baseline"]["value"], j["cpu_baseline"]["gpu_over_cpu"], j["cpu_baseline"]["value_1_thread"])
-d=json.load(open("$out/pmc_summary.json"))
-for k,v in d.items(): print(k[:70], {c:round(x["mean"],1) for c,x in v.items()})
+j=json.loads(open("$out/bench_S3.json").read().strip().splitlines()[-1]); r=j["roofline"]
+print("bench", j["ms_per_step"], j["value"], r["bound"], r["frac"], {k:v["frac"] for k,v in (r["ceilings"] or {}).items()}, r["kernel_ms"], j["latency"], j["cpu_baseline"]["value"], j["cpu_baseline"]["gpu_over_cpu"])
+j=json.loads(open("$out/bench_S3_driver.json").read().strip().splitlines()[-1]); print("driver-style", j["ms_per_step"], j["value"])
 PY
 grep "\"world\": [1248], \"launches_in_flight\": 4" $out/shard_timing.log
