@@ -10,7 +10,8 @@
 //                of a packet are fixed for the whole walk, so the walk is instantiated per octant: no direction test, no
 //                operand swap); s_and_b64 sets SCC, so a vote needs no compare; the stack pointer lives in m0 for the whole
 //                walk (v_writelane / v_readlane take it from there) and the lane's LDS address is kept incrementally.
-//   triangle     ~8 scalar: two scalar loads (32 + 16 bytes), the Moeller-Trumbore arithmetic with the scalar registers as
+//   triangle     ~8 scalar: two scalar loads (32 + 16 bytes; a leaf's triangles are fetched two at a time, one memory
+//                round trip for both), the Moeller-Trumbore arithmetic with the scalar registers as
 //                direct operands (the same IEEE operations in the same order as the compiler's tri_test, so results are
 //                bit-identical to every other kernel instance), and the four rejection tests as a chain of v_cmpx, which
 //                narrows EXEC instead of building masks: the survivors' updates are plain moves.
@@ -24,7 +25,7 @@
 // best, children only shrink it, a pop clips with best_t, an accepted hit sets both), so a triangle hit within [.., far]
 // always replaces the running best: `!(best_t < t)` (nearest: ties -> later item, Solid.hs:37-44) needs no test.
 //
-// Scalar registers s[60:87], vcc, scc and m0 (saved and restored) are scratch, named in the clobber list.
+// Scalar registers s[60:95], vcc, scc and m0 (saved and restored) are scratch, named in the clobber list.
 #pragma once
 #if defined(__HIPCC__)
 
@@ -76,42 +77,39 @@ enum : int { PKW_DONE = 0, PKW_PUSH_OVERFLOW = 1, PKW_BIG_LEAF = 2, PKW_POP_OVER
 #define GLOME_PKW_AXIS_FWD(TAG, O, R) GLOME_PKW_AXIS(TAG, O, R, "s60", "s61", "s62", "s63")
 #define GLOME_PKW_AXIS_BWD(TAG, O, R) GLOME_PKW_AXIS(TAG, O, R, "s61", "s60", "s63", "s62")
 
-// the triangle at byte offset s86 of the pool: s[64:67] = (p1, .), s[68:71] = (e1, .), s[72:75] = (e2, .) (rt_types.h).
+// One triangle test.  P1 / E1 / E2: the scalar registers that hold the record's (p1, .) (e1, .) (e2, .) words (rt_types.h).
 // The arithmetic is tri_test's (Triangle.hs:45-73) operation for operation as hipcc contracts it under -ffp-contract=on:
 // cross(a, b).y = fma(a.z, b.x, -(a.x * b.z)) and cyclic; dot(a, b) = fma(a.z, b.z, fma(a.x, b.x, a.y * b.y)).
-#define GLOME_PKW_TRI_ARITH                                                                           \
-  "  s_load_dwordx8 s[64:71], %[tris], s86\n"                                                         \
-  "  s_load_dwordx4 s[72:75], %[tris], s86 offset:0x20\n"                                             \
-  "  s_mov_b64 exec, %[am]\n"               /* only the lanes whose interval reaches this leaf */     \
-  "  s_waitcnt lgkmcnt(0)\n"                                                                          \
-  "  v_subrev_f32 %[Dx], s64, %[ox]\n"      /* D = o - p1 */                                          \
-  "  v_subrev_f32 %[Dy], s65, %[oy]\n"                                                                \
-  "  v_subrev_f32 %[Dz], s66, %[oz]\n"                                                                \
-  "  v_mul_f32_e64 %[s2y], -%[Dx], s70\n"   /* s2 = D x e1 */                                         \
-  "  v_mul_f32_e64 %[s2x], -%[Dz], s69\n"                                                             \
-  "  v_mul_f32_e64 %[s2z], -%[Dy], s68\n"                                                             \
-  "  v_fma_f32 %[s2y], %[Dz], s68, %[s2y]\n"                                                          \
-  "  v_fma_f32 %[s2x], %[Dy], s70, %[s2x]\n"                                                          \
-  "  v_fma_f32 %[s2z], %[Dx], s69, %[s2z]\n"                                                          \
-  "  v_mul_f32_e64 %[s1y], -%[dx], s74\n"   /* s1 = dir x e2 */                                       \
-  "  v_mul_f32_e64 %[s1x], -%[dz], s73\n"                                                             \
-  "  v_mul_f32_e64 %[s1z], -%[dy], s72\n"                                                             \
-  "  v_fma_f32 %[s1y], %[dz], s72, %[s1y]\n"                                                          \
-  "  v_fma_f32 %[s1x], %[dy], s74, %[s1x]\n"                                                          \
-  "  v_fma_f32 %[s1z], %[dx], s73, %[s1z]\n"                                                          \
-  "  v_mul_f32 %[div], s69, %[s1y]\n"       /* divisor = s1 . e1 */                                   \
-  "  v_fmac_f32 %[div], s68, %[s1x]\n"                                                                \
-  "  v_fmac_f32 %[div], s70, %[s1z]\n"                                                                \
+// Entered with EXEC = the lanes whose interval reaches the leaf; leaves EXEC = the lanes that hit.
+#define GLOME_PKW_TRI_TEST(P1X, P1Y, P1Z, E1X, E1Y, E1Z, E2X, E2Y, E2Z)                               \
+  "  v_subrev_f32 %[Dx], " P1X ", %[ox]\n"  /* D = o - p1 */                                          \
+  "  v_subrev_f32 %[Dy], " P1Y ", %[oy]\n"                                                            \
+  "  v_subrev_f32 %[Dz], " P1Z ", %[oz]\n"                                                            \
+  "  v_mul_f32_e64 %[s2y], -%[Dx], " E1Z "\n"  /* s2 = D x e1 */                                      \
+  "  v_mul_f32_e64 %[s2x], -%[Dz], " E1Y "\n"                                                         \
+  "  v_mul_f32_e64 %[s2z], -%[Dy], " E1X "\n"                                                         \
+  "  v_fma_f32 %[s2y], %[Dz], " E1X ", %[s2y]\n"                                                      \
+  "  v_fma_f32 %[s2x], %[Dy], " E1Z ", %[s2x]\n"                                                      \
+  "  v_fma_f32 %[s2z], %[Dx], " E1Y ", %[s2z]\n"                                                      \
+  "  v_mul_f32_e64 %[s1y], -%[dx], " E2Z "\n"  /* s1 = dir x e2 */                                    \
+  "  v_mul_f32_e64 %[s1x], -%[dz], " E2Y "\n"                                                         \
+  "  v_mul_f32_e64 %[s1z], -%[dy], " E2X "\n"                                                         \
+  "  v_fma_f32 %[s1y], %[dz], " E2X ", %[s1y]\n"                                                      \
+  "  v_fma_f32 %[s1x], %[dy], " E2Z ", %[s1x]\n"                                                      \
+  "  v_fma_f32 %[s1z], %[dx], " E2Y ", %[s1z]\n"                                                      \
+  "  v_mul_f32 %[div], " E1Y ", %[s1y]\n"   /* divisor = s1 . e1 */                                   \
+  "  v_fmac_f32 %[div], " E1X ", %[s1x]\n"                                                            \
+  "  v_fmac_f32 %[div], " E1Z ", %[s1z]\n"                                                            \
   "  v_mul_f32 %[b2], %[dy], %[s2y]\n"      /* dir . s2 */                                            \
   "  v_mul_f32 %[b1], %[Dy], %[s1y]\n"      /* D . s1 */                                              \
-  "  v_mul_f32 %[t], s73, %[s2y]\n"         /* e2 . s2 */                                             \
+  "  v_mul_f32 %[t], " E2Y ", %[s2y]\n"     /* e2 . s2 */                                             \
   "  v_rcp_f32 %[inv], %[div]\n"                                                                      \
   "  v_fmac_f32 %[b2], %[dx], %[s2x]\n"                                                               \
   "  v_fmac_f32 %[b1], %[Dx], %[s1x]\n"                                                               \
-  "  v_fmac_f32 %[t], s72, %[s2x]\n"                                                                  \
+  "  v_fmac_f32 %[t], " E2X ", %[s2x]\n"                                                              \
   "  v_fmac_f32 %[b2], %[dz], %[s2z]\n"                                                               \
   "  v_fmac_f32 %[b1], %[Dz], %[s1z]\n"                                                               \
-  "  v_fmac_f32 %[t], s74, %[s2z]\n"                                                                  \
+  "  v_fmac_f32 %[t], " E2Z ", %[s2z]\n"                                                              \
   "  v_mul_f32 %[b2], %[b2], %[inv]\n"                                                                \
   "  v_mul_f32 %[b1], %[b1], %[inv]\n"                                                                \
   "  v_mul_f32 %[t], %[t], %[inv]\n"                                                                  \
@@ -123,13 +121,16 @@ enum : int { PKW_DONE = 0, PKW_PUSH_OVERFLOW = 1, PKW_BIG_LEAF = 2, PKW_POP_OVER
   "  v_cmpx_ngt_f32 vcc, 0, %[s2x]\n"                                                                 \
   "  v_cmpx_nlt_f32 vcc, 1.0, %[s2y]\n"                                                               \
   "  v_cmpx_ngt_f32 vcc, %[t], %[far]\n"    /* EXEC = the lanes that hit */
+// the triangle pool at byte offset s86: record k in s[64:75], record k + 1 (when the leaf has one) in s[88:95] + s[76:79]
+#define GLOME_PKW_TRI_A GLOME_PKW_TRI_TEST("s64", "s65", "s66", "s68", "s69", "s70", "s72", "s73", "s74")
+#define GLOME_PKW_TRI_B GLOME_PKW_TRI_TEST("s88", "s89", "s90", "s92", "s93", "s94", "s76", "s77", "s78")
 
 // what the lanes that hit do (EXEC = those lanes), and what a popped entry's lane mask s[80:81] is filtered with (SCC = any left)
-#define GLOME_PKW_UPDATE_1                                                                            \
+#define GLOME_PKW_UPDATE_1(REC)                                                                       \
   "  v_mov_b32 %[best_t], %[t]\n"                                                                     \
   "  v_mov_b32 %[far], %[t]\n"              /* far = min(far, t) = t: the test just passed t <= far */ \
-  "  v_mov_b32 %[best_rec], s87\n"
-#define GLOME_PKW_UPDATE_2                                                                            \
+  "  v_mov_b32 %[best_rec], " REC "\n"
+#define GLOME_PKW_UPDATE_2(REC)                                                                       \
   "  s_or_b64 %[occ], %[occ], exec\n"                                                                 \
   "  s_andn2_b64 %[am], %[am], exec\n"      /* an occluded ray is finished; SCC = rays left in this walk's current entry */ \
   "  s_cbranch_scc0 L_leafdone_%=\n"
@@ -172,12 +173,29 @@ enum : int { PKW_DONE = 0, PKW_PUSH_OVERFLOW = 1, PKW_BIG_LEAF = 2, PKW_POP_OVER
       "  s_bfm_b32 s85, s85, 0\n"           /* `count` ones: shifted out one per triangle */                                    \
       "  s_add_u32 s86, s87, %[delta]\n"     /* first primitive */                                                              \
       "  s_mul_i32 s86, s86, 48\n"                                                                                              \
+      /* two triangles per memory round trip: scalar loads return out of order, so a wait is a wait for all of them --   */       \
+      /* the second record's loads go out with the first's                                                                */       \
       "L_tri_%=:\n"                                                                                                             \
-      GLOME_PKW_TRI_ARITH                                                                                                       \
-      GLOME_PKW_UPDATE_##M                                                                                                      \
-      "  s_add_u32 s86, s86, 48\n"                                                                                              \
+      "  s_load_dwordx8 s[64:71], %[tris], s86\n"                                                                               \
+      "  s_load_dwordx4 s[72:75], %[tris], s86 offset:0x20\n"                                                                   \
+      "  s_bitcmp1_b32 s85, 1\n"            /* a second triangle in this leaf? */                                               \
+      "  s_cbranch_scc0 L_one_%=\n"                                                                                             \
+      "  s_load_dwordx8 s[88:95], %[tris], s86 offset:0x30\n"                                                                   \
+      "  s_load_dwordx4 s[76:79], %[tris], s86 offset:0x50\n"                                                                   \
+      "L_one_%=:\n"                                                                                                             \
+      "  s_mov_b64 exec, %[am]\n"           /* only the lanes whose interval reaches this leaf */                               \
+      "  s_waitcnt lgkmcnt(0)\n"                                                                                                \
+      GLOME_PKW_TRI_A                                                                                                           \
+      GLOME_PKW_UPDATE_##M("s87")                                                                                               \
+      "  s_bitcmp1_b32 s85, 1\n"                                                                                                \
+      "  s_cbranch_scc0 L_leafdone_%=\n"    /* that was the leaf's last */                                                      \
       "  s_add_u32 s87, s87, 1\n"                                                                                               \
-      "  s_lshr_b32 s85, s85, 1\n"          /* SCC = triangles left */                                                          \
+      "  s_mov_b64 exec, %[am]\n"                                                                                               \
+      GLOME_PKW_TRI_B                                                                                                           \
+      GLOME_PKW_UPDATE_##M("s87")                                                                                               \
+      "  s_add_u32 s86, s86, 96\n"                                                                                              \
+      "  s_add_u32 s87, s87, 1\n"                                                                                               \
+      "  s_lshr_b32 s85, s85, 2\n"          /* SCC = triangles left */                                                          \
       "  s_cbranch_scc1 L_tri_%=\n"                                                                                             \
       "L_leafdone_%=:\n"                                                                                                        \
       "  s_mov_b64 exec, s[82:83]\n"                                                                                            \
@@ -221,7 +239,7 @@ enum : int { PKW_DONE = 0, PKW_PUSH_OVERFLOW = 1, PKW_BIG_LEAF = 2, PKW_POP_OVER
       : [nodes] "s"(nodes), [tris] "s"(tris), [delta] "s"(delta), [cap] "s"((uint32_t)CAP), [phase] "s"(phase), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z),         \
         [rx] "v"(rcp.x), [ry] "v"(rcp.y), [rz] "v"(rcp.z), [dx] "v"(d.x), [dy] "v"(d.y), [dz] "v"(d.z), [lds] "v"(lds_row), [row1] "n"(CAP * 256)                   \
       : "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", \
-        "s83", "s84", "s85", "s86", "s87", "vcc", "scc", "memory")
+        "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "vcc", "scc", "memory")
 
 // MODE 1 = closest hit with ordered early-out, MODE 2 = any hit.  XF / YF / ZF: the rays of the packet run towards +x / +y / +z.
 // CAP: entries of the LDS part of the stack (the far row lies CAP * 256 bytes after the near row).
