@@ -3,8 +3,7 @@ shape bench.py times alone -- one launch in flight, GROUP frames per launch -- i
 
   python tools/pmc_roofline.py PASSDIR SCENE MODE GROUP OUT.json
 
-Per counter: the mean over the dispatches of the dominant kernel (the kernel with the largest total duration; with the
-adaptive sampler the five pass kernels of a frame are summed per frame).  FETCH_SIZE / WRITE_SIZE stay in KiB as rocprofv3
+Per counter: the mean over the dispatches of the dominant kernel (the kernel with the largest total duration).  FETCH_SIZE / WRITE_SIZE stay in KiB as rocprofv3
 reports them (bench.py applies the gfx950 correction: FETCH_SIZE x 2, MI355X_MICROARCH.md HBM section).  clock_ghz =
 GRBM_GUI_ACTIVE / 8 XCDs / dispatch duration (same guide, DVFS paragraph), from the pass that carries GRBM_GUI_ACTIVE."""
 import collections
@@ -27,7 +26,7 @@ for f, r in rows:
         continue
     seen.add(key)
     dur[r["Kernel_Name"].split("(")[0]] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
-fam = "k_ss_pass" if mode != 0 else max((k for k in dur if "k_render" in k), key=lambda k: dur[k])
+fam = max((k for k in dur if ("k_ss_frame" in k if mode != 0 else "k_render" in k)), key=lambda k: dur[k])
 per_pass = collections.defaultdict(lambda: collections.defaultdict(list))  # file -> counter -> values per dispatch
 times = collections.defaultdict(dict)
 names = set()
@@ -39,7 +38,7 @@ for f, r in rows:
     per_pass[f][r["Counter_Name"]].append(float(r["Counter_Value"]))
     times[f][r["Dispatch_Id"]] = (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-6  # ms
 counters, kernel_ms, clock = {}, [], None
-per_unit = 5 if mode != 0 else 1  # dispatches that make one launch (the sampler's five passes)
+per_unit = 1  # dispatches that make one frame group (the adaptive sampler, too, is one launch per frame)
 for f, cs in per_pass.items():
     t = list(times[f].values())
     n_units = max(1, len(t) // per_unit)
