@@ -121,8 +121,11 @@ def main():
         # frames per launch (and per gather).  Deep batches pay a fill / drain of about one launch per run, so short runs get
         # shallower ones; the break-even points are measured (tools/short_run_groups.py, profiles/r01_l_short_run_groups.log):
         # at 8 ranks a 20-step run takes 0.091 ms per step with one frame per launch and 0.052 with four.
-        if args.mode != 0 or args.product != "packed":
+        if args.product != "packed":
             args.group = 1
+        elif args.mode != 0:
+            # the adaptive sampler: a batch of eight frames lets it work in large regions (fewer, fuller sample packets)
+            args.group = (8 if args.steps >= 16 else 1) if world == 1 else 1
         elif world == 1:
             # (tools/short_run_sweep.sh, profiles/r02_short_run_sweep.log: a 20-step run takes 0.206 ms per step with four frames per
             # launch against 0.253 with one -- a launch cannot be shorter than its slowest work items, whatever it carries)
@@ -189,10 +192,7 @@ def main():
     def lone_launches(nframes, reps):
         """ms per launch of `reps` launches carrying `nframes` frames of this rank's tiles each, never overlapped"""
         cams = (L.Camera * nframes)(*([cam] * nframes))
-        if args.mode != 0:  # the adaptive sampler renders one frame per call: float tuples, five pass kernels
-            buf = torch.zeros((H, W, 5), dtype=torch.float32, device=device)
-            call = lambda: ctx.lib.glome_render_dev(scene.h, C.byref(cam), la, len(lights), C.byref(sf.P_local), C.c_void_p(buf.data_ptr()), None, None)
-        elif world == 1:
+        if world == 1:
             buf = torch.zeros((nframes, H, W), dtype=torch.int32, device=device)
             call = lambda: ctx.lib.glome_render_packed_batch_dev(scene.h, cams, nframes, la, len(lights), C.byref(sf.P), C.c_void_p(buf.data_ptr()), H * W, None)
         else:
@@ -211,7 +211,7 @@ def main():
         n = ctx.lib.glome_ctx_timing_end(ctx.h, out.ctypes.data_as(L.c_fp), reps)
         return [float(x) for x in out[:n]]
 
-    G_lone = 8 if args.mode == 0 else 1
+    G_lone = 8
     ctx.lib.glome_ctx_set_grid_per_cu(ctx.h, 32)  # a launch on its own takes every wave slot its registers / LDS allow
     lone_ms = lone_launches(G_lone, 12)
     one_ms = lone_launches(1, 12) if G_lone != 1 else lone_ms
@@ -246,7 +246,7 @@ def main():
 
     # ---- per-ceiling fractions from the committed counter pass of this launch shape ----
     _, cus, _ = ctx.device_info()
-    kname = ("k_ss_pass_*" if args.mode != 0 else "k_render_flat") if info["tier"] == 0 else ("k_ss_pass_generic" if args.mode != 0 else "k_render_generic")
+    kname = ("k_ss_frame_flat" if args.mode != 0 else "k_render_flat") if info["tier"] == 0 else ("k_ss_frame_generic" if args.mode != 0 else "k_render_generic")
     roofline = {"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None, "kernel": kname, "kernel_ms": round(kernel_ms, 4),
                 "kernel_ms_all": [round(x, 4) for x in lone_ms], "launch_shape": f"1 launch in flight, {G_lone} frame(s) per launch, rank 0's tiles", "ceilings": None,
                 "pmc_source": None, "model": model}

@@ -18,7 +18,10 @@
 //   pop          ~7 scalar.
 //
 // What it declines goes back to the C++ loop for one step (status codes below): pushes and pops beyond the LDS part of the
-// stack (global overflow columns) and leaves of more than six items.  MODE 1 (ordered early-out closest hit) and MODE 2
+// stack (global overflow columns) and leaves of more than six items.  The wave-uniform part of the stack (reference and lane
+// mask of entry k in lane k of three vector registers) never leaves the asm block in registers: before a C++ step it is
+// written to the wave's dump block in global memory, on re-entry (sp > 0) read back -- a register whose inactive lanes carry
+// data must not be visible to the compiler, which may spill or copy it under a partial EXEC mask.  MODE 1 (ordered early-out closest hit) and MODE 2
 // (any hit) only; the faithful / counting variants stay in C++.
 //
 // Invariant used (MODE 1): far <= best_t on the current path at all times (the root interval is clipped with the running
@@ -146,6 +149,14 @@ enum : int { PKW_DONE = 0, PKW_PUSH_OVERFLOW = 1, PKW_BIG_LEAF = 2, PKW_POP_OVER
       "  s_mov_b32 s84, m0\n"               /* m0 holds the stack pointer for the whole walk (restored at the end) */           \
       "  s_mov_b32 m0, %[sp]\n"                                                                                                 \
       "  s_mov_b64 s[82:83], exec\n"                                                                                            \
+      "  s_cmp_eq_u32 %[sp], 0\n"           /* re-entered after a C++ step: the entries come back from the dump block */         \
+      "  s_cbranch_scc1 L_fresh_%=\n"                                                                                           \
+      "  s_waitcnt vmcnt(0)\n"                                                                                                  \
+      "  global_load_dword %[ur], %[dump], off\n"                                                                               \
+      "  global_load_dword %[ulo], %[dump], off offset:256\n"                                                                   \
+      "  global_load_dword %[uhi], %[dump], off offset:512\n"                                                                   \
+      "  s_waitcnt vmcnt(0)\n"                                                                                                  \
+      "L_fresh_%=:\n"                                                                                                           \
       "  s_lshl_b32 s80, %[sp], 8\n"                                                                                            \
       "  v_add_u32 %[av], s80, %[lds]\n"     /* this lane's slot of the next free entry */                                      \
       "  s_cmp_lg_u32 %[phase], 0\n"                                                                                            \
@@ -223,21 +234,27 @@ enum : int { PKW_DONE = 0, PKW_PUSH_OVERFLOW = 1, PKW_BIG_LEAF = 2, PKW_POP_OVER
       "  s_branch L_end_%=\n"                                                                                                   \
       "L_slow_%=:\n"                          /* a push that does not fit the LDS part: the C++ step takes this node */         \
       "  s_mov_b32 %[status], 1\n"                                                                                              \
-      "  s_branch L_end_%=\n"                                                                                                   \
+      "  s_branch L_dump_%=\n"                                                                                                  \
       "L_big_%=:\n"                           /* a leaf of more than six items */                                               \
       "  s_mov_b32 %[status], 2\n"                                                                                              \
-      "  s_branch L_end_%=\n"                                                                                                   \
+      "  s_branch L_dump_%=\n"                                                                                                  \
       "L_popslow_%=:\n"                       /* the top entry lives in the overflow columns */                                 \
       "  s_mov_b32 %[status], 3\n"                                                                                              \
+      "L_dump_%=:\n"                          /* a C++ step follows: the entries (lane k = entry k) leave the registers */       \
+      "  s_mov_b64 exec, s[82:83]\n"                                                                                            \
+      "  global_store_dword %[dump], %[ur], off\n"                                                                              \
+      "  global_store_dword %[dump], %[ulo], off offset:256\n"                                                                  \
+      "  global_store_dword %[dump], %[uhi], off offset:512\n"                                                                  \
+      "  s_waitcnt vmcnt(0)\n"                                                                                                  \
       "L_end_%=:\n"                                                                                                             \
       "  s_mov_b32 %[sp], m0\n"                                                                                                 \
       "  s_mov_b32 m0, s84\n"                                                                                                   \
-      : [ref] "+s"(ref), [am] "+s"(am), [sp] "+s"(sp), [near] "+v"(nearv), [far] "+v"(farv), [best_t] "+v"(best_t), [best_rec] "+v"(best_rec), [ur] "+v"(ur),     \
-        [ulo] "+v"(ulo), [uhi] "+v"(uhi), [occ] "+s"(occm), [status] "=s"(status), [av] "=&v"(av), [t1] "=&v"(t1), [t2] "=&v"(t2), [Dx] "=&v"(Dx), [Dy] "=&v"(Dy),  \
+      : [ref] "+s"(ref), [am] "+s"(am), [sp] "+s"(sp), [near] "+v"(nearv), [far] "+v"(farv), [best_t] "+v"(best_t), [best_rec] "+v"(best_rec), [ur] "=&v"(ur),    \
+        [ulo] "=&v"(ulo), [uhi] "=&v"(uhi), [occ] "+s"(occm), [status] "=s"(status), [av] "=&v"(av), [t1] "=&v"(t1), [t2] "=&v"(t2), [Dx] "=&v"(Dx), [Dy] "=&v"(Dy),  \
         [Dz] "=&v"(Dz), [s2x] "=&v"(s2x), [s2y] "=&v"(s2y), [s2z] "=&v"(s2z), [s1x] "=&v"(s1x), [s1y] "=&v"(s1y), [s1z] "=&v"(s1z), [div] "=&v"(dv), [inv] "=&v"(inv),   \
         [b1] "=&v"(b1), [b2] "=&v"(b2), [t] "=&v"(tt)                                                                                                                 \
       : [nodes] "s"(nodes), [tris] "s"(tris), [delta] "s"(delta), [cap] "s"((uint32_t)CAP), [phase] "s"(phase), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z),         \
-        [rx] "v"(rcp.x), [ry] "v"(rcp.y), [rz] "v"(rcp.z), [dx] "v"(d.x), [dy] "v"(d.y), [dz] "v"(d.z), [lds] "v"(lds_row), [row1] "n"(CAP * 256)                   \
+        [rx] "v"(rcp.x), [ry] "v"(rcp.y), [rz] "v"(rcp.z), [dx] "v"(d.x), [dy] "v"(d.y), [dz] "v"(d.z), [lds] "v"(lds_row), [row1] "n"(CAP * 256), [dump] "v"(dump)                   \
       : "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", \
         "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "vcc", "scc", "memory")
 
@@ -246,10 +263,10 @@ enum : int { PKW_DONE = 0, PKW_PUSH_OVERFLOW = 1, PKW_BIG_LEAF = 2, PKW_POP_OVER
 // phase 0: go on from `ref` with the lanes `am`; phase 1: pop first.  Returns a PKW_* status.
 template <int MODE, bool XF, bool YF, bool ZF, int CAP>
 __device__ __forceinline__ int bih_walk_asm(const F4* nodes, const F4* tris, uint32_t delta, int phase, uint32_t& ref, LaneMask& am, int& sp, float& nearv, float& farv,
-                                            float& best_t, uint32_t& best_rec, LaneMask& occm, V3 o, V3 rcp, V3 d, uint32_t lds_row, uint32_t& ur, uint32_t& ulo, uint32_t& uhi) {
+                                            float& best_t, uint32_t& best_rec, LaneMask& occm, V3 o, V3 rcp, V3 d, uint32_t lds_row, uint32_t* dump) {
   static_assert(MODE == 1 || MODE == 2, "the hand-written walk covers the production traversals only");
   int status;
-  uint32_t av;
+  uint32_t av, ur, ulo, uhi;  // ur / ulo / uhi: the wave-uniform part of the stack, entry k in lane k -- alive inside the asm block only
   float t1, t2, Dx, Dy, Dz, s2x, s2y, s2z, s1x, s1y, s1z, dv, inv, b1, b2, tt;
   // wave-uniform by construction; readfirstlane pins them to scalar registers where the compiler cannot see that
   ref = uni(ref); am = uni(am); sp = (int)uni((uint32_t)sp); occm = uni(occm); phase = (int)uni((uint32_t)phase); delta = uni(delta);

@@ -98,7 +98,7 @@ struct GenericTier {
 };
 
 // LDS carve per wave: three stack rows of cap * 64 words (reference, near, far -- the per-lane traversal's entries), or
-// two (near, far) in kernels whose lanes never push on their own: the packet walk keeps its references in registers
+// two (near, far) in kernels that only ever run the hand-written packet walk, which keeps its references in registers
 template <bool TWO_ROWS = false>
 __device__ __forceinline__ LaneStack lane_stack(uint32_t* lds, int cap, uint32_t* ovf_base, int ovf_cap) {
   int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -108,10 +108,12 @@ __device__ __forceinline__ LaneStack lane_stack(uint32_t* lds, int cap, uint32_t
   s.nearv = (float*)(base + (TWO_ROWS ? 0 : cap * 64)) + lane;
   s.farv = s.nearv + cap * 64;
   s.cap = cap;
-  s.ur = 0; s.ulo = 0; s.uhi = 0;
-  // overflow: one [entry*3][64] block per wave slot (blockIdx.x * waves_per_block + wave)
-  s.ovf_cap = ovf_base ? ovf_cap : 0;
-  s.ovf = ovf_base ? ovf_base + ((size_t)(blockIdx.x * (blockDim.x >> 6) + wave) * ovf_cap * 3) * 64 + lane : nullptr;
+  s.has_ref_row = !TWO_ROWS;
+  // overflow: one [entry * 3][64] block per wave slot (blockIdx.x * waves_per_block + wave); the block after the last
+  // entry is the dump block
+  s.ovf_cap = ovf_cap;
+  s.ovf = ovf_base + ((size_t)(blockIdx.x * (blockDim.x >> 6) + wave) * (ovf_cap + 1) * 3) * 64 + lane;
+  s.dump = s.ovf + (size_t)ovf_cap * 3 * 64;
   return s;
 }
 static size_t flat_lds_bytes(int cap, bool two_rows = false) { return (size_t)cap * 64 * (two_rows ? 8 : 12); }
@@ -259,9 +261,9 @@ __global__ void __launch_bounds__(64) k_render_generic(DRenderArgs A) {
 // renderTileSubsample (Glome.hs:226-323).  The reference runs five passes over each 65x65 tile; a pass looks at
 // neighbour contrast (`decide`, Glome.hs:213-219) and either averages or traces a fresh sample.  Here persistent waves
 // pull regions of a tile's candidate lattice (ss_block_pixel: blocks of 64 candidates of a pass in a compact pixel area,
-// one per lane; 1 or 2x2 blocks per region); a lane takes the contrast test and writes the average when that settles it;
-// the candidates that need a sample are compacted over the region (ballot + LDS list) and traced 64 at a time --
-// neighbours in the image, so the rays are walked as a packet.  A region in which nobody needs a sample traces nothing.
+// one per lane; a region = a rectangle of blocks, ss_region_shape); a lane takes the contrast test and writes the average when
+// that settles it; the candidates that need a sample are compacted over the region (ballot + LDS ring) and traced 64 at a
+// time -- neighbours in the image, so the rays are walked as a packet.  A region in which nobody needs a sample traces nothing.
 // The working buffer `v` is a dense per-tile array in global memory (tile order, row major inside a tile), so all
 // neighbour reads stay inside the tile like the reference's getc (Glome.hs:233-235); `v2` is the output.  A pass reads
 // what the previous passes wrote anywhere in the tile: ss_frame_loop below orders the passes per tile.
@@ -271,8 +273,8 @@ __device__ __forceinline__ void out5_store(float* v, size_t i, const TC& c) { fl
 __device__ __forceinline__ size_t ss_out_index(const DRenderArgs& A, const DTile& t, int dx, int dy) {
   return A.dense ? (size_t)t.pix_base + (size_t)dy * t.w + dx : (size_t)(t.y + dy) * A.width + (t.x + dx);
 }
-__device__ __forceinline__ void ss_write_out(const DRenderArgs& A, const DTile& t, int dx, int dy, const TC& c) {
-  size_t o = ss_out_index(A, t, dx, dy);
+__device__ __forceinline__ void ss_write_out(const DRenderArgs& A, size_t frame_off, const DTile& t, int dx, int dy, const TC& c) {
+  size_t o = ss_out_index(A, t, dx, dy) + frame_off;
   if (A.out5) out5_store(A.out5, o, c);
   if (A.packed) A.packed[o] = rgbf(c.r * c.a, c.g * c.a, c.b * c.a);
 }
@@ -295,20 +297,22 @@ __device__ __forceinline__ void ss_st(float* p, float x) { __hip_atomic_store((u
 __device__ __forceinline__ TC ss_load(const SSBuf& b, size_t i) { const float* p = b.v + i; return tc(ss_ld(p), ss_ld(p + b.plane), ss_ld(p + 2 * b.plane), ss_ld(p + 3 * b.plane), ss_ld(p + 4 * b.plane)); }
 __device__ __forceinline__ void ss_store(const SSBuf& b, size_t i, const TC& c) { float* p = b.v + i; ss_st(p, c.r); ss_st(p + b.plane, c.g); ss_st(p + 2 * b.plane, c.b); ss_st(p + 3 * b.plane, c.a); ss_st(p + 4 * b.plane, c.d); }
 __device__ __forceinline__ TC ss_getc(const SSBuf& v, const DTile& t, int dx, int dy) {  // getc: outside the tile reads blank
-  if (dx >= 0 && dx < t.w && dy >= 0 && dy < t.h) return ss_load(v, (size_t)t.pix_base + (size_t)dy * t.w + dx);
-  return tc_blank();
+  // (the load is unconditional, from a clamped address, so the twenty loads of a contrast test go out back to back)
+  const bool in = dx >= 0 && dx < t.w && dy >= 0 && dy < t.h;
+  const TC c = ss_load(v, (size_t)t.pix_base + (in ? (size_t)dy * t.w + dx : (size_t)0));
+  return in ? c : tc_blank();
 }
 struct SSPlan {  // per pass: regions per tile, regions per tile row, first item of the pass in a head's sequence
   uint32_t per_tile[6], nrx[6], first[7];
   uint32_t tiles_per_head;
 };
-__device__ __forceinline__ SSPlan ss_plan(const DRenderArgs& A) {
+__host__ __device__ inline SSPlan ss_plan(const DRenderArgs& A) {
   SSPlan P;
-  P.tiles_per_head = ((uint32_t)A.ntiles + kSSHeads - 1) / kSSHeads;
+  P.tiles_per_head = ((uint32_t)A.ntiles * (uint32_t)A.nframes + kSSHeads - 1) / kSSHeads;  // (a tile of every frame of the launch)
   P.first[1] = 0; P.per_tile[0] = 0; P.nrx[0] = 1; P.first[0] = 0;
   for (int p = 1; p <= 5; p++) {
     int nrx;
-    P.per_tile[p] = (uint32_t)ss_regions_per_tile(p, A.blocksize, nrx);  // laid out for full tiles; edge tiles leave regions empty
+    P.per_tile[p] = (uint32_t)ss_regions_per_tile(p, A.blocksize, A.ss_rw[p], A.ss_rh[p], nrx);  // laid out for full tiles; edge tiles leave regions empty
     P.nrx[p] = (uint32_t)nrx;
     P.first[p + 1] = P.first[p] + P.per_tile[p] * P.tiles_per_head;
   }
@@ -317,10 +321,10 @@ __device__ __forceinline__ SSPlan ss_plan(const DRenderArgs& A) {
 
 template <class TIER>
 __device__ __forceinline__ void ss_frame_loop(const DRenderArgs& A, TIER& T) {
-  __shared__ uint32_t need_list[256];  // candidates of the region that need a sample: dx | dy << 8 (one wave per block)
-  const SSBuf v{A.scratch, (size_t)A.ss_plane};
+  __shared__ uint32_t need_list[256];  // ring of the region's candidates that need a sample: dx | dy << 8 (one wave per block)
   const int lane = threadIdx.x & 63;
   const SSPlan PL = ss_plan(A);
+  const uint32_t vtiles = (uint32_t)A.ntiles * (uint32_t)A.nframes;
   uint32_t shard = blockIdx.x % kSSHeads, dry = 0;  // (lane 0's)
   for (;;) {
     // ---- take the next item of a queue head (TicketQueue's scheme, over the frame's own heads)
@@ -341,10 +345,14 @@ __device__ __forceinline__ void ss_frame_loop(const DRenderArgs& A, TIER& T) {
     int pass = 1;
     while (w >= PL.first[pass + 1]) pass++;
     const uint32_t j = w - PL.first[pass];
-    const uint32_t ti = (j / PL.per_tile[pass]) * kSSHeads + h;  // tile (ti mod kSSHeads == h)
-    if (ti >= (uint32_t)A.ntiles) continue;                       // padding of the last round of tiles
+    const uint32_t ti = (j / PL.per_tile[pass]) * kSSHeads + h;  // tile of a frame (ti mod kSSHeads == h): frame-major
+    if (ti >= vtiles) continue;                                   // padding of the last round of tiles
     const int r = (int)(j % PL.per_tile[pass]), rx = r % (int)PL.nrx[pass], ry = r / (int)PL.nrx[pass];
-    const DTile t = A.tiles[ti];
+    const uint32_t frame = ti / (uint32_t)A.ntiles;
+    const DTile t = A.tiles[ti - frame * (uint32_t)A.ntiles];
+    const SSBuf v{A.scratch + (size_t)frame * 5 * A.ss_plane, (size_t)A.ss_plane};  // every frame has its own working buffer
+    const size_t frame_off = (size_t)frame * A.frame_stride;
+    const DCamera& cam = frame == 0 ? A.cam : A.more_cams[frame - 1];
     unsigned int* done = A.ss_done + (size_t)ti * 8;
     if (pass >= 2) {  // the tile's previous pass must be complete (its regions read each other's pixels)
       if (lane == 0) while (__hip_atomic_load(&done[pass - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < PL.per_tile[pass - 1]) __builtin_amdgcn_s_sleep(2);
@@ -355,58 +363,61 @@ __device__ __forceinline__ void ss_frame_loop(const DRenderArgs& A, TIER& T) {
     ss_neighbours(pass, ox, oy);
     int bw, bh;
     ss_block_shape(pass, bw, bh);
-    const int rb = ss_region_blocks(pass);
-    // ---- decide: every candidate of the region takes the contrast test; the ones that need a sample are listed
-    uint32_t n = 0;  // wave-uniform
-    for (int sb = 0; sb < rb * rb; sb++) {
-      const int bx = rx * rb + (sb % rb), by = ry * rb + (sb / rb);
-      if (bx * bw >= t.w || by * bh >= t.h) continue;  // wave-uniform: the block lies outside a clipped edge tile
-      if (pass == 1) {  // MUV.replicate ... (0,0,0,0,infinity), Glome.hs:231: this block's pixels start blank
-        for (int i = lane; i < bw * bh; i += 64) {
-          int px = bx * bw + i % bw, py = by * bh + i / bw;
-          if (px < t.w && py < t.h) ss_store(v, (size_t)t.pix_base + (size_t)py * t.w + px, tc_blank());
+    // the region's blocks inside the (possibly clipped) tile: [bx0, bx1) x [by0, by1)
+    const int rw = A.ss_rw[pass], rh = A.ss_rh[pass];
+    const int bx0 = rx * rw, by0 = ry * rh;
+    const int bx1 = min(bx0 + rw, (t.w + bw - 1) / bw), by1 = min(by0 + rh, (t.h + bh - 1) / bh);
+    const int nbx = bx1 - bx0, nb = nbx > 0 && by1 > by0 ? nbx * (by1 - by0) : 0;
+    // ---- decide block after block; whenever 64 candidates wait for a sample (and at the region's end) they are traced as
+    // one packet -- neighbours in the image.  Every pixel of the tile is written by exactly one of the passes 1-4 before a
+    // later pass reads it (Glome.hs:241-297), so the blank initial value (:231) is only ever seen outside the tile (getc).
+    uint32_t n = 0, hd = 0;  // wave-uniform: candidates listed / traced so far (ring positions)
+    int b = 0;
+    for (;;) {
+      for (; b < nb && n - hd < 64u; b++) {
+        const int bx = bx0 + b % nbx, by = by0 + b / nbx;
+        int dx, dy;
+        ss_block_pixel(pass, bx, by, lane, dx, dy);
+        bool need = dx < t.w && dy < t.h;
+        if (need && pass >= 2) {
+          TC a = ss_getc(v, t, dx + ox[0], dy + oy[0]), bb = ss_getc(v, t, dx + ox[1], dy + oy[1]);
+          TC c = ss_getc(v, t, dx + ox[2], dy + oy[2]), d = ss_getc(v, t, dx + ox[3], dy + oy[3]);
+          need = gmaxf(ccmp(a, c), ccmp(bb, d)) > thr;  // decide, Glome.hs:215-216
+          if (!need) {
+            TC avg = cavg4(a, bb, c, d);
+            if (pass < 5) ss_store(v, (size_t)t.pix_base + (size_t)dy * t.w + dx, avg);
+            else ss_write_out(A, frame_off, t, dx, dy, ss_pass5_blend(avg, a, bb, c, d, dx == t.w - 1, dy == t.h - 1));
+          }
         }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(need);
+        if (need) need_list[(n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & 255u] = (uint32_t)dx | ((uint32_t)dy << 8);
+        n += (uint32_t)__popcll(m);
       }
-      int dx, dy;
-      ss_block_pixel(pass, bx, by, lane, dx, dy);
-      bool need = dx < t.w && dy < t.h;
-      if (need && pass >= 2) {
-        TC a = ss_getc(v, t, dx + ox[0], dy + oy[0]), bb = ss_getc(v, t, dx + ox[1], dy + oy[1]);
-        TC c = ss_getc(v, t, dx + ox[2], dy + oy[2]), d = ss_getc(v, t, dx + ox[3], dy + oy[3]);
-        need = gmaxf(ccmp(a, c), ccmp(bb, d)) > thr;  // decide, Glome.hs:215-216
-        if (!need) {
-          TC avg = cavg4(a, bb, c, d);
-          if (pass < 5) ss_store(v, (size_t)t.pix_base + (size_t)dy * t.w + dx, avg);
-          else ss_write_out(A, t, dx, dy, ss_pass5_blend(avg, a, bb, c, d, dx == t.w - 1, dy == t.h - 1));
-        }
-      }
-      const unsigned long long m = __builtin_amdgcn_ballot_w64(need);
-      if (need) need_list[n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)dx | ((uint32_t)dy << 8);
-      n += (uint32_t)__popcll(m);
-    }
-    __syncthreads();  // one wave per block: makes the list visible across lanes
-    // ---- trace: 64 listed candidates at a time -- neighbours in the image, walked as a packet
-    for (uint32_t base = 0; base < n; base += 64) {
-      const bool valid = base + lane < n;
-      const uint32_t e = need_list[valid ? base + lane : base];
+      if (n == hd) break;  // (b == nb: the region is through)
+      __syncthreads();     // one wave per block: makes the list visible across lanes
+      const uint32_t cnt = min(64u, n - hd);
+      const bool valid = (uint32_t)lane < cnt;
+      const uint32_t e = need_list[(hd + (valid ? (uint32_t)lane : 0u)) & 255u];
+      hd += cnt;
       const int dx = (int)(e & 255u), dy = (int)(e >> 8);
       const float off = pass == 5 ? 0.5f : 0.0f;  // pass 5 samples between pixels (getCoordsf (x+.5) (y+.5), Glome.hs:307)
       float xc, yc;
       get_coordsf(A.width, A.height, (float)(t.x + dx) + off, (float)(t.y + dy) + off, xc, yc);
-      Ray ray = primary_ray(A.cam, xc, yc);
+      Ray ray = primary_ray(cam, xc, yc);
       if (valid) T.cnt.primary++;
       HitG hh;
       CA col = trace_primary(T, ray, kInf, A.maxdepth, valid, &hh);
-      if (!valid) continue;
-      TC smp = tc(col.r, col.g, col.b, col.a, hh.hit ? hh.t : kInf);
-      if (pass < 5) ss_store(v, (size_t)t.pix_base + (size_t)dy * t.w + dx, smp);
-      else {
-        TC a = ss_getc(v, t, dx + ox[0], dy + oy[0]), bb = ss_getc(v, t, dx + ox[1], dy + oy[1]);
-        TC c = ss_getc(v, t, dx + ox[2], dy + oy[2]), d = ss_getc(v, t, dx + ox[3], dy + oy[3]);
-        ss_write_out(A, t, dx, dy, ss_pass5_blend(smp, a, bb, c, d, dx == t.w - 1, dy == t.h - 1));
+      if (valid) {
+        TC smp = tc(col.r, col.g, col.b, col.a, hh.hit ? hh.t : kInf);
+        if (pass < 5) ss_store(v, (size_t)t.pix_base + (size_t)dy * t.w + dx, smp);
+        else {
+          TC a = ss_getc(v, t, dx + ox[0], dy + oy[0]), bb = ss_getc(v, t, dx + ox[1], dy + oy[1]);
+          TC c = ss_getc(v, t, dx + ox[2], dy + oy[2]), d = ss_getc(v, t, dx + ox[3], dy + oy[3]);
+          ss_write_out(A, frame_off, t, dx, dy, ss_pass5_blend(smp, a, bb, c, d, dx == t.w - 1, dy == t.h - 1));
+        }
       }
+      __syncthreads();  // the entries just read may be overwritten by the blocks that follow
     }
-    __syncthreads();  // the list is reused by the next region
     if (pass < 5) {   // the region's pixels are in memory before it counts as done
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) atomicAdd(&done[pass], 1u);
@@ -865,8 +876,9 @@ static int persistent_grid(glome_ctx* ctx, size_t lds_per_block, uint32_t total_
 // against 0.036 with 8); items of a large scene keep a wave busy for ~0.1 ms each and a short launch wants 8 (a rank's
 // shard of the flagship frame: 0.039 ms per frame with 8, 0.048 with 4).
 static int grid_floor(const glome_scene* s) { return s->info.n_bih_nodes + s->info.n_mesh_nodes < 4096 ? 3 : 8; }
+// per wave slot: ovf_cap overflow entries + one more block of [3][64] words, the dump block of bih_walk_asm (LaneStack::dump)
 static int ensure_overflow(glome_ctx* ctx, int grid, int waves_per_block, int ovf_cap) {
-  size_t need = (size_t)grid * waves_per_block * ovf_cap * 3 * 64 * sizeof(uint32_t);
+  size_t need = (size_t)grid * waves_per_block * (ovf_cap + 1) * 3 * 64 * sizeof(uint32_t);
   glome_ctx::Slot& sl = ctx->slot();
   if (need <= sl.ovf_bytes) return 0;
   if (sl.d_ovf) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(sl.d_ovf)); sl.d_ovf = nullptr; sl.ovf_bytes = 0; }
@@ -914,8 +926,7 @@ static bool use_two_rows(const glome_scene* s, const glome_render_params* P, uin
   if (P->tile_stride != 1 && items < 48000u) return false;
   if (s->dev.tier != 0 || P->faithful || P->count_work) return false;
   if (s->has_secondary_mats || s->has_nested_mats || s->stack_cap != kAsmLdsCap) return false;
-  int cls = scene_class(s);
-  return cls == CLS_BIH_TRI || cls == (CLS_BIH_SPHERE | CLS_PRIMS);
+  return scene_class(s) == CLS_BIH_TRI;  // (what bih_walk_asm walks: a two-row kernel has no row for bih_tri_packet's references)
 }
 
 static void launch_render(glome_scene* s, const DRenderArgs& A, const glome_render_params* P, int grid, size_t lds) {
@@ -926,7 +937,7 @@ static void launch_render(glome_scene* s, const DRenderArgs& A, const glome_rend
     bool full = s->has_nested_mats || (s->has_secondary_mats && P->maxdepth > 1);
     dim3 g(grid), blk(64);
     int cls = scene_class(s);
-#define GLOME_LAUNCH(F, C, U, K, B) hipLaunchKernelGGL((k_render_flat<F, C, U, K, B>), g, blk, lds, st, A, s->stack_cap, s->ovf_cap ? s->ctx->slot().d_ovf : nullptr, s->ovf_cap)
+#define GLOME_LAUNCH(F, C, U, K, B) hipLaunchKernelGGL((k_render_flat<F, C, U, K, B>), g, blk, lds, st, A, s->stack_cap, s->ctx->slot().d_ovf, s->ovf_cap)
 #define GLOME_BY_CLS(F, C, U)                                                   \
     do {                                                                          \
       if (cls == CLS_BIH_TRI) GLOME_LAUNCH(F, C, U, CLS_BIH_TRI, 1);              \
@@ -937,9 +948,8 @@ static void launch_render(glome_scene* s, const DRenderArgs& A, const glome_rend
     } while (0)
     if (use_two_rows(s, P, A.total_waves * (uint32_t)A.nframes)) {
       size_t lds2 = lds;  // sized by the caller for two rows
-      uint32_t* ov = s->ovf_cap ? s->ctx->slot().d_ovf : nullptr;
-      if (cls == CLS_BIH_TRI) hipLaunchKernelGGL((k_render_flat<false, false, false, CLS_BIH_TRI, 6, true>), g, blk, lds2, st, A, s->stack_cap, ov, s->ovf_cap);
-      else hipLaunchKernelGGL((k_render_flat<false, false, false, (CLS_BIH_SPHERE | CLS_PRIMS), 6, true>), g, blk, lds2, st, A, s->stack_cap, ov, s->ovf_cap);
+      uint32_t* ov = s->ctx->slot().d_ovf;
+      hipLaunchKernelGGL((k_render_flat<false, false, false, CLS_BIH_TRI, 6, true>), g, blk, lds2, st, A, s->stack_cap, ov, s->ovf_cap);
     } else
     if (faithful) { if (full) GLOME_LAUNCH(true, true, true, CLS_EVERY, 1); else GLOME_LAUNCH(true, true, false, CLS_EVERY, 1); }
     else if (count) { if (full) GLOME_LAUNCH(false, true, true, CLS_EVERY, 1); else GLOME_LAUNCH(false, true, false, CLS_EVERY, 1); }
@@ -974,7 +984,7 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
   A.S = s->dev;
   memcpy(&A.cam, cam, sizeof(DCamera));
   if (nframes < 1 || nframes > kMaxBatchFrames) { ctx->err = "a launch carries 1..8 frames"; return GLOME_E_LIMIT; }
-  if (nframes > 1 && (P->mode != GLOME_MODE_TILE || frame_stride <= 0 || frame_stride > 0xffffffffll)) { ctx->err = "frame batches: renderTile mode, positive frame stride"; return GLOME_E_INVALID; }
+  if (nframes > 1 && (frame_stride <= 0 || frame_stride > 0xffffffffll)) { ctx->err = "frame batches: positive frame stride"; return GLOME_E_INVALID; }
   for (int f = 1; f < nframes; f++) memcpy(&A.more_cams[f - 1], cam + f, sizeof(DCamera));
   A.nframes = nframes; A.frame_stride = nframes > 1 ? (uint32_t)frame_stride : 0u;
   for (int i = 0; i < nlights; i++) {
@@ -1000,13 +1010,25 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
     // scratch: v (5 float planes over the owned pixels) | queue heads, one per 128-byte line, then the dry mask | one
     // line of pass counters per tile
     size_t npx = (size_t)tt->pixels;
-    const size_t ctl_words = (size_t)(kSSHeads + 1) * kSSHeadStride + (size_t)A.ntiles * 8;
-    if ((rc = ensure_scratch(ctx, npx * 5 * sizeof(float) + ctl_words * sizeof(unsigned int)))) return rc;
+    const size_t ctl_words = (size_t)(kSSHeads + 1) * kSSHeadStride + (size_t)A.ntiles * nframes * 8;
+    if ((rc = ensure_scratch(ctx, npx * 5 * nframes * sizeof(float) + ctl_words * sizeof(unsigned int)))) return rc;
     A.scratch = ctx->slot().d_scratch;
-    A.ss_cnt = (unsigned int*)(A.scratch + npx * 5);
+    A.ss_cnt = (unsigned int*)(A.scratch + npx * 5 * nframes);
     A.ss_done = A.ss_cnt + (size_t)(kSSHeads + 1) * kSSHeadStride;
     A.ss_plane = (uint32_t)npx;
     A.blocksize = P->blocksize;
+    // Region size by the frames of the launch: what hides a tile's chain of five dependent passes is other frames' tiles
+    // (tools/probe/ss_tune.py, profiles/r02_f_ss_regions.log: one frame alone wants the small regions whatever its tile count)
+    for (int pass = 1; pass <= 5; pass++) {
+      int rw, rh;
+      ss_region_shape(pass, nframes >= 8 ? 2 : (nframes >= 3 ? 1 : 0), rw, rh);
+      A.ss_rw[pass] = (int8_t)rw; A.ss_rh[pass] = (int8_t)rh;
+    }
+    if (const char* e = getenv("GLOME_DEBUG_SS_REGIONS")) {  // "1x5,3x5,5x5,5x5,5x5"
+      int q[10];
+      if (sscanf(e, "%dx%d,%dx%d,%dx%d,%dx%d,%dx%d", q, q + 1, q + 2, q + 3, q + 4, q + 5, q + 6, q + 7, q + 8, q + 9) == 10)
+        for (int pass = 1; pass <= 5; pass++) { A.ss_rw[pass] = (int8_t)q[2 * pass - 2]; A.ss_rh[pass] = (int8_t)q[2 * pass - 1]; }
+    }
     HIPCHK(ctx, hipMemsetAsync(A.ss_cnt, 0, ctl_words * sizeof(unsigned int), ctx->stream));
     bool pooled = ctx->timing && (ctx->timing_seen++ % ctx->timing_stride) == 0 && ctx->pool_used + 2 <= (int)ctx->pool.size();
     hipEvent_t e0 = pooled ? ctx->pool[ctx->pool_used] : ctx->ev0, e1 = pooled ? ctx->pool[ctx->pool_used + 1] : ctx->ev1;
@@ -1017,15 +1039,17 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
     size_t lds = s->dev.tier == 0 ? flat_lds_bytes(s->stack_cap, two_rows) : 0;
     bool full = s->has_nested_mats || (s->has_secondary_mats && P->maxdepth > 1);
     bool tri = s->dev.tier == 0 && (s->cls_mask & ~CLS_BIH_TRI) == 0;
-    uint32_t items = 0;
-    for (int pass = 1; pass <= 5; pass++) { int nbx; items += (uint32_t)ss_regions_per_tile(pass, P->blocksize, nbx) * (uint32_t)A.ntiles; }
+    const uint32_t items = ss_plan(A).first[6] * kSSHeads;
     // (a wave that is not resident yet holds no item, so the items a running wave waits for are always with running waves)
-    int tgrid = persistent_grid(ctx, lds, items, two_rows ? 24 : 32, grid_floor(s));
-    if (s->dev.tier == 0 && s->ovf_cap && (rc = ensure_overflow(ctx, tgrid, 1, s->ovf_cap))) return rc;
-    uint32_t* ov = s->ovf_cap ? ctx->slot().d_ovf : nullptr;
+    // (the sampler's items are long -- a region's contrast tests and one or more packet walks -- so the grid is sized for ~4 per wave)
+    int tgrid = persistent_grid(ctx, lds, (uint32_t)std::min<uint64_t>((uint64_t)items * 16, 0x7fffffffu), two_rows ? 16 : 32, grid_floor(s));
+    tgrid = (int)std::min<uint32_t>((uint32_t)tgrid, items);
+    if (s->dev.tier == 0 && (rc = ensure_overflow(ctx, tgrid, 1, s->ovf_cap))) return rc;
+    uint32_t* ov = ctx->slot().d_ovf;
     dim3 g(tgrid), blk(64);
     if (s->dev.tier != 0) hipLaunchKernelGGL(k_ss_frame_generic, g, blk, 0, ctx->stream, A);
-    else if (two_rows) hipLaunchKernelGGL((k_ss_frame_flat<false, CLS_BIH_TRI, 6, true>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
+    // (four waves per SIMD: with 80 registers the sampler's own state spills, and every reload waits for the loads in flight)
+    else if (two_rows) hipLaunchKernelGGL((k_ss_frame_flat<false, CLS_BIH_TRI, 4, true>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
     else if (tri && !full) hipLaunchKernelGGL((k_ss_frame_flat<false, CLS_BIH_TRI>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
     else if (tri) hipLaunchKernelGGL((k_ss_frame_flat<true, CLS_BIH_TRI>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
     else if (!full) hipLaunchKernelGGL((k_ss_frame_flat<false, CLS_EVERY, 2>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
@@ -1036,7 +1060,7 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
     const bool two_rows = use_two_rows(s, P, A.total_waves * (uint32_t)nframes);
     size_t lds = s->dev.tier == 0 ? flat_lds_bytes(s->stack_cap, two_rows) : 0;
     int grid = persistent_grid(ctx, lds, A.total_waves * (uint32_t)nframes, two_rows ? 24 : 32, grid_floor(s));
-    if (s->dev.tier == 0 && s->ovf_cap && (rc = ensure_overflow(ctx, grid, 1, s->ovf_cap))) return rc;
+    if (s->dev.tier == 0 && (rc = ensure_overflow(ctx, grid, 1, s->ovf_cap))) return rc;
     bool pooled = ctx->timing && (ctx->timing_seen++ % ctx->timing_stride) == 0 && ctx->pool_used + 2 <= (int)ctx->pool.size();
     hipEvent_t e0 = pooled ? ctx->pool[ctx->pool_used] : ctx->ev0, e1 = pooled ? ctx->pool[ctx->pool_used + 1] : ctx->ev1;
     if (pooled) ctx->pool_used += 2;
@@ -1131,8 +1155,8 @@ int glome_rayint_batch_dev(glome_scene* s, size_t n, const float* ox, const floa
   if (s->dev.tier == 0) {
     size_t lds = flat_lds_bytes(s->stack_cap);
     int grid = batch_grid(ctx, n, lds), rc;
-    if (s->ovf_cap && (rc = ensure_overflow(ctx, grid, 1, s->ovf_cap))) return rc;
-    hipLaunchKernelGGL((k_rayint_batch_flat<false>), dim3(grid), dim3(64), lds, ctx->stream, s->dev, n, R, H, s->stack_cap, s->ovf_cap ? ctx->slot().d_ovf : nullptr, s->ovf_cap, ctx->slot().d_counters);
+    if ((rc = ensure_overflow(ctx, grid, 1, s->ovf_cap))) return rc;
+    hipLaunchKernelGGL((k_rayint_batch_flat<false>), dim3(grid), dim3(64), lds, ctx->stream, s->dev, n, R, H, s->stack_cap, ctx->slot().d_ovf, s->ovf_cap, ctx->slot().d_counters);
   } else {
     if (int rcc = reset_counters(ctx)) return rcc;
     hipLaunchKernelGGL(k_rayint_batch_generic, dim3(batch_grid(ctx, n, 0)), dim3(64), 0, ctx->stream, s->dev, n, R, H, ctx->slot().d_counters);
@@ -1151,8 +1175,8 @@ int glome_shadow_batch_dev(glome_scene* s, size_t n, const float* ox, const floa
   if (s->dev.tier == 0) {
     size_t lds = flat_lds_bytes(s->stack_cap);
     int grid = batch_grid(ctx, n, lds), rc;
-    if (s->ovf_cap && (rc = ensure_overflow(ctx, grid, 1, s->ovf_cap))) return rc;
-    hipLaunchKernelGGL(k_shadow_batch_flat, dim3(grid), dim3(64), lds, ctx->stream, s->dev, n, R, occluded, s->stack_cap, s->ovf_cap ? ctx->slot().d_ovf : nullptr, s->ovf_cap, ctx->slot().d_counters);
+    if ((rc = ensure_overflow(ctx, grid, 1, s->ovf_cap))) return rc;
+    hipLaunchKernelGGL(k_shadow_batch_flat, dim3(grid), dim3(64), lds, ctx->stream, s->dev, n, R, occluded, s->stack_cap, ctx->slot().d_ovf, s->ovf_cap, ctx->slot().d_counters);
   } else {
     if (int rcc = reset_counters(ctx)) return rcc;
     hipLaunchKernelGGL(k_shadow_batch_generic, dim3(batch_grid(ctx, n, 0)), dim3(64), 0, ctx->stream, s->dev, n, R, occluded, ctx->slot().d_counters);

@@ -381,12 +381,16 @@ struct LaneStack {
   int ovf_cap;                               // entries available there
   static constexpr int STRIDE = 64;
   GD int total_cap() const { return cap + ovf_cap; }
-  // Packet entries (bih_tri_wave): the node reference and the mask of lanes that want the entry are wave-uniform.  They
-  // live in three vector registers, entry k in lane k of each (a 64-entry scalar stack that costs no LDS: v_writelane /
-  // v_readlane with the stack pointer as the lane); only every lane's own (near, far) goes to the LDS rows.  A kernel
-  // whose lanes never push on their own therefore needs two LDS rows per entry instead of three, which is what bounds
-  // its waves per CU.
-  uint32_t ur, ulo, uhi;
+  // Packet entries (bih_tri_wave): the node reference and the mask of lanes that want the entry are wave-uniform.
+  //   bih_tri_packet (C++) keeps them per lane in the reference row: every lane stores the reference, with bit 31 set
+  //   when the lane is in the entry's mask; a pop reads the row back and votes.  No value ever sits in "lane k of a
+  //   register": a vector register whose inactive lanes matter is not something the compiler knows about -- a spill or a
+  //   copy it places under a partial EXEC mask (a divergent triangle test, say) silently drops those lanes.
+  //   bih_walk_asm (hand-written) does hold entry k in lane k of three registers, but only inside its one asm block;
+  //   when it hands a step back to C++ it writes them to `dump` (one word per lane and register, global memory) and
+  //   reads them back on re-entry, so no C++ variable ever carries them.  push_dump / pop_dump are the C++ steps' view.
+  bool has_ref_row;  // false in kernels with two LDS rows per entry (lane_stack<true>): only bih_walk_asm runs there
+  uint32_t* dump;    // this lane's column of the dump block: [3][64] words per wave
   GD void push2(int sp, float a, float b) {
     if (__builtin_expect(sp < cap, 1)) { nearv[sp * STRIDE] = a; farv[sp * STRIDE] = b; }
     else { uint32_t* o = ovf + (size_t)(sp - cap) * 3 * STRIDE; __builtin_nontemporal_store(as_u(a), o + STRIDE); __builtin_nontemporal_store(as_u(b), o + 2 * STRIDE); }
@@ -399,16 +403,23 @@ struct LaneStack {
       asm volatile("" : "+v"(a), "+v"(b));
     }
   }
-  GD void push_wave(int sp, uint32_t ref, LaneMask m, float a, float b) {
-    uint32_t keep;  // m0 is saved and restored: the compiler does not track it through an asm statement
-    asm("s_mov_b32 %3, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tv_writelane_b32 %0, %5, m0\n\tv_writelane_b32 %1, %6, m0\n\tv_writelane_b32 %2, %7, m0\n\ts_mov_b32 m0, %3"
-        : "+v"(ur), "+v"(ulo), "+v"(uhi), "=&s"(keep) : "s"(sp), "s"(ref), "s"((uint32_t)m), "s"((uint32_t)(m >> 32)));
+  GD void push_wave(int sp, uint32_t ref, LaneMask m, float a, float b) { push(sp, ref | (lane_of(m) ? 0x80000000u : 0u), a, b); }
+  GD void pop_wave(int sp, uint32_t& ref, LaneMask& m, float& a, float& b) const {
+    uint32_t w;
+    pop(sp, w, a, b);
+    ref = uni(w & 0x7fffffffu);
+    m = wave_ballot((w >> 31) != 0);
+  }
+  // entry `sp` of bih_walk_asm's stack, as it lies in the dump block: lane sp's three words
+  GD void push_dump(int sp, uint32_t ref, LaneMask m, float a, float b) {
+    if ((int)(threadIdx.x & 63) == sp) { dump[0] = ref; dump[STRIDE] = (uint32_t)m; dump[2 * STRIDE] = (uint32_t)(m >> 32); }
     push2(sp, a, b);
   }
-  GD void pop_wave(int sp, uint32_t& ref, LaneMask& m, float& a, float& b) const {
+  GD void pop_dump(int sp, uint32_t& ref, LaneMask& m, float& a, float& b) const {
     pop2(sp, a, b);
-    ref = (uint32_t)__builtin_amdgcn_readlane((int)ur, sp);
-    m = (LaneMask)(uint32_t)__builtin_amdgcn_readlane((int)ulo, sp) | ((LaneMask)(uint32_t)__builtin_amdgcn_readlane((int)uhi, sp) << 32);
+    const uint32_t w0 = dump[0], w1 = dump[STRIDE], w2 = dump[2 * STRIDE];
+    ref = (uint32_t)__builtin_amdgcn_readlane((int)w0, sp);
+    m = (LaneMask)(uint32_t)__builtin_amdgcn_readlane((int)w1, sp) | ((LaneMask)(uint32_t)__builtin_amdgcn_readlane((int)w2, sp) << 32);
   }
   // The overflow column is spill traffic (non-temporal).  The empty asm pins the overflow loads inside their branch:
   // without it the compiler sinks both branches' loads into one access through a generic (flat) pointer, and every
@@ -705,7 +716,7 @@ GD PacketResult bih_tri_packet_hw(const F4* nodes, const F4* tris, uint32_t ref,
   const uint32_t lds_row = (uint32_t)(uintptr_t)stk.nearv;
   for (;;) {
     int st;
-#define GLOME_WALK(XF, YF, ZF) st = bih_walk_asm<MODE, XF, YF, ZF, CAP>(nodes, tris, delta, phase, ref, am, sp, nearv, farv, R.best_t, R.best_rec, occm, r.o, rcp, r.d, lds_row, stk.ur, stk.ulo, stk.uhi)
+#define GLOME_WALK(XF, YF, ZF) st = bih_walk_asm<MODE, XF, YF, ZF, CAP>(nodes, tris, delta, phase, ref, am, sp, nearv, farv, R.best_t, R.best_rec, occm, r.o, rcp, r.d, lds_row, stk.dump)
     switch (fwdbits) {  // wave-uniform: one scalar jump per walk
       case 7: GLOME_WALK(true, true, true); break;
       case 6: GLOME_WALK(false, true, true); break;
@@ -733,7 +744,7 @@ GD PacketResult bih_tri_packet_hw(const F4* nodes, const F4* tris, uint32_t ref,
       const float t1 = fwd ? dl : dr, t2 = fwd ? dr : dl;
       const LaneMask m1 = wave_ballot(nearv < t1) & am, m2 = wave_ballot(t2 < farv) & am;
       const float f1 = min_nn(t1, farv), n2 = max_nn(t2, nearv);
-      if ((m1 != 0) & (m2 != 0)) { stk.push_wave(sp, c2, m2, n2, farv); sp++; }
+      if ((m1 != 0) & (m2 != 0)) { stk.push_dump(sp, c2, m2, n2, farv); sp++; }  // depth <= capacity (validated at commit)
       const bool g1 = m1 != 0;
       ref = g1 ? c1 : c2;
       am = g1 ? m1 : m2;
@@ -759,7 +770,7 @@ GD PacketResult bih_tri_packet_hw(const F4* nodes, const F4* tris, uint32_t ref,
       phase = 1;
     } else {  // PKW_POP_OVERFLOW: the top entry sits in the overflow columns
       sp--;
-      stk.pop_wave(sp, ref, am, nearv, farv);
+      stk.pop_dump(sp, ref, am, nearv, farv);
       if (MODE == 1) { farv = gminf(farv, R.best_t); am &= wave_ballot(!(nearv > farv)); }
       if (MODE == 2) am &= ~occm;
       phase = am != 0 ? 0 : 1;
@@ -812,14 +823,17 @@ GD bool bih_tri_wave(const DScene& S, uint32_t hdr, const Ray& r, float d, bool 
     const LaneMask am = todo & wave_ballot(oct == fwdbits);
     todo &= ~am;
     PacketResult R;
+    bool walked = false;
 #if defined(__HIPCC__)
     if constexpr (MODE != 0 && !COUNT && LEAFK == 0 && std::is_same<STK, LaneStack>::value) {
-      if (stk.cap == kAsmLdsCap) R = bih_tri_packet_hw<MODE>(S.bihnodes, S.tris, ref, delta, fwdbits, am, nearv, farv, r.o, r.d, rcp, best_t, stk);
-      else R = bih_tri_packet<MODE, COUNT, LEAFK, STK>(S.bihnodes, S.tris, ref, delta, fwdbits, (uint32_t)am, (uint32_t)(am >> 32), nearv, farv, r.o, r.d, rcp, best_t, stk);
-    } else
+      if (stk.cap == kAsmLdsCap) { R = bih_tri_packet_hw<MODE>(S.bihnodes, S.tris, ref, delta, fwdbits, am, nearv, farv, r.o, r.d, rcp, best_t, stk); walked = true; }
+    }
 #endif
-    R = bih_tri_packet<MODE, COUNT, LEAFK, STK>(S.bihnodes, LEAFK == 0 ? S.tris : S.spheres, ref, delta, fwdbits, (uint32_t)am, (uint32_t)(am >> 32),
-                                                 nearv, farv, r.o, r.d, rcp, best_t, stk);
+    if (!walked) {
+      if (stk.has_ref_row) R = bih_tri_packet<MODE, COUNT, LEAFK, STK>(S.bihnodes, LEAFK == 0 ? S.tris : S.spheres, ref, delta, fwdbits, (uint32_t)am, (uint32_t)(am >> 32),
+                                                                     nearv, farv, r.o, r.d, rcp, best_t, stk);
+      else { R.best_t = best_t; R.best_rec = kNoRec; R.occ_lo = R.occ_hi = R.n_bih = R.n_prim = 0; }  // (a kernel with two stack rows is only launched for what bih_walk_asm walks)
+    }
     if (lane_of(am)) {
       if (COUNT) { cnt.bih += R.n_bih; cnt.prim += R.n_prim; }
       if (MODE != 2 && R.best_rec != kNoRec) { best_t = R.best_t; best_rec = R.best_rec; }
@@ -1760,14 +1774,25 @@ GD void ss_neighbours(int p, int* ox, int* oy) {
 GHD void ss_block_shape(int p, int& bw, int& bh) {
   switch (p) { case 1: case 2: bw = 32; bh = 16; break; case 3: bw = 16; bh = 16; break; case 4: bw = 16; bh = 8; break; default: bw = 8; bh = 8; break; }
 }
-// A work item (region) is 1x1 block in passes 1-2 (nearly every candidate is sampled) and 2x2 blocks in passes 3-5, where
-// only some candidates need a sample: those are compacted over the region before they are traced, so the packets stay full.
-GHD int ss_region_blocks(int p) { return p <= 2 ? 1 : 2; }
-GHD int ss_regions_per_tile(int p, int tile_size, int& nrx) {
+// A work item (region) is a rectangle of rw x rh blocks.  The candidates of a region that need a sample are compacted
+// over the WHOLE region as they are found and traced 64 at a time, so a region costs one partly filled packet at most.
+// What a tile costs is packet walks (each a chain of dependent fetches), not candidates: large regions mean fewer
+// walks, small regions mean more of them side by side -- and a tile's five passes are a chain, which only other tiles
+// and other frames hide.  `size` 0: a frame or two per launch (1 block per region in passes 1-2, 2x2 after); 1: three to
+// seven frames; 2: a batch of eight (pass 1 -- every candidate is sampled: 545 of a 65x65 tile -- in columns of blocks,
+// the later passes, where a few percent of the candidates need a sample, the whole tile).  Measured on S3, ms per frame
+// with 1 / 4 / 8 frames per launch (profiles/r02_f_ss_regions.log): size 0: 0.89 / 0.54 / 0.53, size 1: 1.25 / 0.49 /
+// 0.45, size 2: 1.98 / 0.67 / 0.43.
+// Blocks outside a clipped tile are skipped.
+GHD void ss_region_shape(int p, int size, int& rw, int& rh) {
+  if (size >= 2) { rw = p == 1 ? 1 : (p == 2 ? 3 : 5); rh = 5; }
+  else if (size == 1) { rw = p <= 2 ? 1 : 3; rh = p == 1 ? 2 : (p == 2 || p == 4 ? 5 : 3); }
+  else { rw = rh = p <= 2 ? 1 : 2; }
+}
+GHD int ss_regions_per_tile(int p, int tile_size, int rw, int rh, int& nrx) {
   int bw, bh; ss_block_shape(p, bw, bh);
-  const int rb = ss_region_blocks(p);
-  nrx = (tile_size + bw * rb - 1) / (bw * rb);
-  return nrx * ((tile_size + bh * rb - 1) / (bh * rb));
+  nrx = (tile_size + bw * rw - 1) / (bw * rw);
+  return nrx * ((tile_size + bh * rh - 1) / (bh * rh));
 }
 // candidate pixel (tile-local) of `lane` in block (bx, by) of pass p; every lane of a block maps to a distinct candidate
 GD void ss_block_pixel(int p, int bx, int by, int lane, int& dx, int& dy) {

@@ -124,6 +124,7 @@ struct DRenderArgs {
   unsigned int* ss_done; // adaptive sampler: [tile * 8 + pass] regions of the tile's pass that are complete
   uint32_t ss_plane;     // adaptive sampler: pixels per channel plane of the working buffer `scratch` (r | g | b | a | depth planes)
   int32_t blocksize;     // adaptive sampler: tile edge (<= 65); work items are laid out for full-size tiles
+  int8_t ss_rw[8], ss_rh[8];  // adaptive sampler: a work item of pass p covers ss_rw[p] x ss_rh[p] blocks of its tile
   float* out5;         // width*height*5
   uint32_t* packed;    // width*height or null
   DCounters* counters;

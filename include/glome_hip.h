@@ -254,7 +254,8 @@ int glome_render_tiles_packed_dev(glome_scene*, const glome_camera*, const glome
  * most 8).  Frame f's pixels land frame_stride_pixels words after frame f-1's: rows of a dense tile payload
  * (..._tiles_packed_batch_dev; stride >= this rank's payload size) or whole packed framebuffers (..._packed_batch_dev;
  * stride >= width*height).  A rank's share of one frame is a few thousand work items -- too little to fill the GPU
- * beyond its slowest item; a batch restores long launches.  renderTile mode only. */
+ * beyond its slowest item; a batch restores long launches.  Both render modes (the adaptive sampler of a batch of 4 or
+ * more frames works in larger regions per work item: fewer, fuller sample packets; the frames are unchanged). */
 int glome_render_tiles_packed_batch_dev(glome_scene*, const glome_camera* cams, int nframes, const glome_light* lights, int nlights,
                                         const glome_render_params*, uint32_t* payload_dev, int64_t frame_stride_pixels, glome_stats*);
 int glome_render_packed_batch_dev(glome_scene*, const glome_camera* cams, int nframes, const glome_light* lights, int nlights,

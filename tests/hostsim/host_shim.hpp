@@ -35,6 +35,7 @@ struct LaneStack {
   uint32_t* ovf;
   int ovf_cap;
   static constexpr int STRIDE = 1;
+  static constexpr bool has_ref_row = true;
   GD int total_cap() const { return cap + ovf_cap; }
   GD void push(int sp, uint32_t n, float a, float b) {
     if (sp < cap) { node[sp * STRIDE] = n; nearv[sp * STRIDE] = a; farv[sp * STRIDE] = b; }

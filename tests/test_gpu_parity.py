@@ -541,6 +541,36 @@ def test_two_row_packet_kernel_over_a_one_leaf_bih(gpu_ctx):
     sc.release()
 
 
+@pytest.mark.parametrize("nframes", [3, 8])
+def test_adaptive_sampler_frame_batches_equal_the_frames_rendered_alone(gpu_ctx, nframes):
+    """renderTileSubsample over several views in ONE launch (glome_render_packed_batch_dev, mode 1): the sampler then works in
+    larger regions per work item (3 frames: medium, 8: a whole tile per pass) -- other packets, the same pixels.  Every frame
+    of the batch must equal the frame rendered alone, bit for bit; the frame size leaves clipped tiles on two edges."""
+    import torch
+    sd = scenes.s3(48)
+    b, nm, sc = commit(gpu_ctx, sd)
+    cam, lights = product_camera_lights(sd)
+    W, H = 531, 397
+    P = api.render_params(width=W, height=H, maxdepth=1, mode=1)
+    views = []
+    for f in range(nframes):  # the scene's camera, then the eye moved sideways and up a little
+        pos, at, up, angle = sd.cam
+        views.append(api.camera([pos[0] + 0.4 * f, pos[1] + 0.1 * f, pos[2]], at, up, angle))
+    alone = [sc.render(v, lights, P)[1] for v in views]
+    assert any(not np.array_equal(alone[0], a) for a in alone[1:])
+    px = torch.zeros((nframes, H, W), dtype=torch.int32, device=torch.device("cuda:0"))
+    cams = (L.Camera * nframes)(*views)
+    la = (L.Light * len(lights))(*lights)
+    for rep in range(2):
+        assert sc.lib.glome_render_packed_batch_dev(sc.h, cams, nframes, la, len(lights), C.byref(P), C.c_void_p(px.data_ptr()), H * W, None) == 0, gpu_ctx.err()
+        gpu_ctx.synchronize()
+        got = px.cpu().numpy().view(np.uint32)
+        for f in range(nframes):
+            assert np.array_equal(got[f], alone[f]), (rep, f)
+        px.zero_()
+    sc.release()
+
+
 # ------------------------------------------------------------------ BASELINE configs[4]: 1M triangles, 3840x2160, adaptive, shards
 def _bih_op(sd, nm):
     """(host node, item ids) of the scene's `bih` call: SceneDesc node ids run over the node ops in order (a bulk op makes many)"""

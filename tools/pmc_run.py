@@ -11,9 +11,9 @@ b = api.Builder(); nm, _ = sd.replay(b); ctx = api.Context(0); sc = ctx.commit(b
 cam = api.camera(*sd.cam); lights = [api.light(p, c, r, s) for (p, c, r, s) in sd.lights]
 MODE = int(os.environ.get("MODE", "0"))
 P = api.render_params(width=cfg["width"], height=cfg["height"], maxdepth=cfg["maxdepth"], mode=MODE)
-G = int(os.environ.get("GROUP", "4")) if MODE == 0 else 1
+G = int(os.environ.get("GROUP", "4"))
 ctx.lib.glome_ctx_set_grid_per_cu(ctx.h, int(os.environ.get("GRID_PER_CU", "32")))  # the launch runs alone
-sf = dist.ShardedFrame(sc, P, 0, 1, torch.device("cuda:0"), lanes=1, product="packed" if MODE == 0 else "rgbad", group=G)
+sf = dist.ShardedFrame(sc, P, 0, 1, torch.device("cuda:0"), lanes=1, product="packed", group=G)
 for i in range(int(os.environ.get("LAUNCHES", "12")) * G):
     sf.step(cam, lights)
 sf.flush()
