@@ -541,6 +541,22 @@ def test_two_row_packet_kernel_over_a_one_leaf_bih(gpu_ctx):
     sc.release()
 
 
+def test_reference_default_scene_with_the_full_lattice(gpu_ctx):
+    """GlomeView's default scene (TestScene.hs:183-197 `geom''`, zoo.testscene) at the reference's own sizes -- the lattice of
+    21^3 = 9261 spheres under its bih, hollowed out by the sphere of radius 32 the camera stands inside -- against the oracle,
+    in renderTile and in renderTileSubsample mode, maxdepth 3 as GlomeView traces it."""
+    sd = zoo.testscene(10)
+    b, nm, sc = commit(gpu_ctx, sd)
+    info = sc.info()
+    assert info["tier"] == 1 and info["n_spheres"] >= 9261  # (a Warp material and composites below composites: the interpreter)
+    cam, lights = product_camera_lights(sd)
+    img, packed, st = sc.render(cam, lights, api.render_params(width=400, height=300, maxdepth=3))
+    parity.check_image(img, (st["rays_primary"], st["rays_shadow"], st["rays_secondary"]), sd, 400, 300, 3)
+    sub, _, st = sc.render(cam, lights, api.render_params(width=260, height=195, maxdepth=3, mode=1))
+    parity.check_subsample_image(sub, (st["rays_primary"], st["rays_shadow"], st["rays_secondary"]), sd, 260, 195, 3)
+    sc.release()
+
+
 @pytest.mark.parametrize("nframes", [3, 8])
 def test_adaptive_sampler_frame_batches_equal_the_frames_rendered_alone(gpu_ctx, nframes):
     """renderTileSubsample over several views in ONE launch (glome_render_packed_batch_dev, mode 1): the sampler then works in
