@@ -27,7 +27,7 @@ class Light(C.Structure):  # glome_light
 class RenderParams(C.Structure):  # glome_render_params
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("mode", C.c_int32), ("blocksize", C.c_int32),
                 ("maxdepth", C.c_int32), ("fog", C.c_int32), ("thresholds", C.c_float * 4), ("tile_first", C.c_int32),
-                ("tile_stride", C.c_int32), ("faithful", C.c_int32), ("count_work", C.c_int32)]
+                ("tile_stride", C.c_int32), ("faithful", C.c_int32), ("count_work", C.c_int32), ("rank0_share_pct", C.c_int32)]
 
 
 class Stats(C.Structure):  # glome_stats

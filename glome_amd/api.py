@@ -99,12 +99,13 @@ def light(pos, color, rad=1000000.0, shadow=True):
 
 
 def render_params(width=720, height=480, mode=0, blocksize=65, maxdepth=3, fog=0, tile_first=0, tile_stride=1,
-                  faithful=0, count_work=0, thresholds=None):
+                  faithful=0, count_work=0, thresholds=None, rank0_share_pct=0):
     lib = L.load()
     p = L.RenderParams()
     lib.glome_render_params_default(C.byref(p))
     p.width, p.height, p.mode, p.blocksize, p.maxdepth, p.fog = width, height, mode, blocksize, maxdepth, fog
     p.tile_first, p.tile_stride, p.faithful, p.count_work = tile_first, tile_stride, faithful, count_work
+    p.rank0_share_pct = rank0_share_pct
     if thresholds is not None:
         p.thresholds[:] = [float(t) for t in thresholds]
     return p

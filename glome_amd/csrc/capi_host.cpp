@@ -45,7 +45,7 @@ void glome_render_params_default(glome_render_params* p) {
   p->blocksize = 65;                       // Glome.hs:116
   p->maxdepth = 3;                         // Glome.hs:25
   p->thresholds[0] = 0.14f; p->thresholds[1] = 0.15f; p->thresholds[2] = 0.16f; p->thresholds[3] = 0.18f;  // Glome.hs:221-224
-  p->tile_first = 0; p->tile_stride = 1;
+  p->tile_first = 0; p->tile_stride = 1; p->rank0_share_pct = 0;
 }
 
 int glome_xfm_translate(const double v[3], double out[24]) { return xguard([&] { xf_to(xf_translate(d3(v)), out); }); }
@@ -341,7 +341,7 @@ long glome_sb_bih_dump(glome_sb* sb, int32_t id, long cap, double* lsplit, doubl
 int glome_tiles_layout(const glome_render_params* P, int tile_first, int tile_stride, int32_t* xywh_base, int cap) {
   if (!P || P->width <= 0 || P->height <= 0 || P->blocksize <= 0 || tile_stride <= 0 || tile_first < 0) return GLOME_E_INVALID;
   std::vector<DTile> t; uint32_t w; int64_t px;
-  owned_tiles(P->width, P->height, P->blocksize, tile_first, tile_stride, t, w, px);
+  owned_tiles(P->width, P->height, P->blocksize, tile_first, tile_stride, P->rank0_share_pct, t, w, px);
   for (size_t k = 0; k < t.size() && (int)k < cap; k++) {
     xywh_base[5 * k] = t[k].x; xywh_base[5 * k + 1] = t[k].y; xywh_base[5 * k + 2] = t[k].w; xywh_base[5 * k + 3] = t[k].h; xywh_base[5 * k + 4] = (int32_t)t[k].pix_base;
   }

@@ -590,18 +590,18 @@ static std::string g_global_error;
   } while (0)
 
 static int check_params(glome_ctx* ctx, const glome_render_params* P) {
-  if (!P || P->width <= 0 || P->height <= 0 || P->blocksize <= 0 || P->tile_stride <= 0 || P->tile_first < 0) { ctx->err = "bad render params"; return GLOME_E_INVALID; }
+  if (!P || P->width <= 0 || P->height <= 0 || P->blocksize <= 0 || P->tile_stride <= 0 || P->tile_first < 0 || P->rank0_share_pct < 0 || P->rank0_share_pct > 100) { ctx->err = "bad render params"; return GLOME_E_INVALID; }
   if ((int64_t)P->width * P->height > (1ll << 30)) { ctx->err = "frame too large"; return GLOME_E_INVALID; }
   if (P->maxdepth < 1 || P->maxdepth > kMaxTraceDepth) { ctx->err = "maxdepth must be in 1.." + std::to_string(kMaxTraceDepth); return GLOME_E_LIMIT; }
   return 0;
 }
 static int get_tiles(glome_ctx* ctx, const glome_render_params* P, int first, int stride, glome_ctx::TileTable** out, int blocksize = 0) {
   if (!blocksize) blocksize = P->blocksize;
-  std::vector<int> key{P->width, P->height, blocksize, first, stride};
+  std::vector<int> key{P->width, P->height, blocksize, first, stride, P->rank0_share_pct};
   auto it = ctx->tile_cache.find(key);
   if (it == ctx->tile_cache.end()) {
     glome_ctx::TileTable tt;
-    owned_tiles(P->width, P->height, blocksize, first, stride, tt.host, tt.total_waves, tt.pixels);
+    owned_tiles(P->width, P->height, blocksize, first, stride, P->rank0_share_pct, tt.host, tt.total_waves, tt.pixels);
     size_t bytes = std::max<size_t>(1, tt.host.size()) * sizeof(DTile);
     HIPCHK(ctx, hipMalloc((void**)&tt.dev, bytes));
     if (!tt.host.empty()) HIPCHK(ctx, hipMemcpy(tt.dev, tt.host.data(), tt.host.size() * sizeof(DTile), hipMemcpyHostToDevice));
@@ -1270,7 +1270,7 @@ int glome_inside_batch(glome_scene* s, size_t n, const float* px, const float* p
 int64_t glome_tiles_payload_floats(const glome_render_params* P, int tile_first, int tile_stride) {
   if (!P || P->width <= 0 || P->height <= 0 || P->blocksize <= 0 || tile_stride <= 0 || tile_first < 0) return -1;
   std::vector<DTile> t; uint32_t w; int64_t px;
-  owned_tiles(P->width, P->height, P->blocksize, tile_first, tile_stride, t, w, px);
+  owned_tiles(P->width, P->height, P->blocksize, tile_first, tile_stride, P->rank0_share_pct, t, w, px);
   return px * 5;
 }
 int glome_tiles_pack_dev(glome_ctx* ctx, const glome_render_params* P, const float* rgbad_dev, float* payload_dev) {
@@ -1287,13 +1287,13 @@ int glome_tiles_pack_dev(glome_ctx* ctx, const glome_render_params* P, const flo
 }
 // one table over every tile of the frame; pix_base = owner rank's slab offset + the tile's offset inside that rank's payload
 static int gathered_table(glome_ctx* ctx, const glome_render_params* P, int world, int64_t stride_pixels, glome_ctx::TileTable** out) {
-  std::vector<int> key{P->width, P->height, P->blocksize, -world, (int)stride_pixels};
+  std::vector<int> key{P->width, P->height, P->blocksize, -world, (int)stride_pixels, P->rank0_share_pct};
   auto it = ctx->tile_cache.find(key);
   if (it == ctx->tile_cache.end()) {
     glome_ctx::TileTable tt;
     for (int r = 0; r < world; r++) {
       std::vector<DTile> t; uint32_t w; int64_t px;
-      owned_tiles(P->width, P->height, P->blocksize, r, world, t, w, px);
+      owned_tiles(P->width, P->height, P->blocksize, r, world, P->rank0_share_pct, t, w, px);
       if ((int64_t)r * stride_pixels + px > 0xffffffffll) { ctx->err = "gathered payload too large"; return GLOME_E_LIMIT; }
       for (DTile& d : t) { d.pix_base += (uint32_t)(r * stride_pixels); tt.host.push_back(d); }
       tt.pixels += px;

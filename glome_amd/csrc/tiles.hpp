@@ -1,5 +1,6 @@
 // tiles.hpp -- the reference's tile map (chunk / renderTiles, Glome.hs:371-386) and the wave decomposition of a tile.
 #pragma once
+#include <algorithm>
 #include <utility>
 #include <vector>
 
@@ -23,13 +24,39 @@ inline uint32_t tile_waves(int w, int h) {
   uint32_t rest = (uint32_t)(w * h) - nbx * nby * 64;
   return nbx * nby + (rest + 63) / 64;
 }
+// Who owns tile k of a frame shared by `world` ranks.  Plain round robin (share_pct 0 or 100): rank k mod world.  With
+// rank0_share_pct in 1..99 rank 0 -- the rank that also receives and blits every frame -- owns that percentage of a fair
+// share and the others split the rest evenly: a repeating pattern of s0 + (world - 1) * 10 slots, s0 = pct / 10 rounded,
+// each rank's slots spread evenly over the period (largest remaining deficit first), so neighbouring tiles still go to
+// different ranks.  Every rank computes the same pattern from (world, pct).
+inline std::vector<int> shard_pattern(int world, int share_pct) {
+  std::vector<int> pat;
+  if (world <= 1 || share_pct <= 0 || share_pct >= 100) { for (int r = 0; r < std::max(world, 1); r++) pat.push_back(r); return pat; }
+  const int s = 10, s0 = std::max(1, (s * share_pct + 50) / 100), period = s0 + (world - 1) * s;
+  std::vector<long> given((size_t)world, 0);
+  for (int j = 0; j < period; j++) {
+    int best = 0; long bestd = -(1L << 60);
+    for (int r = 0; r < world; r++) {
+      const long target = r == 0 ? s0 : s;
+      const long d = target * (j + 1) - given[(size_t)r] * period;  // how far behind its share rank r is after slot j
+      if (d > bestd) { bestd = d; best = r; }
+    }
+    given[(size_t)best]++;
+    pat.push_back(best);
+  }
+  return pat;
+}
 // tiles owned by (first, stride) in renderTiles' order: x chunks outer, y chunks inner (Glome.hs:382-384)
-inline void owned_tiles(int width, int height, int blocksize, int first, int stride, std::vector<DTile>& out, uint32_t& total_waves, int64_t& pixels) {
+inline void owned_tiles(int width, int height, int blocksize, int first, int stride, int share_pct, std::vector<DTile>& out, uint32_t& total_waves, int64_t& pixels) {
   out.clear(); total_waves = 0; pixels = 0;
+  const bool weighted = share_pct > 0 && share_pct < 100 && stride > 1 && first < stride;
+  std::vector<int> pat;
+  if (weighted) pat = shard_pattern(stride, share_pct);
   int k = 0;
   for (auto& xc : chunk(width, blocksize))
     for (auto& yc : chunk(height, blocksize)) {
-      if (k >= first && (k - first) % stride == 0) {
+      const bool mine = weighted ? pat[(size_t)k % pat.size()] == first : (k >= first && (k - first) % stride == 0);
+      if (mine) {
         DTile t{xc.first, yc.first, xc.second, yc.second, total_waves, (uint32_t)pixels};
         out.push_back(t);
         total_waves += tile_waves(t.w, t.h);

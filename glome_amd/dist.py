@@ -53,6 +53,10 @@ def _clone_params(p, **kw):
     return q
 
 
+# rank 0's share of a fair share of the tiles, by ranks (renderTile mode; measured, profiles/r02_g_shard_share.log)
+RANK0_SHARE_PCT = {1: 0, 2: 85, 4: 70, 8: 65}
+
+
 class ShardPlan:
     """Who owns which tiles, how big each rank's payload is, and the one exchange step.  Backend agnostic: the GPU
     path (ShardedFrame) and the CPU multi-process test drive the same plan."""
@@ -147,9 +151,15 @@ class ShardedFrame:
     blitTile are fused and 4 bytes per pixel cross xGMI.  "rgbad" -- the float (r, g, b, a, depth) tuples ([h, w, 5]),
     20 bytes per pixel (one frame per launch)."""
 
-    def __init__(self, scene, params, rank, world, device, lanes=4, product="rgbad", group=1, force_pipeline=False, work_tiles=64):
+    def __init__(self, scene, params, rank, world, device, lanes=4, product="rgbad", group=1, force_pipeline=False, work_tiles=64, rank0_share_pct=None):
         import torch
         self.torch = torch
+        # rank 0 also receives and blits every frame: it owns less than a fair share of the tiles (glome_render_params.rank0_share_pct;
+        # the defaults are where rank 0's and another rank's sustained frame periods met on one GPU, tools/shard_share.py)
+        if rank0_share_pct is None:
+            rank0_share_pct = RANK0_SHARE_PCT.get(world, 60 if world > 8 else 0) if params.mode == 0 else 0
+        params = _clone_params(params, rank0_share_pct=int(rank0_share_pct))
+        self.rank0_share_pct = int(rank0_share_pct)
         # renderTile's pixels do not depend on the tile map (the adaptive sampler's do, Q21): the shard unit is then a 64x64
         # *work* tile
         # (64: all 8x8 blocks, no thin leftover strips; tools/shard_balance.py: 32 and 16 lose cache locality between a rank's

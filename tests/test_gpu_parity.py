@@ -105,15 +105,16 @@ def test_full_size_counts_and_pixels_match_oracle_on_a_tile_sample(s3_full):
     assert abs(st["prim_tests"] - rc["prim_tests"]) <= rc["prim_tests"] // 5000 + 4
 
 
-@pytest.mark.parametrize("world", [2, 8])
-def test_full_size_tile_shards_reassemble_bit_exactly(gpu_ctx, s3_full, world):
-    """The multi-GPU data path on one GPU: each 'rank' renders its round-robin tiles into a dense payload, the payloads are
-    blitted into a frame -- identical to the whole-frame render, bit for bit."""
+@pytest.mark.parametrize("world,pct", [(2, 0), (8, 0), (8, 60), (3, 70)])
+def test_full_size_tile_shards_reassemble_bit_exactly(gpu_ctx, s3_full, world, pct):
+    """The multi-GPU data path on one GPU: each 'rank' renders its tiles (round robin, or rank 0 with less than a fair share:
+    rank0_share_pct) into a dense payload, the payloads are blitted into a frame -- identical to the whole-frame render, bit
+    for bit."""
     import torch
     sd, sc = s3_full
     cam, lights = product_camera_lights(sd)
     dev = torch.device("cuda:0")
-    P = api.render_params(width=1920, height=1080, maxdepth=1)
+    P = api.render_params(width=1920, height=1080, maxdepth=1, rank0_share_pct=pct)
     whole = torch.zeros((1080, 1920, 5), dtype=torch.float32, device=dev)
     sc.render_dev(cam, lights, P, whole.data_ptr())
     frame = torch.full((1080, 1920, 5), float("nan"), dtype=torch.float32, device=dev)

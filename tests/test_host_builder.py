@@ -150,3 +150,34 @@ def test_no_gpu_means_loud_failure_not_fallback(built):
         api.Context(0)
     src = "".join(open(os.path.join(ROOT, "glome_amd", f)).read() for f in os.listdir(os.path.join(ROOT, "glome_amd")) if f.endswith(".py"))
     assert "oracle" not in src.replace("# the oracle", "")  # the product package never imports the checker
+
+
+@pytest.mark.parametrize("world,pct", [(2, 90), (3, 70), (4, 75), (8, 60), (8, 35), (5, 0), (8, 100)])
+def test_weighted_shards_partition_the_frame(built, world, pct):
+    """glome_render_params.rank0_share_pct: every tile of the frame belongs to exactly one rank, rank 0 owns about the stated
+    percentage of a fair share, the other ranks' shares differ by a few tiles at most, and no rank owns long runs of
+    neighbouring tiles (the pattern interleaves)."""
+    from glome_amd import dist
+    P = api.render_params(width=1920, height=1080, blocksize=64, rank0_share_pct=pct)
+    whole = dist.owned_layout(api.render_params(width=1920, height=1080, blocksize=64), 0, 1)
+    seen = {}
+    counts = []
+    for r in range(world):
+        lay = dist.owned_layout(P, r, world)
+        counts.append(len(lay))
+        for x, y, w, h, base in lay:
+            assert (x, y) not in seen
+            seen[(int(x), int(y))] = r
+        assert dist.payload_floats(P, r, world) == 5 * int((lay[:, 2] * lay[:, 3]).sum())
+    assert len(seen) == len(whole)
+    fair = len(whole) / world
+    if pct in (0, 100):
+        order = [seen[(int(x), int(y))] for x, y, _, _, _ in whole]
+        assert order == [k % world for k in range(len(whole))]  # plain round robin, as before
+    else:
+        want0 = len(whole) * (pct / 100.0) / (pct / 100.0 + world - 1)
+        assert abs(counts[0] - want0) <= 0.08 * fair + 2, (counts, want0)
+        assert max(counts[1:]) - min(counts[1:]) <= 2, counts
+        order = [seen[(int(x), int(y))] for x, y, _, _, _ in whole]
+        runs = max(len(list(g)) for _, g in __import__("itertools").groupby(order))
+        assert runs <= 2, runs

@@ -246,61 +246,7 @@ def portal():
 ALL["portal"] = portal
 
 
-def _polyhedron(sd, points, pos, r, name):
-    """TestScene.hs:29-54: a sphere cut by one plane per direction"""
-    pos = np.array(pos, dtype=np.float64)
-    planes = []
-    for p in points:
-        n = np.array(p, dtype=np.float64)
-        n = n / np.sqrt(n @ n)
-        planes.append(sd.plane_offset(n, r + float(n @ pos)))
-    return sd.tag(sd.intersection([sd.sphere(pos, 1.26 * r)] + planes), name)
-
-
-def testscene(lattice_n=10):
-    """GlomeView's own default scene, `geom''` of TestScene.hs:183-197 with TestScene's lights, camera and textures --
-    every item but the `oak` (TestScene.hs:68-110 draws its branching from System.Random, which is not part of the
-    reference tree): the chessboard of 64 textured boxes carved by a sphere (a Difference whose first operand is a
-    transformed group), the dodecahedron and the transformed icosahedron (Intersections of a sphere with 12 / 20 planes)
-    under the stripe and the perlin Blend textures, a cone, the lattice of (2n+1)^3 spheres under its own bih, rotated,
-    scaled and hollowed out by a sphere, the portal (a Warp material looking into this very scene) inside a transform, and
-    a refracting sphere squashed by a non-uniform scale.  Nesting reaches four composite levels below the root bih."""
-    sd = SceneDesc()
-    m = scenes.materials(sd)
-    dull_gray = sd.material_surface((0.4, 0.3, 0.35), 1, 0.2, 0.8, 0, 0)                                        # :211
-    mottled = sd.material_blend_fn(m["mirror"], scenes.matte(sd, (0.15, 0.3, 0.5)), api.WEIGHT_PERLIN, [3.0])  # :213-220
-    stripe = sd.material_blend_fn(m["shiny_white"], dull_gray, api.WEIGHT_STRIPE_TRIANGLE, [4, 8, 5])          # :225-231
-    # chessboard, TestScene.hs:140-150
-    xs = [-3.5 + i for i in range(8)]
-    squares = []
-    for x in xs:
-        for z in xs:
-            white = (int(np.floor(x)) + int(np.floor(z))) % 2 == 0
-            squares.append(sd.tex(sd.box((x - 0.5, -3, z - 0.5), (x + 0.5, (x * z) / 40, z + 0.5)), m["shiny_white"] if white else mottled))
-    chessboard = sd.group(squares)
-    carved_board = sd.difference(sd.transform(chessboard, [api.scale((2, 1.2, 2))]), sd.tex(sd.sphere((4, 1.5, 3), 3.5), m["shiny_white"]))  # :185
-    gr = (1 + 5 ** 0.5) / 2
-    r = 1.0
-    dod_pts = [(0, y, z) for y in (-r, r) for z in (-gr * r, gr * r)] + [(x, 0, z) for z in (-r, r) for x in (-gr * r, gr * r)] + \
-              [(x, y, 0) for x in (-r, r) for y in (-gr * r, gr * r)]
-    dodeca = sd.tex(_polyhedron(sd, dod_pts, (-6, 3, 0), r, "dodecahedron"), stripe)                              # :186
-    r = 1.5
-    ico_pts = [(x, y, z) for x in (-r, r) for y in (-r, r) for z in (-r, r)] + [(0, y, z) for y in (-r / gr, r / gr) for z in (-gr * r, gr * r)] + \
-              [(x, y, 0) for x in (-r / gr, r / gr) for y in (-gr * r, gr * r)] + [(x, 0, z) for x in (-gr * r, gr * r) for z in (-r / gr, r / gr)]
-    icosa = sd.tex(sd.transform(_polyhedron(sd, ico_pts, (4, 1.5, 3), r, "icosahedron"), [api.rotate((0, 0, 1), api.deg(11)), api.rotate((1, 0, 0), api.deg(7))]), mottled)  # :187-188
-    cone = sd.cone((-6, -1, 0), 0.7, (-6, 3, 0), 0)                                                              # :189
-    n = int(lattice_n)
-    lattice = sd.bih([sd.sphere((float(x), float(y), float(z)), 0.2) for x in range(-n, n + 1) for y in range(-n, n + 1) for z in range(-n, n + 1)])  # :21-26
-    hollow = sd.tex(sd.difference(sd.transform(lattice, [api.rotate((0, 0, 1), api.deg(23)), api.rotate((1, 0, 0), api.deg(43)), api.scale((3, 3, 3))]),
-                                  sd.sphere((0, 0, 0), 3.2 * n)), m["shiny_red"])                                 # :191-193 (sphere 32 for n = 10)
-    # portal 5 2 (1/3), TestScene.hs:152-181, 194-195
-    w, h, th, dl = 2.0, 5.0, 1.0 / 3.0, 1e-4
-    frame = sd.tag(sd.tex(sd.difference(sd.box((-w, 0, -th), (w, h, th)), sd.box((th - w, th, -(th + dl)), (w - th, h - th, th + dl))), scenes.matte(sd, (0.4, 0.4, 0.8))), "door frame")
-    surface = sd.box((-w, 0, -dl), (w, h - dl, dl))
-    warp = sd.material_warp(frame, None, scenes.LIGHTS, api.compose([api.rotate((1, 0, 0), api.deg(-85)), api.translate((8, 40, -4))]))
-    door = sd.transform(sd.group([frame, sd.tex(surface, warp)]), [api.rotate((0, 1, 0), api.deg(8)), api.translate((-3, 0.5, -5))])
-    glass = sd.transform(sd.tex(sd.sphere((-2.3, 0.3, 4.2), 1.7), sd.material_refract(0.35, 0.8, 1.5)), [api.scale((1, 0.4, 1))])  # :196
-    return _finish(sd, sd.bih([carved_board, dodeca, icosa, cone, hollow, door, glass]))
+testscene = scenes.testscene  # GlomeView's default scene (TestScene.hs:183-197), in glome_amd/scenes.py so bench.py can time it
 
 
 ALL["testscene"] = lambda: testscene(4)  # (a 9x9x9 lattice keeps the CPU oracle's frames in seconds; the GPU tests also run the 21x21x21 one)
