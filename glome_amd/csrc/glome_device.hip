@@ -647,7 +647,10 @@ glome_ctx* glome_ctx_create(int device_ordinal) {
     delete c;
     return nullptr;
   }
-  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+  // The context's own stream is a BLOCKING stream: work a caller put on the device's default stream (filling or allocating
+  // the very buffers it hands to a *_dev entry point) is ordered before this context's launches and after them, as with any
+  // HIP code that never names a stream.  A caller that wants overlap brings its own streams (glome_ctx_use_slot).
+  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamDefault)) != hipSuccess) return fail("hipStreamCreate", e);
   c->own_stream = c->stream;
   if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return fail("hipEventCreate", e);
   if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return fail("hipEventCreate", e);

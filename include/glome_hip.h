@@ -44,6 +44,9 @@ enum glome_status {
 };
 
 /* ---- context ---- */
+/* The context launches on a stream of its own, created as a blocking stream: it is ordered against the device's default
+ * (null) stream in both directions, so buffers a caller prepared there may be handed to the *_dev entry points directly.
+ * Work on the caller's own non-blocking streams is the caller's to order (or the stream is given to glome_ctx_use_slot). */
 glome_ctx* glome_ctx_create(int device_ordinal); /* NULL on failure; see glome_global_error() */
 void glome_ctx_destroy(glome_ctx*);
 const char* glome_last_error(const glome_ctx*);
