@@ -3,7 +3,7 @@
 # usage: tools/run_configs.sh [--no-cpu]
 mkdir -p gpurun_out/configs
 extra=$1
-for spec in "S1 0" "S2 0" "S2 1" "S3 0" "S3mesh 0" "S4 0" "S3 1" "S5 0" "S5 1" "TS 0" "TS 1"; do
+for spec in "S1 0" "S2 0" "S2 1" "S3 0" "S3mesh 0" "S4 0" "S3 1" "S5 0" "S5mesh 0" "S5 1" "TS 0" "TS 1"; do
   set -- $spec
   timeout -k 10 400 python bench.py --scene $1 --mode $2 $extra > gpurun_out/configs/$1_mode$2.json 2> gpurun_out/configs/$1_mode$2.err || echo "FAILED $1 $2"
   tail -c 400 gpurun_out/configs/$1_mode$2.err | grep -v amdgpu.ids | tail -2
