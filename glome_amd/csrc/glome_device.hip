@@ -1043,15 +1043,19 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
     bool full = s->has_nested_mats || (s->has_secondary_mats && P->maxdepth > 1);
     bool tri = s->dev.tier == 0 && (s->cls_mask & ~CLS_BIH_TRI) == 0;
     const uint32_t items = ss_plan(A).first[6] * kSSHeads;
+    const bool big_tree = s->info.n_bih_nodes > 500000;
     // (a wave that is not resident yet holds no item, so the items a running wave waits for are always with running waves)
     // (the sampler's items are long -- a region's contrast tests and one or more packet walks -- so the grid is sized for ~4 per wave)
-    int tgrid = persistent_grid(ctx, lds, (uint32_t)std::min<uint64_t>((uint64_t)items * 16, 0x7fffffffu), two_rows ? 16 : 32, grid_floor(s));
+    int tgrid = persistent_grid(ctx, lds, (uint32_t)std::min<uint64_t>((uint64_t)items * 16, 0x7fffffffu), two_rows ? (big_tree ? 20 : 16) : 32, grid_floor(s));
     tgrid = (int)std::min<uint32_t>((uint32_t)tgrid, items);
     if (s->dev.tier == 0 && (rc = ensure_overflow(ctx, tgrid, 1, s->ovf_cap))) return rc;
     uint32_t* ov = ctx->slot().d_ovf;
     dim3 g(tgrid), blk(64);
     if (s->dev.tier != 0) hipLaunchKernelGGL(k_ss_frame_generic, g, blk, 0, ctx->stream, A);
-    // (four waves per SIMD: with 80 registers the sampler's own state spills, and every reload waits for the loads in flight)
+    // (four waves per SIMD: with 80 registers the sampler's own state spills, and every reload waits for the loads in flight;
+    // a tree of a million nodes misses the caches often enough that a fifth wave pays for the spills of 96 registers:
+    // S5 2.28 -> 2.12 ms per frame, S3 0.294 -> 0.310)
+    else if (two_rows && big_tree) hipLaunchKernelGGL((k_ss_frame_flat<false, CLS_BIH_TRI, 5, true>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
     else if (two_rows) hipLaunchKernelGGL((k_ss_frame_flat<false, CLS_BIH_TRI, 4, true>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
     else if (tri && !full) hipLaunchKernelGGL((k_ss_frame_flat<false, CLS_BIH_TRI>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
     else if (tri) hipLaunchKernelGGL((k_ss_frame_flat<true, CLS_BIH_TRI>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
