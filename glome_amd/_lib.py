@@ -24,6 +24,9 @@ class Light(C.Structure):  # glome_light
     _fields_ = [("pos", C.c_float * 3), ("color", C.c_float * 3), ("rad", C.c_float), ("shadow", C.c_int32)]
 
 
+OK, E_INVALID, E_SCENE, E_NO_DEVICE, E_HIP, E_LIMIT = 0, -1, -2, -3, -4, -5  # glome_status
+
+
 class RenderParams(C.Structure):  # glome_render_params
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("mode", C.c_int32), ("blocksize", C.c_int32),
                 ("maxdepth", C.c_int32), ("fog", C.c_int32), ("thresholds", C.c_float * 4), ("tile_first", C.c_int32),

@@ -790,3 +790,65 @@ def test_multi_gpu_c_abi_frames_equal_the_single_gpu_frames(gpu_ctx, n):
         s_.release()
     for c in ctxs[1:]:
         c.close()
+
+
+# ------------------------------------------------------------------ edge cases: empty, tiny and ragged inputs, refused parameters
+def test_empty_and_tiny_inputs_through_the_c_abi(gpu_ctx):
+    """An empty ray batch; a scene that is an empty group (every ray misses: transparent pixels at depth = infinity, Shader.hs:
+    186-187); frames smaller than one 8x8 work item and than one tile, in both render modes, against the oracle; a shard that
+    owns no tile at all (more ranks than tiles)."""
+    from glome_amd.scene import SceneDesc
+    sd = scenes.s1(nlights=2)
+    b, nm, sc = commit(gpu_ctx, sd)
+    none = sc.rayint(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
+    assert none["t"].shape == (0,) and sc.shadow(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), np.zeros(0, np.float32)).shape == (0,)
+    assert sc.inside(np.zeros((0, 3), np.float32)).shape == (0,)
+    cam, lights = product_camera_lights(sd)
+    o, om, _ = oracle_for(sd)
+    for (w, h) in ((1, 1), (7, 3), (9, 70), (66, 5)):
+        for mode in (0, 1):
+            img, packed, st = sc.render(cam, lights, api.render_params(width=w, height=h, maxdepth=1, mode=mode))
+            ref, _, rc = o.render(w, h, maxdepth=1, mode=mode, want_packed=False)
+            e = np.abs(img[..., :4] - ref[..., :4]) / np.maximum(1, np.abs(ref[..., :4]))
+            assert e.max() <= 2e-4 and st["rays_primary"] == rc["rays_primary"], (w, h, mode, float(e.max()))
+    # a shard with nothing to do: rank 5 of 7 on a one-tile frame
+    init = np.full((40, 50, 5), 7.0, np.float32)
+    img, _, st = sc.render(cam, lights, api.render_params(width=50, height=40, maxdepth=1, tile_first=5, tile_stride=7), want_packed=False, init=init)
+    assert st["n_tiles"] == 0 and st["rays_primary"] == 0 and np.all(img == 7.0)
+    sc.release()
+    # the empty scene
+    ed = SceneDesc()
+    ed.set_root(ed.group([]))
+    ed.add_light(*scenes.LIGHTS[0]); ed.set_camera(*scenes.CUST_CAM)
+    b, nm, sc = commit(gpu_ctx, ed)
+    ro, rd = random_rays(500, 3)
+    r = sc.rayint(ro, rd)
+    assert np.all(r["t"] == -1) and np.all(r["prim"] == -1) and not sc.shadow(ro, rd, np.full(500, 50.0, np.float32)).any() and not sc.inside(ro).any()
+    cam, lights = product_camera_lights(ed)
+    for mode in (0, 1):
+        img, packed, st = sc.render(cam, lights, api.render_params(width=70, height=33, maxdepth=3, mode=mode))
+        assert np.all(img[..., :4] == 0) and np.all(img[..., 4] == 1e6) and np.all(packed == 0) and st["rays_shadow"] == 0
+    sc.release()
+
+
+def test_refused_parameters_fail_with_a_status_not_a_frame(gpu_ctx):
+    """Out-of-range arguments are refused with a status code and a message (include/glome_hip.h), nothing is rendered."""
+    import torch
+    sd = scenes.s1(nlights=1)
+    b, nm, sc = commit(gpu_ctx, sd)
+    cam, lights = product_camera_lights(sd)
+    la = (L.Light * len(lights))(*lights)
+    buf = torch.zeros((9, 64, 64), dtype=torch.int32, device=torch.device("cuda:0"))
+    for kw in (dict(width=0), dict(height=-3), dict(maxdepth=0), dict(maxdepth=9), dict(blocksize=0), dict(tile_stride=0), dict(tile_first=-1), dict(rank0_share_pct=101)):
+        P = api.render_params(**{**dict(width=64, height=64, maxdepth=1), **kw})
+        rc = sc.lib.glome_render_dev(sc.h, C.byref(cam), la, len(lights), C.byref(P), None, C.c_void_p(buf.data_ptr()), None)
+        assert rc in (L.E_INVALID, L.E_LIMIT) and gpu_ctx.err(), kw
+    P = api.render_params(width=64, height=64, maxdepth=1)
+    cams = (L.Camera * 9)(*[cam] * 9)
+    assert sc.lib.glome_render_packed_batch_dev(sc.h, cams, 9, la, len(lights), C.byref(P), C.c_void_p(buf.data_ptr()), 64 * 64, None) == L.E_LIMIT  # 1..8 frames
+    assert sc.lib.glome_render_packed_batch_dev(sc.h, cams, 2, la, len(lights), C.byref(P), C.c_void_p(buf.data_ptr()), 0, None) == L.E_INVALID   # frame stride
+    too_many = (L.Light * 9)(*[lights[0]] * 9)
+    assert sc.lib.glome_render_dev(sc.h, C.byref(cam), too_many, 9, C.byref(P), None, C.c_void_p(buf.data_ptr()), None) in (L.E_INVALID, L.E_LIMIT)
+    gpu_ctx.synchronize()
+    assert int(buf.abs().sum()) == 0
+    sc.release()
