@@ -119,6 +119,54 @@ def test_two_rank_tile_sharding_reassembles_the_frame(built, tmp_path):
         assert np.array_equal(pf[k], ref), k
 
 
+def _weighted_worker(rank, world, port, outdir, pct):
+    """three ranks, rank 0 with less than a fair share (glome_render_params.rank0_share_pct): payload sizes differ per rank,
+    the gather pads to the largest"""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as tdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    from helpers import oracle_for
+    from glome_amd import api, dist, scenes
+    sd = scenes.s1(nlights=1)
+    o, om, _ = oracle_for(sd)
+    P = api.render_params(width=W, height=H, maxdepth=1, blocksize=16, rank0_share_pct=pct)  # 13 x 10 tiles
+    plan = dist.ShardPlan(P, rank, world, unit=1)
+    _, whole_px, _ = o.render(W, H, maxdepth=1, want_packed=True)  # (the oracle has no weighted shards: every rank packs its tiles of the whole frame)
+    lay = plan.layout(rank)
+    pk = dist.pack_numpy(whole_px.astype(np.int64), lay)
+    assert pk.size == plan.sizes[rank]
+    pay = torch.zeros(plan.maxp, dtype=torch.int64)
+    pay[:pk.size] = torch.from_numpy(pk)
+    gat = torch.zeros((world, plan.maxp), dtype=torch.int64) if rank == 0 else None
+    plan.gather(pay, gat)
+    if rank == 0:
+        fpx = np.full((H, W), -1, np.int64)
+        for r in range(world):
+            dist.blit_numpy(fpx, gat[r].numpy(), plan.layout(r))
+        np.save(os.path.join(outdir, "weighted.npy"), fpx)
+        np.save(os.path.join(outdir, "weighted_sizes.npy"), np.array(plan.sizes))
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+def test_three_ranks_with_a_weighted_share_reassemble_the_frame(built, tmp_path):
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_weighted_worker, args=(3, port, str(tmp_path), 60), nprocs=3, join=True)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import oracle_for
+    from glome_amd import scenes
+    o, om, _ = oracle_for(scenes.s1(nlights=1))
+    _, whole_px, _ = o.render(W, H, maxdepth=1, want_packed=True)
+    assert np.array_equal(np.load(tmp_path / "weighted.npy"), whole_px.astype(np.int64))
+    sizes = np.load(tmp_path / "weighted_sizes.npy")
+    assert sizes.sum() == W * H and sizes[0] < 0.8 * sizes[1] and abs(int(sizes[1]) - int(sizes[2])) <= 2 * 16 * 16
+
+
 def test_shard_plan_partitions_tiles(built):
     from glome_amd import api, dist
     for (w, h, world) in [(720, 480, 8), (1920, 1080, 8), (3840, 2160, 8), (200, 150, 3), (64, 64, 2)]:
