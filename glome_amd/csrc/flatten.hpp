@@ -311,6 +311,8 @@ class Flattener {
           if (!T.nodes[b.left].leaf && ng < 4) group[ng++] = b.left;
           if (!T.nodes[b.right].leaf && ng < 4) group[ng++] = b.right;
         }
+        // a treelet never straddles a cache line: one that would is started on the next line (the skipped slots stay unused)
+        if ((nslots & 3u) + (uint32_t)ng > 4u) nslots = (nslots + 3u) & ~3u;
         for (int q = 0; q < ng; q++) slot[group[q]] = nslots++;
         // branch children of the group's members that did not fit start treelets of their own; right pushed first so the
         // left subtree is laid out next

@@ -980,7 +980,7 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
   // a whole renderTile frame in image layout: the pixels are independent and every tile is owned, so the tile size only
   // decides how the work is cut.  64x64 tiles are all 8x8 blocks -- no thin leftover strips (a 65x65 tile has 129
   // pixels in a column and a row, whose 64-pixel items are the least coherent and slowest of the frame)
-  const bool whole = P->mode == GLOME_MODE_TILE && dense == 0 && P->tile_first == 0 && P->tile_stride == 1 && !getenv("GLOME_NO_RETILE");
+  const bool whole = P->mode == GLOME_MODE_TILE && dense == 0 && P->tile_first == 0 && P->tile_stride == 1;
   if ((rc = get_tiles(ctx, P, P->tile_first, P->tile_stride, &tt, whole ? 64 : 0))) return rc;
   DRenderArgs A;
   memset(&A, 0, sizeof(A));
