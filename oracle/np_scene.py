@@ -640,6 +640,77 @@ class Scene:
             out.append(row)
         return out
 
+    # ---- renderTileSubsample, Glome.hs:179-323, over the tile map of renderTiles (:371-386)
+    def get_color(self, xc, yc, maxdepth):  # Glome.hs:27-33 + 53-55: (ColorA, depth) of one camera-space sample
+        pos, fwd, up, right = self.cam
+        v = (fwd[0] + right[0] * (-xc) + up[0] * yc, fwd[1] + right[1] * (-xc) + up[1] * yc, fwd[2] + right[2] * (-xc) + up[2] * yc)
+        self.rays[0] += 1
+        c, hit = self.trace(self.nodes[self.root], pos, vnorm(v), INF, maxdepth)
+        return (c[0], c[1], c[2], c[3], ridepth(hit))
+
+    def render_subsample(self, width, height, maxdepth, blocksize=65, thresholds=(0.14, 0.15, 0.16, 0.18)):
+        """renderTiles with renderTileSubsample: every tile of `chunk width blocksize` x `chunk height blocksize` sampled
+        adaptively in its own buffer (neighbours outside the tile read (0,0,0,0,infinity)), then blitted."""
+        self.rays = [0, 0, 0]
+        blank = (0.0, 0.0, 0.0, 0.0, INF)
+
+        def chunk(size):  # :371-377
+            out, pos = [], 0
+            while True:
+                if pos + blocksize >= size:
+                    out.append((pos, size - pos)); return out
+                out.append((pos, blocksize)); pos += blocksize
+
+        def coords(xf, yf):  # getCoords / getCoordsf, :119-140
+            return (((xf / width) * 2) - 1) * (width / height), -(((yf / height) * 2) - 1)
+
+        def ccmp(p, q):  # cCmp, :179-189
+            def muldiff(a, b):
+                if a == 0 and b == 0: return 0.0
+                return (fdiv(a, b) - 1) if a > b else (fdiv(b, a) - 1)
+            return abs(q[0] - p[0]) + abs(q[1] - p[1]) + abs(q[2] - p[2]) + abs(q[3] - p[3]) + muldiff(p[4], q[4])
+
+        def cavg(a, b, c, d): return tuple((a[k] + b[k] + c[k] + d[k]) * 0.25 for k in range(5))  # :191-197
+        def cavg2(a, b): return tuple((a[k] + b[k]) * 0.5 for k in range(5))                         # :199-205
+
+        def decide(thr, xf, yf, a, b, c, d):  # :213-219
+            if fmax(ccmp(a, c), ccmp(b, d)) > thr: return self.get_color(*coords(xf, yf), maxdepth)
+            return cavg(a, b, c, d)
+
+        frame = [[None] * width for _ in range(height)]
+        for (xt, tw) in chunk(width):
+            for (yt, th) in chunk(height):
+                v = {}
+
+                def getc(buf, x, y):
+                    if xt <= x < xt + tw and yt <= y < yt + th: return buf.get((x, y), blank)  # MUV.replicate ... blank
+                    return blank
+
+                t1, t2, t3, t4 = thresholds
+                for x in range(xt, xt + tw, 2):          # :241-250: the even lattice, (dx + dy) mod 4 == 0, always traced
+                    for y in range(yt, yt + th, 2):
+                        if ((x - xt) + (y - yt)) % 4 == 0: v[(x, y)] = self.get_color(*coords(float(x), float(y)), maxdepth)
+                for x in range(xt, xt + tw, 2):          # :251-263: the rest of the even lattice from its 4 neighbours two away
+                    for y in range(yt, yt + th, 2):
+                        if ((x - xt) + (y - yt)) % 4 == 2:
+                            v[(x, y)] = decide(t1, float(x), float(y), getc(v, x - 2, y), getc(v, x, y + 2), getc(v, x + 2, y), getc(v, x, y - 2))
+                for x in range(xt + 1, xt + tw, 2):      # :273-283: odd-odd pixels from their diagonals
+                    for y in range(yt + 1, yt + th, 2):
+                        v[(x, y)] = decide(t2, float(x), float(y), getc(v, x - 1, y - 1), getc(v, x + 1, y - 1), getc(v, x + 1, y + 1), getc(v, x - 1, y + 1))
+                for x in range(xt, xt + tw):             # :285-297: the remaining pixels from their 4 neighbours
+                    for y in range(yt, yt + th):
+                        if ((x - xt) + (y - yt)) % 2 == 1:
+                            v[(x, y)] = decide(t3, float(x), float(y), getc(v, x - 1, y), getc(v, x, y + 1), getc(v, x + 1, y), getc(v, x, y - 1))
+                v2 = {}
+                for x in range(xt, xt + tw):             # :299-319: supersample between pixels, blend into the copy
+                    for y in range(yt, yt + th):
+                        a, b, c, d = getc(v, x, y), getc(v, x, y + 1), getc(v, x + 1, y + 1), getc(v, x + 1, y)
+                        color = decide(t4, x + 0.5, y + 0.5, a, b, c, d)
+                        if x == xt + tw - 1: v2[(x, y)] = color if y == yt + th - 1 else cavg2(color, cavg2(a, b))
+                        else: v2[(x, y)] = cavg2(color, cavg2(a, d)) if y == yt + th - 1 else cavg2(color, cavg(a, b, c, d))
+                for (x, y), c in v2.items(): frame[y][x] = c
+        return frame
+
 
 def load(sd):
     """SceneDesc -> Scene (the same constants the C++ oracle and the product receive)."""

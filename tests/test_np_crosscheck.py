@@ -158,6 +158,30 @@ def test_whole_frames_of_two_independent_restatements_agree(built, name, w, h, m
     assert sc.rays == [rc["rays_primary"], rc["rays_shadow"], rc["rays_secondary"]]
 
 
+@pytest.mark.parametrize("name,w,h,bs,md", [("S1", 75, 40, 65, 1), ("S3small", 37, 29, 16, 1), ("S4", 40, 22, 65, 3)])
+def test_adaptive_sampler_of_two_independent_restatements_agrees(built, name, w, h, bs, md):
+    """renderTileSubsample over renderTiles' tile map (Glome.hs:226-323, 371-386) twice: the C++ oracle's pass loops against
+    np_scene.render_subsample, written from the Haskell text in its own shape (one dictionary per tile, getc / putc, the five
+    loops in the reference's order).  Same pixels to rounding, same number of samples traced -- one frame wider than a tile
+    (clipped second tile column), one of several small ragged tiles, one with reflections."""
+    from helpers import oracle_for, product_camera_lights
+    from oracle import np_scene as NS
+    from glome_amd import scenes
+    sd = {"S1": lambda: scenes.s1(nlights=2), "S3small": lambda: scenes.s3(12), "S4": scenes.s4}[name]()
+    o, om, _ = oracle_for(sd)
+    ref, _, rc = o.render(w, h, maxdepth=md, mode=1, blocksize=bs, want_packed=False)
+    sc, nm = NS.load(sd)
+    cam, _ = product_camera_lights(sd)
+    sc.set_camera_vectors([float(x) for x in cam.pos], [float(x) for x in cam.fwd], [float(x) for x in cam.up], [float(x) for x in cam.right])
+    got = np.array(sc.render_subsample(w, h, md, blocksize=bs))
+    assert got.shape == ref.shape
+    assert sc.rays == [rc["rays_primary"], rc["rays_shadow"], rc["rays_secondary"]]  # the same contrast decisions everywhere
+    fin = np.isfinite(ref[..., 4]) & (ref[..., 4] < 1e5)
+    assert np.array_equal(np.isfinite(got[..., 4]) & (got[..., 4] < 1e5), fin)
+    assert np.allclose(got[..., :4], ref[..., :4], rtol=1e-10, atol=1e-12), float(np.abs(got[..., :4] - ref[..., :4]).max())
+    assert np.allclose(got[..., 4][fin], ref[..., 4][fin], rtol=1e-10)
+
+
 def test_bih_trees_of_two_independent_builders_are_the_same(built):
     """build_rec (Bih.hs:211-285) twice: the oracle's tree (through the product's host builder, which test_host_builder pins
     to the oracle's) against np_scene's, node for node -- split planes, axes, leaf contents in order."""
