@@ -155,7 +155,7 @@ class Sphere(Solid):  # Sphere.hs
         hit = (v - sq) if (v - sq) > 0 else (v + sq)
         if hit < 0 or hit > dist: return None
         p = vscaleadd(o, d, hit)
-        return (hit, p, vnorm(vsub(p, self.c)), texs, self.uid)
+        return (hit, p, vnorm(vsub(p, self.c)), texs, self.uid, (o, d))  # (.., riray: the ray as this solid received it)
     def shadow(self, o, d, dist):  # :51-71
         eo = vsub(self.c, o)
         v = vdot(eo, d)
@@ -192,7 +192,7 @@ class Triangle(Solid):  # Triangle.hs
         r = tri_core(*self.p, o, d, dist)
         if r is None: return None
         e1, e2 = vsub(self.p[1], self.p[0]), vsub(self.p[2], self.p[0])
-        return (r[0], vscaleadd(o, d, r[0]), vnorm(vcross(e1, e2)), texs, self.uid)  # :73: not flipped toward the viewer (Q5)
+        return (r[0], vscaleadd(o, d, r[0]), vnorm(vcross(e1, e2)), texs, self.uid, (o, d))  # :73: not flipped toward the viewer (Q5)
     def shadow(self, o, d, dist): return tri_core(*self.p, o, d, dist) is not None  # :82-107
     def bound(self):  # :147-158
         return (tuple(fmin(fmin(self.p[0][k], self.p[1][k]), self.p[2][k]) - DELTA for k in range(3)),
@@ -214,10 +214,10 @@ class Box(Solid):  # Box.hs
         if lastin < 0:  # origin inside: the exit face, normal along the direction
             k = 0 if outs[0] == firstout else (1 if outs[1] == firstout else 2)
             n = axes[k] if d[k] > 0 else vinvert(axes[k])
-            return (firstout, vscaleadd(o, d, firstout), n, texs, self.uid)
+            return (firstout, vscaleadd(o, d, firstout), n, texs, self.uid, (o, d))
         k = 0 if ins[0] == lastin else (1 if ins[1] == lastin else 2)
         n = vinvert(axes[k]) if d[k] > 0 else axes[k]
-        return (lastin, vscaleadd(o, d, lastin), n, texs, self.uid)
+        return (lastin, vscaleadd(o, d, lastin), n, texs, self.uid, (o, d))
     def shadow(self, o, d, dist):  # :56-62
         near, far = bbclip_ub(o, d, self.bb)
         return not (near > far or far <= 0 or far > dist)
@@ -230,7 +230,7 @@ class Plane(Solid):  # Plane.hs
     def rayint(self, o, d, dist, texs):  # :27-32 (Q2: a NaN passes both tests)
         hit = -fdiv(vdot(self.n, o) - self.off, vdot(self.n, d))
         if hit < 0 or hit > dist: return None
-        return (hit, vscaleadd(o, d, hit), self.n, texs, self.uid)
+        return (hit, vscaleadd(o, d, hit), self.n, texs, self.uid, (o, d))
     def inside(self, p): return vdot(vsub(vscale(self.n, self.off), p), self.n) > 0  # :34-38
     def bound(self): return EVERYTHING_BB  # :40-44
 
@@ -292,7 +292,7 @@ class Instance(Solid):  # Solid.hs:386-532
         no, nd, ls = self._local(o, d)
         h = self.s.rayint(no, nd, dist * ls, texs)
         if h is None: return None
-        return (h[0] * (1.0 / ls), xfm_point(self.f, h[1]), vnorm(xfm_tvec(self.i, h[2])), h[3], h[4])
+        return (h[0] * (1.0 / ls), xfm_point(self.f, h[1]), vnorm(xfm_tvec(self.i, h[2])), h[3], h[4], h[5])  # riray stays the local ray (:397-403)
     def shadow(self, o, d, dist):  # :464-471
         no, nd, ls = self._local(o, d)
         return self.s.shadow(no, nd, dist * ls)
@@ -318,7 +318,7 @@ class Difference(Solid):  # Csg.hs
             hb = self.b.rayint(o, d, dist, texs)
             if hb is None: return None
             if self.a.inside(hb[1]) and not self.b.inside(vscaleadd(hb[1], d, DELTA)):
-                return (hb[0], hb[1], vinvert(hb[2]), self.a.get_metainfo(hb[1]), hb[4])  # useatex: textures of A at the point
+                return (hb[0], hb[1], vinvert(hb[2]), self.a.get_metainfo(hb[1]), hb[4], hb[5])  # useatex: textures of A at the point
             return rayint_advance(self, o, d, dist, texs, hb[0])
         ha = self.a.rayint(o, d, dist, texs)
         if ha is None: return None
@@ -471,7 +471,7 @@ class Mesh(Solid):
             r = tri_core(a, b, c, o, d, far)
             if r is None: return None
             tex = texs if self.texi[i] == -1 else (self.texv[self.texi[i]],) + texs  # :148-150
-            return (r[0], vscaleadd(o, d, r[0]), vnorm(vcross(vsub(b, a), vsub(c, a))), tex, self.uid)
+            return (r[0], vscaleadd(o, d, r[0]), vnorm(vcross(vsub(b, a), vsub(c, a))), tex, self.uid, (o, d))
         def traverse(n, near, far):
             if n[0] == "leaf":
                 acc = None
@@ -539,12 +539,17 @@ class Scene:
     def material_refract(self, refl, refr, ior): self.mats.append(("refract", refl, refr, ior)); return len(self.mats) - 1
     def material_layers(self, mats): self.mats.append(("layers", list(mats))); return len(self.mats) - 1
     def material_blend(self, a, b, w): self.mats.append(("blend", a, b, w)); return len(self.mats) - 1
+    def material_warp(self, frame, scene, lights, xfm):  # Shader.hs:47-50; lights: [(pos, colour, radius, shadow)], xfm: the closure's matrix (3x4 forward first)
+        ls = [(tuple(l[0]), tuple(l[1]), l[2], l[3]) for l in lights]
+        self.mats.append(("warp", frame, -1 if scene is None else scene, ls, tuple(float(x) for x in list(xfm)[:12])))
+        return len(self.mats) - 1
+    def tag(self, node): return node  # tags only matter for picking
 
     # ---- Shader.hs
-    def mpreshade(self, sld, hit):  # :65-80 (Q18)
+    def mpreshade(self, sld, hit, lights=None):  # :65-80 (Q18)
         out = []
-        _, p, n, _, _ = hit
-        for (lpos, lcol, rad, do_shadow) in self.lights:
+        p, n = hit[1], hit[2]
+        for (lpos, lcol, rad, do_shadow) in (self.lights if lights is None else lights):
             lvec = vsub(lpos, p)
             if vdot(lvec, n) < 0: continue
             llen = vlen(lvec)
@@ -558,11 +563,11 @@ class Scene:
 
     def mpostshade(self, lz, mat, o, d, sld, hit, recurs):  # :82-184 (Q17)
         m = self.mats[mat]
-        _, p, n, _, _ = hit
+        p, n = hit[1], hit[2]
         eyedir = vinvert(d)
         if m[0] == "surface":
             _, color, alpha, amb, kd, ks, shine = m
-            if lz[0] is None: lz[0] = self.mpreshade(sld, hit)  # lazy ctxb (Trace.hs:63)
+            if lz[0] is None: lz[0] = self.mpreshade(sld, hit, lz[1])  # lazy ctxb (Trace.hs:63)
             rgb = vscale(color, amb)
             direct = (0.0, 0.0, 0.0)
             for (lcolor, ldir) in lz[0]:
@@ -579,33 +584,40 @@ class Scene:
             refl = m[1]
             if refl > 0 and recurs > 0:
                 out = reflect(d, n)
-                c = self.trace(sld, vscaleadd(p, out, DELTA), out, INF, recurs - 1, True)[0]
+                c = self.trace(sld, vscaleadd(p, out, DELTA), out, INF, recurs - 1, True, lz[1])[0]
                 return (c[0], c[1], c[2], c[3] * refl)
             return (0.0, 0.0, 0.0, 1.0)
         if m[0] == "refract":
             _, refl, refr, ior = m
             if (refl > 0 or refr > 0) and recurs > 0:
                 out = reflect(d, n)
-                cr = self.trace(sld, vscaleadd(p, out, DELTA), out, INF, recurs - 1, True)[0]
+                cr = self.trace(sld, vscaleadd(p, out, DELTA), out, INF, recurs - 1, True, lz[1])[0]
                 eta = ior if vdot(n, eyedir) > 0 else 1.0 / ior
                 c1 = vdot(d, n)
                 cs2 = 1 - (eta * eta) * (1 - (c1 * c1))
                 if cs2 < 0: ct = (0.0, 0.0, 0.0, 1.0)
                 else:
                     t = vadd(vscale(d, eta), vscale(n, eta * c1 - math.sqrt(cs2)))
-                    ct = self.trace(sld, vscaleadd(p, t, DELTA), t, INF, recurs - 1, True)[0]
+                    ct = self.trace(sld, vscaleadd(p, t, DELTA), t, INF, recurs - 1, True, lz[1])[0]
                 return tuple(cr[k] * refl + ct[k] * refr for k in range(4))
             return (0.0, 0.0, 0.0, 0.0)
+        if m[0] == "warp":  # Shader.hs:157-175: the frame through the hit's own (local) ray, then the other scene through the
+            _, frame, scene, wlights, xf = m  # warped ray, no farther than the frame's hit; the nearer of the two is shown
+            fcolor, fint = self.trace(self.nodes[frame], hit[5][0], hit[5][1], INF, recurs - 1, True, lz[1])
+            wo = xfm_point(xf, p)
+            wd = vnorm(xfm_vec(xf, vnorm(d)))  # xfm ray hit = xfm_ray M (Ray (pos hit) (vnorm (dir ray))), TestScene.hs:166-172
+            wcolor, wint = self.trace(sld if scene < 0 else self.nodes[scene], wo, wd, ridepth(fint), recurs - 1, True, wlights)
+            return fcolor if ridepth(fint) < ridepth(wint) else wcolor
         if m[0] == "layers": return casum([self.mpostshade(lz, k, o, d, sld, hit, recurs) for k in m[1]])
         if m[0] == "blend": return caweight(self.mpostshade(lz, m[1], o, d, sld, hit, recurs), self.mpostshade(lz, m[2], o, d, sld, hit, recurs), m[3])
         raise ValueError(m[0])
 
-    def trace(self, sld, o, d, depth, recurs, secondary=False):  # Trace.hs:59-82 (Q16) -> (ColorA, Rayint)
+    def trace(self, sld, o, d, depth, recurs, secondary=False, lights=None):  # Trace.hs:59-82 (Q16) -> (ColorA, Rayint)
         if recurs == 0: return (0.0, 0.0, 0.0, 0.0), None
         if secondary: self.rays[2] += 1
         hit = sld.rayint(o, d, depth, ())
         if hit is None: return (0.0, 0.0, 0.0, 0.0), None
-        lz = [None]
+        lz = [None, lights]  # (the lazily evaluated light list of this hit, the Light list it is made from)
         acc = (0.0, 0.0, 0.0, 0.0)
         for t in hit[3]:
             if acc[3] + DELTA >= 1: break  # opaque (Trace.hs:50-51)
