@@ -305,6 +305,118 @@ class Instance(Solid):  # Solid.hs:386-532
         return self.s.transform((mat_mult(xf[0], self.f), mat_mult(self.i, xf[1])))
 
 
+NVZ, VZ = (0.0, 0.0, -1.0), (0.0, 0.0, 1.0)
+
+
+def disc_hit(point, norm, r2, o, d, dist):  # rayint_disc / shadow_disc, Cone.hs:69-91: the distance, or None
+    t = fdiv(-vdot(norm, vsub(o, point)), vdot(norm, d))  # plane_int_dist, Vec.hs:391-394
+    if t < 0 or t > dist: return None
+    off = vsub(vscaleadd(o, d, t), point)
+    return None if vdot(off, off) > r2 else t
+
+
+class Cone(Solid):  # the canonical cone on the z axis (Cone.hs:155-251): radius r at z = 0, apex at z = height, kept between clip1 and clip2
+    def __init__(self, r, clip1, clip2, height): self.r, self.c1, self.c2, self.h = r, clip1, clip2, height
+    def _side(self, o, d, dist):  # the quadratic of rayint_cone / shadow_cone: the distance to the infinite cone, or None
+        r, height = self.r, self.h
+        k = fdiv(r, height); k = k * k
+        ox, oy, oz = o; dx, dy, dz = d
+        a = dx * dx + dy * dy - k * dz * dz
+        b = 2 * (dx * ox + dy * oy - k * dz * (oz - height))
+        c = ox * ox + oy * oy - k * (oz - height) * (oz - height)
+        disc = b * b - 4 * a * c
+        if disc < 0: return None
+        ds = math.sqrt(disc)
+        q = (b - ds) * (-0.5) if b < 0 else (b + ds) * (-0.5)
+        t0_, t1_ = fdiv(q, a), fdiv(c, q)
+        t0, t1 = fmin(t0_, t1_), fmax(t0_, t1_)
+        if t1 < 0 or t0 > dist: return None
+        t = t1 if t0 < 0 else t0
+        return None if (t < 0 or t > dist) else t
+    def _cap(self, o, d, dist):  # which end disc the ray can still reach when the side hit lies outside the clips (:181-191)
+        if d[2] > 0: return ((0.0, 0.0, self.c1), NVZ, self.r * self.r) if o[2] < self.c1 else None
+        if o[2] > self.c2:
+            r2 = self.r * (1 - fdiv(self.c2 - self.c1, self.h))
+            return ((0.0, 0.0, self.c2), VZ, r2 * r2)
+        return None
+    def rayint(self, o, d, dist, texs):
+        t = self._side(o, d, dist)
+        if t is None: return None
+        pos = vscaleadd(o, d, t)
+        if pos[2] > self.c1 and pos[2] < self.c2:
+            invhyp = 1 / math.sqrt(self.h * self.h + self.r * self.r)
+            up, out = self.r * invhyp, self.h * invhyp
+            corr = fdiv(out, math.sqrt(pos[0] * pos[0] + pos[1] * pos[1]))
+            return (t, pos, (pos[0] * corr, pos[1] * corr, up), texs, self.uid, (o, d))
+        cap = self._cap(o, d, dist)
+        if cap is None: return None
+        td = disc_hit(cap[0], cap[1], cap[2], o, d, dist)
+        return None if td is None else (td, vscaleadd(o, d, td), cap[1], texs, self.uid, (o, d))
+    def shadow(self, o, d, dist):
+        t = self._side(o, d, dist)
+        if t is None: return False
+        z = o[2] + d[2] * t
+        if z > self.c1 and z < self.c2: return True
+        cap = self._cap(o, d, dist)
+        return cap is not None and disc_hit(cap[0], cap[1], cap[2], o, d, dist) is not None
+    def inside(self, p):  # :244-247
+        r = self.r * (1 - fdiv(p[2] - self.c1, self.h))
+        return p[2] > self.c1 and p[2] < self.c2 and p[0] * p[0] + p[1] * p[1] < r * r
+    def bound(self): return ((-self.r, -self.r, self.c1), (self.r, self.r, self.c2))  # :249-251
+
+
+def orth(v1):  # Vec.hs:366-378
+    dvx = v1[0]
+    v2 = vnorm(vcross(v1, (1.0, 0.0, 0.0))) if (dvx < 0.8 and dvx > -0.8) else vnorm(vcross(v1, (0.0, 1.0, 0.0)))
+    return v2, vcross(v1, v2)
+
+
+def xyz_to_uvw(u, v, w):  # Vec.hs:602-623: (forward, inverse)
+    return (u[0], v[0], w[0], 0.0, u[1], v[1], w[1], 0.0, u[2], v[2], w[2], 0.0) + (u[0], u[1], u[2], 0.0, v[0], v[1], v[2], 0.0, w[0], w[1], w[2], 0.0)
+
+
+def translate(t):  # Vec.hs:564-568
+    return (1.0, 0, 0, t[0], 0, 1.0, 0, t[1], 0, 0, 1.0, t[2]) + (1.0, 0, 0, -t[0], 0, 1.0, 0, -t[1], 0, 0, 1.0, -t[2])
+
+
+def cone(p1, r1, p2, r2):  # Cone.hs:53-67 (the cylinder case, r1 - r2 < delta, is not restated here)
+    if r1 < r2: return cone(p2, r2, p1, r1)
+    assert r1 - r2 >= DELTA
+    axis = vsub(p2, p1)
+    ln = vlen(axis)
+    ax1 = vscale(axis, 1 / ln)
+    ax2, ax3 = orth(ax1)
+    height = fdiv(r1 * ln, r1 - r2)
+    return Cone(r1, 0.0, ln, height).transform(compose([xyz_to_uvw(ax2, ax3, ax1), translate(p1)]))
+
+
+# ----------------------------------------------------------------------------------------------- Texture.hs: stripes and Perlin noise
+def triangle_wave(x):  # :16-21
+    off = x - math.floor(x)
+    return off * 2 if off < 0.5 else 2 - off * 2
+
+
+PHI = (3, 0, 2, 7, 4, 1, 5, 11, 8, 10, 9, 6)                                                     # :55-56
+GRAD = [(x, y, z) for x in (-1.0, 0.0, 1.0) for y in (-1.0, 0.0, 1.0) for z in (-1.0, 0.0, 1.0) if 1.1 < vlen((x, y, z)) < 1.5]  # :58-63
+
+
+def noise(p):  # :93-108
+    def omega(t_):  # :48-52
+        t = abs(t_); t2 = t * t; t3 = t2 * t
+        return (-6) * t3 * t2 + 15 * t3 * t - 10 * t3 + 1
+    def knot(i, j, k, v):  # :65-75
+        a = PHI[abs(k) % 12]; b = PHI[abs(j + a) % 12]; c = PHI[abs(i + b) % 12]
+        return omega(v[0]) * omega(v[1]) * omega(v[2]) * vdot(GRAD[c], v)
+    i, j, k = math.floor(p[0]), math.floor(p[1]), math.floor(p[2])
+    u, v, w = p[0] - i, p[1] - j, p[2] - k
+    return (knot(i, j, k, (u, v, w)) + knot(i + 1, j, k, (u - 1, v, w)) + knot(i, j + 1, k, (u, v - 1, w)) + knot(i, j, k + 1, (u, v, w - 1)) +
+            knot(i + 1, j + 1, k, (u - 1, v - 1, w)) + knot(i + 1, j, k + 1, (u - 1, v, w - 1)) + knot(i, j + 1, k + 1, (u, v - 1, w - 1)) +
+            knot(i + 1, j + 1, k + 1, (u - 1, v - 1, w - 1)))
+
+
+def perlin(v): return (noise(v) + 1) * 0.5  # :110-117
+
+
 def rayint_advance(s, o, d, dist, texs, adv):  # Solid.hs:85-91
     a = adv + DELTA
     h = s.rayint(vscaleadd(o, d, a), d, dist - a, texs)
@@ -428,6 +540,23 @@ class Bih(Solid):
                 return (traverse(l, near, fmin(dl, far)) if near < dl else False) or (traverse(r, fmax(dr, near), far) if dr < far else False)
             return (traverse(r, near, fmin(dr, far)) if near < dr else False) or (traverse(l, fmax(dl, near), far) if dl < far else False)
         return traverse(self.root, near, fmin(dist, far0))
+    def _inbox(self, p): return all(p[k] > self.bb[0][k] and p[k] < self.bb[1][k] for k in range(3))
+    def inside(self, p):  # inside_bih, :550-565: a point traversal; a leaf holds a group (the list instance: any)
+        def traverse(n):
+            if n[0] == "leaf": return any(s.inside(p) for s in n[1])
+            _, lsplit, rsplit, axis, l, r = n
+            return (traverse(l) if p[axis] < lsplit else False) or (traverse(r) if p[axis] > rsplit else False)
+        return self._inbox(p) and traverse(self.root)
+    def get_metainfo(self, p):  # get_metainfo_bih, :567-585: left `paircat` right; a leaf like the list instance (Solid.hs:337-339)
+        def traverse(n):
+            if n[0] == "leaf":
+                out = ()
+                for s in n[1]:
+                    if s.inside(p): out = s.get_metainfo(p) + out
+                return out
+            _, lsplit, rsplit, axis, l, r = n
+            return (traverse(l) if p[axis] < lsplit else ()) + (traverse(r) if p[axis] > rsplit else ())
+        return traverse(self.root) if self._inbox(p) else ()
     def bound(self): return self.bb
 
 
@@ -544,6 +673,10 @@ class Scene:
         self.mats.append(("warp", frame, -1 if scene is None else scene, ls, tuple(float(x) for x in list(xfm)[:12])))
         return len(self.mats) - 1
     def tag(self, node): return node  # tags only matter for picking
+    def cone(self, p1, r1, p2, r2): return self._add(cone(tuple(p1), r1, tuple(p2), r2))
+    def material_blend_fn(self, a, b, fn, params):  # TestScene.hs:213-231: Blend a b (f pos); fn 1 = perlin (pos * s), 3 = stripe axis triangle_wave
+        assert fn in (1, 3)
+        self.mats.append(("blend_fn", a, b, fn, tuple(float(x) for x in params))); return len(self.mats) - 1
 
     # ---- Shader.hs
     def mpreshade(self, sld, hit, lights=None):  # :65-80 (Q18)
@@ -609,6 +742,9 @@ class Scene:
             wcolor, wint = self.trace(sld if scene < 0 else self.nodes[scene], wo, wd, ridepth(fint), recurs - 1, True, wlights)
             return fcolor if ridepth(fint) < ridepth(wint) else wcolor
         if m[0] == "layers": return casum([self.mpostshade(lz, k, o, d, sld, hit, recurs) for k in m[1]])
+        if m[0] == "blend_fn":
+            w = perlin(vscale(p, m[4][0])) if m[3] == 1 else triangle_wave(vdot(p, m[4][:3]))
+            return caweight(self.mpostshade(lz, m[1], o, d, sld, hit, recurs), self.mpostshade(lz, m[2], o, d, sld, hit, recurs), w)
         if m[0] == "blend": return caweight(self.mpostshade(lz, m[1], o, d, sld, hit, recurs), self.mpostshade(lz, m[2], o, d, sld, hit, recurs), m[3])
         raise ValueError(m[0])
 
