@@ -200,6 +200,20 @@ class Triangle(Solid):  # Triangle.hs
     def transform(self, xf): return Triangle(*[xfm_point(xf[0], q) for q in self.p])  # bakes the matrix in, :164-168
 
 
+def smooth_normal(n1, n2, n3, b1, b2):  # Triangle.hs:135-139: vnorm (vadd3 (n1 * (1 - (b1 + b2))) (n2 * b1) (n3 * b2))
+    a, b, c = vscale(n1, 1 - (b1 + b2)), vscale(n2, b1), vscale(n3, b2)
+    return vnorm((a[0] + b[0] + c[0], a[1] + b[1] + c[1], a[2] + b[2] + c[2]))
+
+
+class TriangleNorm(Triangle):  # Triangle.hs:109-141, 170-178: vertex normals, interpolated by the hit's barycentrics
+    def __init__(self, p1, p2, p3, n1, n2, n3): Triangle.__init__(self, p1, p2, p3); self.n = (tuple(n1), tuple(n2), tuple(n3))
+    def rayint(self, o, d, dist, texs):
+        r = tri_core(*self.p, o, d, dist)
+        if r is None: return None
+        return (r[0], vscaleadd(o, d, r[0]), smooth_normal(*self.n, r[1], r[2]), texs, self.uid, (o, d))
+    def transform(self, xf): return TriangleNorm(*[xfm_point(xf[0], q) for q in self.p], *[vnorm(xfm_vec(xf[0], n)) for n in self.n])
+
+
 class Box(Solid):  # Box.hs
     def __init__(self, a, b): self.bb = (tuple(a), tuple(b))
     def rayint(self, o, d, dist, texs):  # :18-54 (Q1, Q6)
@@ -315,6 +329,35 @@ def disc_hit(point, norm, r2, o, d, dist):  # rayint_disc / shadow_disc, Cone.hs
     return None if vdot(off, off) > r2 else t
 
 
+class Disc(Solid):  # Cone.hs:21, 29-31, 69-102
+    def __init__(self, pos, norm, r): self.pos, self.norm, self.r2 = tuple(pos), tuple(norm), r * r
+    def rayint(self, o, d, dist, texs):
+        t = disc_hit(self.pos, self.norm, self.r2, o, d, dist)
+        return None if t is None else (t, vscaleadd(o, d, t), self.norm, texs, self.uid, (o, d))
+    def shadow(self, o, d, dist): return disc_hit(self.pos, self.norm, self.r2, o, d, dist) is not None
+    def bound(self):  # bound (sphere pos (sqrt rsqr))
+        r = math.sqrt(self.r2)
+        return (tuple(self.pos[k] - r for k in range(3)), tuple(self.pos[k] + r for k in range(3)))
+
+
+class NoShadow(Solid):  # Tex.hs:77-85
+    def __init__(self, s): self.s = s
+    def rayint(self, o, d, dist, texs): return self.s.rayint(o, d, dist, texs)
+    def shadow(self, o, d, dist): return False
+    def inside(self, p): return self.s.inside(p)
+    def bound(self): return self.s.bound()
+    def get_metainfo(self, p): return self.s.get_metainfo(p)
+
+
+class OnlyShadow(Solid):  # Tex.hs:88-96
+    def __init__(self, s): self.s = s
+    def rayint(self, o, d, dist, texs): return None
+    def shadow(self, o, d, dist): return self.s.shadow(o, d, dist)
+    def inside(self, p): return self.s.inside(p)
+    def bound(self): return self.s.bound()
+    def get_metainfo(self, p): return self.s.get_metainfo(p)
+
+
 class Cone(Solid):  # the canonical cone on the z axis (Cone.hs:155-251): radius r at z = 0, apex at z = height, kept between clip1 and clip2
     def __init__(self, r, clip1, clip2, height): self.r, self.c1, self.c2, self.h = r, clip1, clip2, height
     def _side(self, o, d, dist):  # the quadratic of rayint_cone / shadow_cone: the distance to the infinite cone, or None
@@ -365,6 +408,59 @@ class Cone(Solid):  # the canonical cone on the z axis (Cone.hs:155-251): radius
     def bound(self): return ((-self.r, -self.r, self.c1), (self.r, self.r, self.c2))  # :249-251
 
 
+class Cylinder(Solid):  # the canonical cylinder on the z axis between h1 and h2 (Cone.hs:104-151); shadow is the class default
+    def __init__(self, r, h1, h2): self.r, self.h1, self.h2 = r, h1, h2
+    def rayint(self, o, d, dist, texs):
+        r = self.r
+        ox, oy, oz = o; dx, dy, dz = d
+        a = dx * dx + dy * dy
+        b = 2 * (dx * ox + dy * oy)
+        c = ox * ox + oy * oy - r * r
+        disc = b * b - 4 * a * c
+        if disc < 0: return None
+        ds = math.sqrt(disc)
+        q = (b - ds) * (-0.5) if b < 0 else (b + ds) * (-0.5)
+        t0_, t1_ = fdiv(q, a), fdiv(c, q)
+        t0, t1 = fmin(t0_, t1_), fmax(t0_, t1_)
+        if t1 < 0 or t0 > dist: return None
+        t = t1 if t0 < 0 else t0
+        if t < 0 or t > dist: return None
+        pos = vscaleadd(o, d, t)
+        if pos[2] > self.h1 and pos[2] < self.h2: return (t, pos, (fdiv(pos[0], r), fdiv(pos[1], r), 0.0), texs, self.uid, (o, d))
+        if dz > 0: cap = ((0.0, 0.0, self.h1), NVZ) if oz < self.h1 else None
+        else: cap = ((0.0, 0.0, self.h2), VZ) if oz > self.h2 else None
+        if cap is None: return None
+        td = disc_hit(cap[0], cap[1], r * r, o, d, dist)
+        return None if td is None else (td, vscaleadd(o, d, td), cap[1], texs, self.uid, (o, d))
+    def inside(self, p): return p[2] > self.h1 and p[2] < self.h2 and p[0] * p[0] + p[1] * p[1] < self.r * self.r
+    def bound(self): return ((-self.r, -self.r, self.h1), (self.r, self.r, self.h2))
+
+
+def cylinder(p1, p2, r):  # Cone.hs:41-49
+    axis = vsub(p2, p1)
+    ln = vlen(axis)
+    ax1 = vscale(axis, 1 / ln)
+    ax2, ax3 = orth(ax1)
+    return Cylinder(r, 0.0, ln).transform(compose([xyz_to_uvw(ax2, ax3, ax1), translate(p1)]))
+
+
+class Bound(Solid):  # Bound.hs:27-66: sb is looked at only by rays that start inside sa or hit it
+    def __init__(self, a, b): self.a, self.b = a, b
+    def rayint(self, o, d, dist, texs): return self.b.rayint(o, d, dist, texs) if (self.a.inside(o) or self.a.shadow(o, d, dist)) else None
+    def shadow(self, o, d, dist): return self.b.shadow(o, d, dist) if (self.a.inside(o) or self.a.shadow(o, d, dist)) else False
+    def inside(self, p): return self.a.inside(p) and self.b.inside(p)
+    def get_metainfo(self, p): return self.b.get_metainfo(p) if self.a.inside(p) else ()
+    def bound(self): return bboverlap(self.a.bound(), self.b.bound())
+
+
+class InnerBound(Solid):  # Bound.hs:93-108: sb is searched no farther than sa's hit
+    def __init__(self, a, b): self.a, self.b = a, b
+    def rayint(self, o, d, dist, texs): return self.b.rayint(o, d, ridepth(self.a.rayint(o, d, dist, ())), texs)
+    def shadow(self, o, d, dist): return self.a.shadow(o, d, dist) or self.b.shadow(o, d, dist)
+    def inside(self, p): return self.a.inside(p) or self.b.inside(p)
+    def bound(self): return self.b.bound()
+
+
 def orth(v1):  # Vec.hs:366-378
     dvx = v1[0]
     v2 = vnorm(vcross(v1, (1.0, 0.0, 0.0))) if (dvx < 0.8 and dvx > -0.8) else vnorm(vcross(v1, (0.0, 1.0, 0.0)))
@@ -379,9 +475,9 @@ def translate(t):  # Vec.hs:564-568
     return (1.0, 0, 0, t[0], 0, 1.0, 0, t[1], 0, 0, 1.0, t[2]) + (1.0, 0, 0, -t[0], 0, 1.0, 0, -t[1], 0, 0, 1.0, -t[2])
 
 
-def cone(p1, r1, p2, r2):  # Cone.hs:53-67 (the cylinder case, r1 - r2 < delta, is not restated here)
+def cone(p1, r1, p2, r2):  # Cone.hs:53-67
     if r1 < r2: return cone(p2, r2, p1, r1)
-    assert r1 - r2 >= DELTA
+    if r1 - r2 < DELTA: return cylinder(p1, p2, r2)
     axis = vsub(p2, p1)
     ln = vlen(axis)
     ax1 = vscale(axis, 1 / ln)
@@ -391,6 +487,10 @@ def cone(p1, r1, p2, r2):  # Cone.hs:53-67 (the cylinder case, r1 - r2 < delta, 
 
 
 # ----------------------------------------------------------------------------------------------- Texture.hs: stripes and Perlin noise
+def square_wave(x): return 0.0 if (x - math.floor(x)) < 0.5 else 1.0  # :11-14
+def sine_wave(x): return math.sin(x * 2 * math.pi) * 0.5 + 0.5           # :23-24
+
+
 def triangle_wave(x):  # :16-21
     off = x - math.floor(x)
     return off * 2 if off < 0.5 else 2 - off * 2
@@ -562,8 +662,9 @@ class Bih(Solid):
 
 # ----------------------------------------------------------------------------------------------- Mesh (Mesh.hs)
 class Mesh(Solid):
-    def __init__(self, verts, tris, texi, texv):  # mesh, :50-134; tris: (a, b, c) vertex indices; texi: per-triangle index into texv, or -1
+    def __init__(self, verts, tris, texi, texv, norms=(), tnorms=None):  # mesh, :50-134; tris: (a, b, c) vertex indices; texi: per-triangle index into texv, or -1; tnorms: (na, nb, nc) or -1s
         self.verts, self.tris, self.texi, self.texv = [tuple(v) for v in verts], [tuple(t) for t in tris], texi, texv
+        self.norms, self.tnorms = list(norms), tnorms
         self.bb = bbpts(self.verts)
         self.tbb = [bbpts([self.verts[a], self.verts[b], self.verts[c]]) for (a, b, c) in self.tris]
         self.bvh = self.build_tree(list(range(len(self.tris))), self.bb)
@@ -600,7 +701,9 @@ class Mesh(Solid):
             r = tri_core(a, b, c, o, d, far)
             if r is None: return None
             tex = texs if self.texi[i] == -1 else (self.texv[self.texi[i]],) + texs  # :148-150
-            return (r[0], vscaleadd(o, d, r[0]), vnorm(vcross(vsub(b, a), vsub(c, a))), tex, self.uid, (o, d))
+            if self.tnorms is None or self.tnorms[i][0] == -1: nrm = vnorm(vcross(vsub(b, a), vsub(c, a)))  # :154-155
+            else: nrm = smooth_normal(*(self.norms[k] for k in self.tnorms[i]), r[1], r[2])            # :156-160
+            return (r[0], vscaleadd(o, d, r[0]), nrm, tex, self.uid, (o, d))
         def traverse(n, near, far):
             if n[0] == "leaf":
                 acc = None
@@ -648,6 +751,7 @@ class Scene:
     def _add(self, s): s.uid = len(self.nodes); self.nodes.append(s); return s.uid
     def sphere(self, c, r): return self._add(Sphere(c, r))
     def triangle(self, p1, p2, p3): return self._add(Triangle(p1, p2, p3))
+    def trianglenorm(self, p1, p2, p3, n1, n2, n3): return self._add(TriangleNorm(p1, p2, p3, n1, n2, n3))
     def triangles_bulk(self, pts9): return [self._add(Triangle(p[0:3], p[3:6], p[6:9])) for p in pts9.tolist()]
     def box(self, a, b): return self._add(Box(a, b))
     def plane(self, pt, n):  # Plane.hs:16-19: plane orig norm_ = Plane (vnorm norm_) (vdot orig (vnorm norm_))
@@ -660,9 +764,9 @@ class Scene:
     def intersection(self, ids): return self._add(Intersection([self.nodes[i] for i in ids]))
     def transform(self, node, xfms): return self._add(self.nodes[node].transform(compose(xfms)))
     def tex(self, node, mat): return self._add(Tex(self.nodes[node], mat))
-    def mesh(self, verts, norms, tris, mats):  # Tri a b c na nb nc tex tag (Mesh.hs:27-29); vertex normals are not restated here
-        assert len(norms) == 0 and all(int(t[3]) == -1 for t in tris)
-        return self._add(Mesh([tuple(v) for v in verts.tolist()], [tuple(int(x) for x in t[:3]) for t in tris], [int(t[6]) for t in tris], list(mats)))
+    def mesh(self, verts, norms, tris, mats):  # Tri a b c na nb nc tex tag (Mesh.hs:27-29)
+        return self._add(Mesh([tuple(v) for v in verts.tolist()], [tuple(int(x) for x in t[:3]) for t in tris], [int(t[6]) for t in tris], list(mats),
+                              [tuple(v) for v in norms.tolist()], [tuple(int(x) for x in t[3:6]) for t in tris]))
     def material_surface(self, color, alpha, amb, kd, ks, shine): self.mats.append(("surface", tuple(color), alpha, amb, kd, ks, shine)); return len(self.mats) - 1
     def material_reflect(self, refl): self.mats.append(("reflect", refl)); return len(self.mats) - 1
     def material_refract(self, refl, refr, ior): self.mats.append(("refract", refl, refr, ior)); return len(self.mats) - 1
@@ -674,8 +778,14 @@ class Scene:
         return len(self.mats) - 1
     def tag(self, node): return node  # tags only matter for picking
     def cone(self, p1, r1, p2, r2): return self._add(cone(tuple(p1), r1, tuple(p2), r2))
+    def cylinder(self, p1, p2, r): return self._add(cylinder(tuple(p1), tuple(p2), r))
+    def disc(self, pos, n, r): return self._add(Disc(pos, n, r))
+    def noshadow(self, node): return self._add(NoShadow(self.nodes[node]))
+    def onlyshadow(self, node): return self._add(OnlyShadow(self.nodes[node]))
+    def bound_object(self, a, b): return self._add(Bound(self.nodes[a], self.nodes[b]))
+    def innerbound(self, a, b): return self._add(InnerBound(self.nodes[a], self.nodes[b]))
     def material_blend_fn(self, a, b, fn, params):  # TestScene.hs:213-231: Blend a b (f pos); fn 1 = perlin (pos * s), 3 = stripe axis triangle_wave
-        assert fn in (1, 3)
+        assert fn in (1, 2, 3, 4)
         self.mats.append(("blend_fn", a, b, fn, tuple(float(x) for x in params))); return len(self.mats) - 1
 
     # ---- Shader.hs
@@ -743,7 +853,7 @@ class Scene:
             return fcolor if ridepth(fint) < ridepth(wint) else wcolor
         if m[0] == "layers": return casum([self.mpostshade(lz, k, o, d, sld, hit, recurs) for k in m[1]])
         if m[0] == "blend_fn":
-            w = perlin(vscale(p, m[4][0])) if m[3] == 1 else triangle_wave(vdot(p, m[4][:3]))
+            w = perlin(vscale(p, m[4][0])) if m[3] == 1 else {2: square_wave, 3: triangle_wave, 4: sine_wave}[m[3]](vdot(p, m[4][:3]))
             return caweight(self.mpostshade(lz, m[1], o, d, sld, hit, recurs), self.mpostshade(lz, m[2], o, d, sld, hit, recurs), w)
         if m[0] == "blend": return caweight(self.mpostshade(lz, m[1], o, d, sld, hit, recurs), self.mpostshade(lz, m[2], o, d, sld, hit, recurs), m[3])
         raise ValueError(m[0])

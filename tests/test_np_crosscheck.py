@@ -140,17 +140,24 @@ def _frames(sd, w, h, maxdepth):
     return ref, rc, got, sc
 
 
-@pytest.mark.parametrize("name,w,h,md", [("S1", 48, 32, 1), ("S3small", 40, 24, 1), ("S3mesh_small", 40, 24, 1), ("S4", 48, 27, 3), ("materials", 40, 30, 3), ("portal", 56, 42, 3), ("testscene", 64, 48, 3)])
+_FRAMES = [("S1", 48, 32, 1), ("S3small", 40, 24, 1), ("S3mesh_small", 40, 24, 1), ("S4", 48, 27, 3), ("csg", 40, 30, 3), ("flat_mixed", 40, 30, 3),
+           ("materials", 40, 30, 3), ("mesh", 40, 30, 3), ("mirror_terrain", 40, 30, 3), ("nested", 40, 30, 3), ("portal", 56, 42, 3), ("quadrics", 40, 30, 3),
+           ("testscene", 64, 48, 3), ("textures", 40, 30, 3)]
+
+
+@pytest.mark.parametrize("name,w,h,md", _FRAMES)
 def test_whole_frames_of_two_independent_restatements_agree(built, name, w, h, md):
-    """BIH builder + rayint_bih + shadow_bih (S1, S3small), Mesh builder + rayint_mesh (S3mesh_small), Instance / Difference /
-    Intersection / get_metainfo and the trace / mpreshade / mpostshade recursion with Reflect (S4), Refract / Blend /
-    AdditiveLayers (materials), Warp with riray, its own lights and the frame's depth as the other scene's reach (portal), and GlomeView's default scene
-    (testscene: cones, plane-cut polyhedra, perlin / stripe Blend textures, inside_bih / get_metainfo_bih under a Difference): the C++ oracle and oracle/np_scene.py -- written separately from the Haskell text -- give the
-    same frame to rounding, pixel for pixel, and trace the same number of rays."""
+    """The benchmark scenes at small sizes and EVERY scene of the zoo (tests/zoo.py: all primitive families incl. smooth
+    triangles and discs, cylinders / cones through `orth` + `xyz_to_uvw`, Tex stacks, NoShadow / OnlyShadow, groups, Instances of
+    instances, Difference / Intersection over primitives and over an instanced bih with `inside_bih` / `get_metainfo_bih`,
+    Bound / InnerBound, a Mesh with vertex normals and per-triangle textures, Reflect / Refract / Blend / AdditiveLayers, the
+    perlin and stripe solid textures, Warp with `riray` and its own lights, GlomeView's default scene): the C++ oracle and
+    oracle/np_scene.py -- written separately from the Haskell text -- give the same frame to rounding, pixel for pixel, and
+    trace the same number of rays."""
     import zoo
     from glome_amd import scenes
     mk = {"S1": lambda: scenes.s1(nlights=2), "S3small": lambda: scenes.s3(12), "S3mesh_small": lambda: scenes.s3(12, as_mesh=True), "S4": scenes.s4,
-          "materials": zoo.materials, "portal": zoo.portal, "testscene": lambda: zoo.testscene(3)}[name]
+          "testscene": lambda: zoo.testscene(3)}.get(name) or zoo.ALL[name]
     ref, rc, got, sc = _frames(mk(), w, h, md)
     assert got.shape == ref.shape
     assert np.array_equal(got[..., 4] < 1e6, ref[..., 4] < 1e6)          # the same pixels hit
