@@ -570,17 +570,17 @@ def test_reference_default_scene_with_the_full_lattice(gpu_ctx):
     sc.release()
 
 
-@pytest.mark.parametrize("nframes", [3, 8])
-def test_adaptive_sampler_frame_batches_equal_the_frames_rendered_alone(gpu_ctx, nframes):
+@pytest.mark.parametrize("nframes,which", [(3, "S3"), (8, "S3"), (3, "testscene")])
+def test_adaptive_sampler_frame_batches_equal_the_frames_rendered_alone(gpu_ctx, nframes, which):
     """renderTileSubsample over several views in ONE launch (glome_render_packed_batch_dev, mode 1): the sampler then works in
     larger regions per work item (3 frames: medium, 8: a whole tile per pass) -- other packets, the same pixels.  Every frame
     of the batch must equal the frame rendered alone, bit for bit; the frame size leaves clipped tiles on two edges."""
     import torch
-    sd = scenes.s3(48)
+    sd = scenes.s3(48) if which == "S3" else zoo.testscene(2)  # (the flat tier's sampler kernel / the generic tier's, with secondary rays)
     b, nm, sc = commit(gpu_ctx, sd)
     cam, lights = product_camera_lights(sd)
-    W, H = 531, 397
-    P = api.render_params(width=W, height=H, maxdepth=1, mode=1)
+    W, H = (531, 397) if which == "S3" else (267, 199)
+    P = api.render_params(width=W, height=H, maxdepth=1 if which == "S3" else 3, mode=1)
     views = []
     for f in range(nframes):  # the scene's camera, then the eye moved sideways and up a little
         pos, at, up, angle = sd.cam
