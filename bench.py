@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--product", default="packed", choices=["packed", "rgbad"],
                     help="what a frame is: GlomeView's framebuffer of packed 0x00RRGGBB pixels (blitTile; 4 B/pixel cross xGMI) "
                          "or the float (r,g,b,a,depth) tuples (20 B/pixel)")
+    ap.add_argument("--rehearse", action="store_true", help="N ranks on ONE GPU over gloo (payloads staged through the host): a rehearsal of the multi-process "
+                                                            "control flow where there is a single device; its timings mean nothing")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -83,6 +85,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible (there is no CPU path to time)")
+    if args.rehearse:
+        local = 0  # every rank on the one device
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist_on = world > 1 or args.force_dist
@@ -91,7 +95,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.force_dist and world == 1:
             os.environ.setdefault("MASTER_PORT", "29533"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        tdist.init_process_group("nccl", device_id=device)
+        if args.rehearse:
+            tdist.init_process_group("gloo")
+        else:
+            tdist.init_process_group("nccl", device_id=device)
 
     cfg = scenes.CONFIGS[args.scene]
     sd = cfg["make"]()
@@ -181,6 +188,17 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     value = rays_per_step / (elapsed / args.steps) / 1e6
+
+    # ---- after the timed region: the last frame the job delivered (rank 0's framebuffer, reassembled from every rank's tiles)
+    # against the same view rendered whole on this GPU -- the multi-GPU data path checks itself in every run
+    frame_check = None
+    if args.product == "packed":
+        torch.cuda.synchronize(device)
+        ctx.lib.glome_ctx_use_slot(ctx.h, None, 0)
+        whole = torch.zeros((H, W), dtype=torch.int32, device=device)
+        scene.render_dev(cam, lights, P, None, whole.data_ptr(), want_stats=False)
+        ctx.synchronize()
+        frame_check = bool(torch.equal(sf.frame.reshape(H, W), whole))
 
     # ---- the dominant kernel alone: launch duration and single-frame latency (HIP events on the launch stream) ----
     # One launch in flight at a time (the timed region above overlaps several, so a launch's own duration there is longer
@@ -325,7 +343,8 @@ def main():
                    "width": W, "height": H, "rays_per_frame": {"primary": rays[0], "shadow": rays[1], "secondary": rays[2]},
                    "sampling": "renderTile, 1 primary ray/pixel" if args.mode == 0 else "renderTileSubsample (adaptive, 1/8..2 primary rays/pixel)", "launches_in_flight": sf.n, "frames_per_launch": sf.G, "rank0_share_pct": sf.rank0_share_pct, "frame_product": "packed 0x00RRGGBB framebuffer (trace + blitTile fused, 4 B/pixel)" if args.product == "packed" else "float (r,g,b,a,depth) per pixel, 20 B/pixel", "tiles": f"{'64x64 work' if args.mode == 0 else '65x65 reference'} tiles, round-robin over ranks; a launch renders a rank's tiles of {sf.G} frames, one RCCL gather to rank 0 per launch, overlapped with the next launch" if (world > 1 or args.force_dist) else ("65x65 reference tile map, one GPU; a whole renderTile frame is cut into 64x64 work tiles (same pixels, no leftover strips)" if args.mode == 0 else "65x65 reference tiles, one GPU"),
                    "scene_setup_s": round(setup_s, 2), "bih_build": "host" if args.host_build else "device (glome_sb_bih_dev / glome_sb_mesh_dev) for lists of 4096+ objects", "device_bytes": info["device_bytes"]},
-        "roofline": roofline, "latency": latency, "cpu_baseline": cpu, "rccl_ranks": world if dist_on else 0,
+        "roofline": roofline, "latency": latency, "cpu_baseline": cpu, "frame_equals_single_gpu_render": frame_check, "rccl_ranks": world if (dist_on and not args.rehearse) else 0,
+        **({"rehearsal": "ranks share one GPU, payloads gathered over gloo through the host: not a measurement"} if args.rehearse else {}),
     }
     print(json.dumps(out), flush=True)
     if dist_on:

@@ -54,7 +54,7 @@ def _clone_params(p, **kw):
 
 
 # rank 0's share of a fair share of the tiles, by ranks (renderTile mode; measured, profiles/r02_g_shard_share.log)
-RANK0_SHARE_PCT = {1: 0, 2: 85, 4: 70, 8: 65}
+RANK0_SHARE_PCT = {1: 0, 2: 85, 3: 78, 4: 70, 5: 68, 6: 67, 7: 66, 8: 65}  # (2, 4, 8 measured; the others in between)
 
 
 class ShardPlan:
@@ -76,6 +76,18 @@ class ShardPlan:
         """The path's only collective: every rank's (padded) tile payload -> rank 0.  `gathered` (rank 0) is one
         [world, maxp] tensor; returns the work handle when async_op."""
         import torch.distributed as dist
+        if payload.is_cuda and dist.get_backend() == "gloo":  # bench.py --rehearse: gloo gathers host tensors only
+            host = payload.cpu()
+            parts = [host.new_empty(host.shape) for _ in range(self.world)] if self.rank == 0 else None
+            dist.gather(host, parts, dst=0)
+            if self.rank == 0:
+                for r in range(self.world):
+                    gathered[r].copy_(parts[r])
+
+            class _Done:
+                def wait(self):
+                    return True
+            return _Done() if async_op else None
         return dist.gather(payload, list(gathered.unbind(0)) if self.rank == 0 else None, dst=0, async_op=async_op)
 
 
@@ -157,7 +169,7 @@ class ShardedFrame:
         # rank 0 also receives and blits every frame: it owns less than a fair share of the tiles (glome_render_params.rank0_share_pct;
         # the defaults are where rank 0's and another rank's sustained frame periods met on one GPU, tools/shard_share.py)
         if rank0_share_pct is None:
-            rank0_share_pct = RANK0_SHARE_PCT.get(world, 60 if world > 8 else 0) if params.mode == 0 else 0
+            rank0_share_pct = RANK0_SHARE_PCT.get(world, 65) if params.mode == 0 else 0
         params = _clone_params(params, rank0_share_pct=int(rank0_share_pct))
         self.rank0_share_pct = int(rank0_share_pct)
         # renderTile's pixels do not depend on the tile map (the adaptive sampler's do, Q21): the shard unit is then a 64x64
