@@ -5,11 +5,13 @@
 //   k_render_flat<FAITHFUL,COUNT,FULL,CLS,LB,TWO_ROWS>
 //                                       persistent: one wave pulls 64-pixel work items (8x8 blocks of a 65x65
 //                                       reference tile, Glome.hs:371-386; up to 8 frames per launch) from a ticket
-//                                       queue; the wave walks a triangle / sphere BIH once for its 64 rays (packet:
-//                                       rt_device.hpp bih_tri_wave) -> shadow rays -> shade -> secondary rays (per lane).
-//                                       No ray streams in HBM at all.
+//                                       queue of eight heads; the wave walks a triangle / sphere BIH once for its 64 rays
+//                                       (packet: rt_device.hpp bih_tri_wave; for triangles the hand-written walk of
+//                                       bih_packet_asm.hpp) -> shadow rays -> shade; secondary rays re-enter the same walk
+//                                       through the shading state machine (shade_vm).  No ray streams in HBM at all.
 //   k_render_generic                    same loop over the generic interpreter (rt_generic.hpp)
-//   k_ss_frame_flat / k_ss_frame_generic  the adaptive sampler (renderTileSubsample, Glome.hs:226-323): five passes, one launch
+//   k_ss_frame_flat / k_ss_frame_generic  the adaptive sampler (renderTileSubsample, Glome.hs:226-323): five passes per
+//                                       tile, one launch per frame or batch of frames
 //   k_rayint_batch / k_shadow_batch / k_inside_batch   the `Solid` method seams on SoA ray streams
 //   k_tiles_pack / k_tiles_blit / k_tiles_blit_packed  Tile payload <-> frame (blitTile, Glome.hs:353-358)
 //   k_bb_* / k_mb_* (bih_build_device.hpp)             `bih` and the Mesh BVH built level by level (Bih.hs:211-285, Mesh.hs:69-113)
