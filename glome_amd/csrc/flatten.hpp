@@ -45,6 +45,8 @@ class Flattener {
     F.root_rec = (uint32_t)F.recs.size();
     F.recs.push_back(r);
     F.nesting_depth = depth_of(root);
+    if (tex_depth_of(root) > kMaxTexDepth)
+      throw limit_error("a primitive lies under " + std::to_string(tex_depth_of(root)) + " nested textures; the device's texture stack holds " + std::to_string(kMaxTexDepth));
     const bool warps = bind_warps();  // Warp materials refer to records: the frame's, and the scene's they look into
     if (F.nesting_depth > kGenericDepth) throw limit_error("scene nests composites deeper than the device interpreter supports (" + std::to_string(F.nesting_depth) + " > " + std::to_string(kGenericDepth) + ")");
     // flat tier: root program of simple entries
@@ -108,6 +110,7 @@ class Flattener {
       any = true;
       const uint32_t frame = slot(emit(m.wframe)), scene = m.wscene < 0 ? F.root_rec : slot(emit(m.wscene));
       F.nesting_depth = std::max(F.nesting_depth, std::max(depth_of(m.wframe), m.wscene < 0 ? 0 : depth_of(m.wscene)));
+      if (std::max(tex_depth_of(m.wframe), m.wscene < 0 ? 0 : tex_depth_of(m.wscene)) > kMaxTexDepth) throw limit_error("a Warp material's frame / scene has more nested textures than the device's texture stack holds");
       if (F.nesting_depth > kGenericDepth) throw limit_error("a Warp material's frame / scene nests composites deeper than the device interpreter supports");
       const uint32_t xf = (uint32_t)(F.xfms.size() / 6);
       for (int q = 0; q < 3; q++) F.xfms.push_back(mk4(m.wxf.f.m[4 * q], m.wxf.f.m[4 * q + 1], m.wxf.f.m[4 * q + 2], m.wxf.f.m[4 * q + 3]));
@@ -143,6 +146,28 @@ class Flattener {
       case K_TEX: case K_TAG: case K_NOSHADOW: case K_ONLYSHADOW: return depth_of(n.a);
       default: return 0;
     }
+  }
+
+  // longest texture stack a hit can carry: the Tex wrappers on a path from `id` down to a primitive (a Mesh adds its
+  // per-triangle texture, Mesh.hs:148-150).  The device stack holds kMaxTexDepth materials; a deeper one is refused at
+  // commit -- the traversal would silently drop the outermost textures.
+  mutable std::unordered_map<int, int> tex_memo;
+  int tex_depth_of(int id) const {
+    auto it = tex_memo.find(id);
+    if (it != tex_memo.end()) return it->second;
+    const Node& n = G.at(id);
+    int d = 0;
+    switch (n.kind) {
+      case K_LIST: case K_ISECT: for (int k : n.kids) d = std::max(d, tex_depth_of(k)); break;
+      case K_INSTANCE: case K_TAG: case K_NOSHADOW: case K_ONLYSHADOW: d = tex_depth_of(n.a); break;
+      case K_DIFF: case K_BOUND: case K_INNERBOUND: d = std::max(tex_depth_of(n.a), tex_depth_of(n.b)); break;
+      case K_BIH: for (auto& bn : n.bih->nodes) for (int k : bn.items) d = std::max(d, tex_depth_of(k)); break;
+      case K_MESH: for (const MeshTri& t : n.mesh->tris) if (t.tex >= 0) { d = 1; break; } break;
+      case K_TEX: d = tex_depth_of(n.a) + 1; break;
+      default: break;
+    }
+    tex_memo[id] = d;
+    return d;
   }
 
   // ---- primitive pools ----

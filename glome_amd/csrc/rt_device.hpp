@@ -472,16 +472,22 @@ GD void bih_traverse(const DScene& S, uint32_t hdr, const Ray& r, float d, STK& 
   farv = gminf(d, farv);  // `traverse root near (fmin d far)`, Bih.hs:368
   V3 rcp = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
   uint32_t ref = as_u(h0.w);
+  // A tree that is one leaf: the reference tests it whatever the root interval (`traverse (BihLeaf s) near far = rayint s r
+  // far`, Bih.hs:339) -- and something CAN be hit when the ray misses the box: Refract's transmitted direction is not unit
+  // length (Shader.hs:141), and rayint_sphere's formula (Sphere.hs:20-41) reports hits for such rays where the line misses
+  // the sphere.  The reference shows them; so do we.
+  const bool root_leaf = (ref & BREF_LEAF) != 0;
   int sp = 0;
   for (;;) {
     bool popit = true;
     if (MODE == 1) farv = gminf(farv, best_t());
     if (ref & BREF_LEAF) {
       // BihLeaf: `rayint s r far` -- the reference tests a leaf it has reached without looking at near > far
-      // (Bih.hs:339); with early-out an empty interval cannot hold the nearest hit, so it is skipped.
+      // (Bih.hs:339); below a branch the interval was non-empty when the leaf was chosen, so with early-out an empty one
+      // means `far` has shrunk to the best hit since: nothing nearer can be in it, and it is skipped.
       uint32_t count = (ref >> 26) & 7u, first = ref & BREF_FIRST;
       if (count == 7u) { F4 n = ld4(S.bihnodes, first); count = as_u(n.z); first = as_u(n.w); }
-      if (count != 0 && (MODE == 0 || !(nearv > farv))) {
+      if (count != 0 && (MODE == 0 || root_leaf || !(nearv > farv))) {
         if (leaf(first, first + delta, count, farv)) return;
       }
     } else {
@@ -545,7 +551,9 @@ GD bool bih_tri(const DScene& S, uint32_t hdr, const Ray& r, float d, STK& stk, 
   bool occ = false;
   if (nearv > farv) {  // the root interval is empty
     if (!(ref & BREF_LEAF)) { if (COUNT) cnt.bih++; return false; }  // a branch is entered, counted and left (Bih.hs:343)
-    if (MODE != 0) return false;                                       // a root leaf is tested regardless (Bih.hs:339)
+    // a root leaf is tested regardless, with tmax = far (Bih.hs:339).  With a sound bound nothing can be hit then -- but
+    // Refract's transmitted direction is not unit length (Shader.hs:141), and rayint_sphere's formula (Sphere.hs:20-41)
+    // reports hits for such rays where the line misses the sphere and its box: the reference shows them, so do we.
   }
   for (;;) {
     bool popit;
@@ -797,7 +805,7 @@ GD bool bih_tri_wave(const DScene& S, uint32_t hdr, const Ray& r, float d, bool 
     // of more than six items would land on a row they do not have.  The count is wave-uniform.
     uint32_t count = (ref >> 26) & 7u, first = ref & BREF_FIRST;
     if (count == 7u) { F4 ln = ld4u(S.bihnodes, first); count = uni(as_u(ln.z)); first = uni(as_u(ln.w)); }
-    if (!valid || (MODE != 0 && nearv > farv)) return false;  // a root leaf is tested regardless of its interval (Bih.hs:339), which only matters when nothing clips `far`
+    if (!valid) return false;  // (a root leaf is tested regardless of its interval, Bih.hs:339: see bih_traverse)
     bool occ1 = false;
     for (uint32_t k = 0; k < count; k++) {
       float t;

@@ -852,3 +852,24 @@ def test_refused_parameters_fail_with_a_status_not_a_frame(gpu_ctx):
     gpu_ctx.synchronize()
     assert int(buf.abs().sum()) == 0
     sc.release()
+
+
+@pytest.mark.parametrize("seed", [0, 4, 7, 23, 36, 56])
+def test_random_composite_scenes_on_the_gpu(gpu_ctx, seed):
+    """The fuzz of tests/test_hostsim_parity.py (zoo.random_composites) through the C ABI: seeds that exposed differences on the
+    host compile of the device headers, and a few that never did."""
+    sd = zoo.random_composites(seed)
+    b, nm, sc = commit(gpu_ctx, sd)
+    parity.check_rays(lambda o, d: sc.rayint(o, d), lambda o, d, t: sc.shadow(o, d, t), sc.inside, sd, nm, n=20000)
+    cam, lights = product_camera_lights(sd)
+    W, H = 192, 108
+    img, packed, st = sc.render(cam, lights, api.render_params(width=W, height=H, maxdepth=3))
+    o, om, _ = oracle_for(sd)
+    ref, _, rc = o.render(W, H, maxdepth=3, want_packed=False)
+    of, _, _ = oracle_for(sd, use_float=True)
+    ref32, _, _ = of.render(W, H, maxdepth=3, want_packed=False)
+    err = lambda a, r: (np.abs(a[..., :4] - r[..., :4]) / np.maximum(1, np.abs(r[..., :4]))).max(-1)
+    both = (err(img, ref) > 1e-4) & (err(img, ref32) > 1e-4)
+    assert both.mean() <= 2e-3, (int(both.sum()), np.argwhere(both)[:6].tolist())
+    assert st["rays_primary"] == rc["rays_primary"] and abs(st["rays_shadow"] - rc["rays_shadow"]) <= max(8, rc["rays_shadow"] // 100)
+    sc.release()

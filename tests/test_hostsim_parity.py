@@ -137,3 +137,46 @@ def test_one_leaf_bih_of_more_than_six_items(built):
     assert len(nl) == 1 and nl[0] == 9  # a single node: the root leaf, nine items
     hs = HostSim(b, nm[sd.root])
     assert hs.info()["max_bih_depth"] >= 12 and hs.info()["tier"] == 0
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_random_composite_scenes(built, seed):
+    """Fuzz: zoo.random_composites(seed) -- every primitive family under random Tex stacks, grouped, instanced with rotations and
+    non-uniform scales, carved and intersected, nested three composite levels deep, with mirrors, Refract (whose transmitted
+    rays are not unit length in the reference, Shader.hs:141) and a stripe Blend -- through the device headers against the
+    oracle: the per-ray methods within the usual bounds, and the frame with at most 0.2 % of its pixels away from BOTH the fp64
+    oracle and the same oracle computing in fp32 (a pixel off against one of them only is a rounding flip at a silhouette,
+    a refraction or a stripe edge; off against both would be a difference in logic).  This test found the root-leaf rule of
+    bih_traverse (a one-leaf bih is tested whatever its root interval, Bih.hs:339) and the unchecked texture-stack depth."""
+    from helpers import oracle_for
+    sd = zoo.random_composites(seed)
+    b = api.Builder()
+    nm, _ = sd.replay(b)
+    hs = HostSim(b, nm[sd.root])
+    parity.check_rays(lambda o, d: hs.rayint(o, d), lambda o, d, t: hs.shadow(o, d, t), hs.inside, sd, nm, n=6000)
+    cam, lights = product_camera_lights(sd)
+    W, H = 96, 54
+    img, cnt = hs.render(cam, lights, W, H, 3)
+    o, om, _ = oracle_for(sd)
+    ref, _, rc = o.render(W, H, maxdepth=3, want_packed=False)
+    of, _, _ = oracle_for(sd, use_float=True)
+    ref32, _, _ = of.render(W, H, maxdepth=3, want_packed=False)
+    err = lambda a, r: (np.abs(a[..., :4] - r[..., :4]) / np.maximum(1, np.abs(r[..., :4]))).max(-1)
+    both = (err(img, ref) > 1e-4) & (err(img, ref32) > 1e-4)
+    assert both.mean() <= 2e-3, (int(both.sum()), np.argwhere(both)[:6].tolist())
+    assert int(cnt[0]) == rc["rays_primary"] and abs(int(cnt[1]) - rc["rays_shadow"]) <= max(8, rc["rays_shadow"] // 100)
+
+
+def test_more_nested_textures_than_the_stack_holds_are_refused(built):
+    sd = zoo.SceneDesc()
+    m = sd.material_surface((1, 1, 1), 1, 0.2, 0.8, 0, 0)
+    n = sd.sphere((0, 1, 0), 1)
+    for _ in range(4):
+        n = sd.tex(n, m)
+    ok = sd.group([n, sd.sphere((3, 1, 0), 1)])
+    b = api.Builder(); nm, _ = sd.replay(b)
+    HostSim(b, nm[ok])  # four nested textures: the device stack's capacity
+    deep = sd.transform(sd.group([sd.tex(ok, m)]), [api.translate((0.0, 0.0, 1.0))])  # a fifth, two composites further out
+    b = api.Builder(); nm, _ = sd.replay(b)
+    with pytest.raises(RuntimeError, match="nested textures"):
+        HostSim(b, nm[deep])

@@ -190,6 +190,17 @@ def test_adaptive_sampler_of_two_independent_restatements_agrees(built, name, w,
     assert np.allclose(got[..., 4][fin], ref[..., 4][fin], rtol=1e-10)
 
 
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_random_composite_scenes_through_both_restatements(built, seed):
+    """zoo.random_composites(seed) -- random nestings of every construct -- through the C++ oracle and oracle/np_scene.py: the
+    same frame (to rounding) and the same ray counts."""
+    import zoo
+    ref, rc, got, sc = _frames(zoo.random_composites(seed), 64, 36, 3)
+    assert np.array_equal(got[..., 4] < 1e6, ref[..., 4] < 1e6)
+    assert np.allclose(got[..., :4], ref[..., :4], rtol=1e-10, atol=1e-12), float(np.abs(got[..., :4] - ref[..., :4]).max())
+    assert sc.rays == [rc["rays_primary"], rc["rays_shadow"], rc["rays_secondary"]]
+
+
 def test_bih_trees_of_two_independent_builders_are_the_same(built):
     """build_rec (Bih.hs:211-285) twice: the oracle's tree (through the product's host builder, which test_host_builder pins
     to the oracle's) against np_scene's, node for node -- split planes, axes, leaf contents in order."""

@@ -250,3 +250,65 @@ testscene = scenes.testscene  # GlomeView's default scene (TestScene.hs:183-197)
 
 
 ALL["testscene"] = lambda: testscene(4)  # (a 9x9x9 lattice keeps the CPU oracle's frames in seconds; the GPU tests also run the 21x21x21 one)
+
+
+def random_composites(seed, n_items=9, max_depth=3):
+    """A random scene in TestScene.hs vocabulary: primitives of every family under random Tex stacks, grouped, instanced with
+    random (rotate, non-uniform scale, translate) transforms, carved (Difference) and intersected, nested up to `max_depth`
+    composite levels, some of it under a `bih`.  Seeded: the same seed gives the same scene on every backend."""
+    rng = np.random.default_rng(seed)
+    sd = SceneDesc()
+    m = scenes.materials(sd)
+    mats = [m["shiny_white"], m["shiny_red"], m["mirror"], scenes.matte(sd, (0.2, 0.3, 0.9)), sd.material_refract(0.3, 0.7, 1.4),
+            sd.material_blend_fn(m["shiny_white"], m["shiny_red"], api.WEIGHT_STRIPE_TRIANGLE, [2, 3, 1])]
+    U = lambda a, b: float(rng.uniform(a, b))
+
+    def prim(c):
+        k = int(rng.integers(0, 6))
+        if k == 0: return sd.sphere(c, U(0.4, 1.1))
+        if k == 1: return sd.box((c[0] - U(0.3, 0.9), c[1] - U(0.3, 0.9), c[2] - U(0.3, 0.9)), (c[0] + U(0.3, 0.9), c[1] + U(0.3, 0.9), c[2] + U(0.3, 0.9)))
+        if k == 2: return sd.cone((c[0], c[1] - 0.6, c[2]), U(0.4, 0.9), (c[0] + U(-0.4, 0.4), c[1] + U(0.5, 1.2), c[2] + U(-0.4, 0.4)), U(0.0, 0.35))
+        if k == 3: return sd.cylinder((c[0] - 0.5, c[1], c[2]), (c[0] + U(0.3, 0.9), c[1] + U(-0.3, 0.6), c[2] + U(-0.3, 0.3)), U(0.25, 0.6))
+        if k == 4: return sd.triangle((c[0] - 0.8, c[1] - 0.4, c[2]), (c[0] + 0.8, c[1] - 0.3, c[2] + U(-0.4, 0.4)), (c[0] + U(-0.3, 0.3), c[1] + 0.9, c[2] + U(-0.3, 0.3)))
+        return sd.disc(c, (0.0, 0.6, 0.8), U(0.4, 0.9))
+
+    def solid_prim(c):  # something with an inside (CSG operands)
+        k = int(rng.integers(0, 3))
+        if k == 0: return sd.sphere(c, U(0.5, 1.1))
+        if k == 1: return sd.box((c[0] - U(0.4, 0.9), c[1] - U(0.4, 0.9), c[2] - U(0.4, 0.9)), (c[0] + U(0.4, 0.9), c[1] + U(0.4, 0.9), c[2] + U(0.4, 0.9)))
+        return sd.cone((c[0], c[1] - 0.7, c[2]), U(0.5, 0.9), (c[0], c[1] + U(0.6, 1.1), c[2]), U(0.0, 0.3))
+
+    def xf():
+        ax = np.array([U(-1, 1), U(-1, 1), U(0.2, 1)]); ax = ax / np.sqrt(ax @ ax)
+        return [api.rotate(tuple(float(x) for x in ax), U(-1.2, 1.2)), api.scale((U(0.6, 1.5), U(0.6, 1.5), U(0.6, 1.5))), api.translate((U(-0.8, 0.8), U(-0.2, 0.6), U(-0.8, 0.8)))]
+
+    def tex(n, budget):  # -> (node, textures still allowed above it): at most 4 on any path (the device's texture stack)
+        for _ in range(int(rng.integers(0, 3))):
+            if budget[0] > 0: n = sd.tex(n, mats[int(rng.integers(0, len(mats)))]); budget[0] -= 1
+        return n
+
+    def node(c, depth, budget):
+        k = int(rng.integers(0, 7)) if depth > 0 else 0
+        if k <= 1: return tex(prim(c), budget)
+        near = lambda s: (c[0] + U(-s, s), c[1] + U(-s, s), c[2] + U(-s, s))
+        sub = lambda: [budget[0]]  # every child path starts from what is left here
+        def wrap(make):  # textures outside a composite come out of the budget its children may use
+            outer = [budget[0]]
+            n_out = int(rng.integers(0, 3))
+            inner = [max(0, outer[0] - n_out)]
+            n = make(inner)
+            for _ in range(min(n_out, outer[0])): n = sd.tex(n, mats[int(rng.integers(0, len(mats)))])
+            return n
+        if k == 2: return wrap(lambda bud: sd.group([node(near(0.9), depth - 1, [bud[0]]) for _ in range(int(rng.integers(2, 4)))]))
+        if k == 3: return sd.transform(node(c, depth - 1, [budget[0]]), xf())
+        if k == 4:
+            def mk(bud):
+                a = node(c, depth - 1, [bud[0]]) if rng.uniform() < 0.4 else tex(solid_prim(c), [bud[0]])
+                return sd.difference(a, tex(solid_prim(near(0.6)), [bud[0]]))
+            return wrap(mk)
+        if k == 5: return wrap(lambda bud: sd.intersection([tex(solid_prim(near(0.35)), [bud[0]]) for _ in range(int(rng.integers(2, 4)))]))
+        return sd.bih([node(near(1.2), depth - 1, [budget[0]]) for _ in range(int(rng.integers(2, 5)))])
+
+    items = [node((U(-5, 5), U(0.6, 2.6), U(-4, 4)), max_depth, [4]) for _ in range(n_items)]
+    pl = sd.tex(sd.plane((0, 0, 0), (0, 1, 0)), scenes.matte(sd, (0, 0.8, 0.3)))
+    return _finish(sd, sd.group([pl, sd.bih(items)]))
