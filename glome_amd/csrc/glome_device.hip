@@ -83,6 +83,7 @@ struct GenericTier {
   // `root`: the record the trace runs over -- the scene's, or the frame / scene of a Warp material
   __device__ __forceinline__ HitG closest(const Ray& r, float tmax, uint32_t root) {
     GCtx<true> g{S, cnt, err, pool};
+    g.exact_bih = !unit_length(r.d);  // (Refract's transmitted ray: rt_generic.hpp GCtx)
     HitG h = rayint_g<kGenericDepth>(g, ldu4(S.recs, root), r, tmax, (TexStack)0);
     err = g.err;
     return h;
@@ -426,10 +427,10 @@ __device__ __forceinline__ void ss_frame_loop(const DRenderArgs& A, TIER& T) {
     }
   }
 }
-template <bool FULL, int CLS, int LB = 1, bool TWO_ROWS = false>
+template <bool FULL, int CLS, int LB = 1, bool TWO_ROWS = false, bool FAITHFUL = false>
 __global__ void __launch_bounds__(64, LB) k_ss_frame_flat(DRenderArgs A, int stack_cap, uint32_t* ovf, int ovf_cap) {
   extern __shared__ uint32_t lds[];
-  FlatTier<false, false, FULL, CLS> T{A.S, A.lights, A.nlights, lane_stack<TWO_ROWS>(lds, stack_cap, ovf, ovf_cap), Cnt()};
+  FlatTier<FAITHFUL, false, FULL, CLS> T{A.S, A.lights, A.nlights, lane_stack<TWO_ROWS>(lds, stack_cap, ovf, ovf_cap), Cnt()};
   ss_frame_loop(A, T);
   if (A.want_counters) flush_counters(A.counters, T.cnt, T.err);
   else if ((CLS & CLS_CSG) && __builtin_amdgcn_ballot_w64(T.err != 0) && (threadIdx.x & 63) == 0) atomicOr(&A.counters->error, 1u);
@@ -466,8 +467,15 @@ template <bool FAITHFUL>
 __global__ void __launch_bounds__(64) k_rayint_batch_flat(DScene S, size_t n, RayStream R, HitStream H, int stack_cap, uint32_t* ovf, int ovf_cap, DCounters* c) {
   extern __shared__ uint32_t lds[];
   FlatTier<FAITHFUL, false, false, CLS_EVERY> T{S, nullptr, 0, lane_stack(lds, stack_cap, ovf, ovf_cap), Cnt()};
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    store_hit(H, i, T.closest(load_ray(R, i), R.tmax[i]));
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const Ray r = load_ray(R, i);
+    if (FAITHFUL || unit_length(r.d)) { store_hit(H, i, T.closest(r, R.tmax[i])); continue; }
+    // a caller's ray that is not unit length: the reference's own traversal (rayint_sphere reports hits for such rays that lie
+    // outside the sphere's box, so the ordered early-out's pruning is not exact for them)
+    HitG ch;
+    Cand c = closest_flat<true, false, CLS_EVERY>(S, r, R.tmax[i], T.stk, T.cnt, true, &ch, &T.err);
+    store_hit(H, i, finalize_flat<CLS_EVERY>(S, r, c, &ch));
+  }
   if (T.err) atomicOr(&c->error, 1u);
 }
 __global__ void __launch_bounds__(64) k_shadow_batch_flat(DScene S, size_t n, RayStream R, uint8_t* occ, int stack_cap, uint32_t* ovf, int ovf_cap, DCounters* c) {
@@ -578,6 +586,7 @@ struct glome_scene {
   glome_scene_info info{};
   int stack_cap = 8;
   bool has_secondary_mats = false, has_nested_mats = false;
+  bool has_refract = false;  // a Refract material: its transmitted rays are not unit length (Shader.hs:141) -- see launch_render
   int cls_mask = CLS_ALL;  // which entry classes the flat root program contains
 };
 
@@ -822,6 +831,7 @@ glome_scene* glome_scene_commit(glome_ctx* ctx, glome_sb* sb, int32_t root) {
   I.max_bih_depth = F.max_bih_depth; I.max_mesh_depth = F.max_mesh_depth;
   for (const Mat& m : sb_graph(sb).mats) {
     if (m.kind == MAT_REFLECT || m.kind == MAT_REFRACT || m.kind == MAT_WARP) s->has_secondary_mats = true;
+    if (m.kind == MAT_REFRACT) s->has_refract = true;
     if (m.kind == MAT_LAYERS || m.kind == MAT_BLEND) s->has_nested_mats = true;
   }
   if (F.tier == 0) {
@@ -937,6 +947,11 @@ static bool use_two_rows(const glome_scene* s, const glome_render_params* P, uin
 static void launch_render(glome_scene* s, const DRenderArgs& A, const glome_render_params* P, int grid, size_t lds) {
   hipStream_t st = s->ctx->stream;
   bool faithful = P->faithful != 0, count = P->count_work != 0 || faithful;
+  // A scene with a Refract material, traced deeper than the primary ray: the transmitted rays are not unit length
+  // (Shader.hs:141), and for those rayint_sphere (Sphere.hs:20-41) reports hits outside the sphere's box -- the ordered
+  // early-out's pruning is exact only for unit rays, so such a frame is traversed as the reference traverses (the flat
+  // tier's faithful instance; the generic tier switches per ray, rt_generic.hpp).
+  if (s->dev.tier == 0 && s->has_refract && P->maxdepth > 1) faithful = count = true;
   if (s->dev.tier == 0) {
     // lean kernel: legal when no secondary trace can do work and no material nests (Blend / AdditiveLayers)
     bool full = s->has_nested_mats || (s->has_secondary_mats && P->maxdepth > 1);
@@ -1060,7 +1075,9 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
     else if (two_rows && big_tree) hipLaunchKernelGGL((k_ss_frame_flat<false, CLS_BIH_TRI, 5, true>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
     else if (two_rows) hipLaunchKernelGGL((k_ss_frame_flat<false, CLS_BIH_TRI, 4, true>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
     else if (tri && !full) hipLaunchKernelGGL((k_ss_frame_flat<false, CLS_BIH_TRI>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
-    else if (tri) hipLaunchKernelGGL((k_ss_frame_flat<true, CLS_BIH_TRI>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
+    else if (tri && !(s->has_refract && P->maxdepth > 1)) hipLaunchKernelGGL((k_ss_frame_flat<true, CLS_BIH_TRI>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
+    // (a Refract material traced deeper than the primary ray: the reference's own traversal, see launch_render)
+    else if (full && s->has_refract && P->maxdepth > 1) hipLaunchKernelGGL((k_ss_frame_flat<true, CLS_EVERY, 1, false, true>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
     else if (!full) hipLaunchKernelGGL((k_ss_frame_flat<false, CLS_EVERY, 2>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
     else hipLaunchKernelGGL((k_ss_frame_flat<true, CLS_EVERY, 2>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
     HIPCHK(ctx, hipGetLastError());

@@ -138,9 +138,9 @@ GD void bbclip_ub_rcp(V3 o, V3 rcp, V3 lo, V3 hi, float& nearv, float& farv) {
 // keeps full precision, so the fp32 result lands on the reference's fp64 value.  glome's rays are unit length
 // except Refract's transmitted direction (Shader.hs:141, unnormalised as written); those keep the reference form,
 // which is what the fp64 path computes for them.
+GD bool unit_length(V3 dir) { const float dd = vdot(dir, dir); return dd > 0.99999f && dd < 1.00001f; }
 GD float sphere_disc(V3 eo, V3 dir, float v, float r) {
-  float dd = vdot(dir, dir);
-  if (dd > 0.99999f && dd < 1.00001f) {
+  if (unit_length(dir)) {
     V3 perp = eo - dir * v;
     return r * r - vdot(perp, perp);
   }

@@ -24,6 +24,10 @@ template <bool COUNT> struct GCtx {
   unsigned int err;
   GPool& pool;
   int fr_top = 0, adv_top = 0;
+  // the ray of this call is not unit length (Refract's transmitted ray, Shader.hs:141): BIHs are then walked exactly as the
+  // reference walks them (no ordered early-out) -- rayint_sphere's formula (Sphere.hs:20-41) reports hits for such a ray that
+  // lie outside the sphere's box, so `nearer than the best so far` no longer follows from a node's interval
+  bool exact_bih = false;
 };
 
 template <int D, bool C> struct G;  // the four class methods at nesting budget D
@@ -103,7 +107,10 @@ template <int D, bool C> struct G {
           V3 newdir = mat_vec(x.i0, x.i1, x.i2, r.d), neworig = mat_point(x.i0, x.i1, x.i2, r.o);
           float lenscale = sqrtf(vdot(newdir, newdir)), invlenscale = 1.0f / lenscale;
           Ray lr; lr.o = neworig; lr.d = newdir * invlenscale;
+          const bool exact_outside = g.exact_bih;
+          g.exact_bih = false;  // (the local ray is unit length)
           HitG h = rayint_g<D - 1>(g, ldu4(S.recs, rec.y), lr, d * lenscale, tex);
+          g.exact_bih = exact_outside;
           if (!h.hit) return h;
           h.t = h.t * invlenscale;
           h.p = mat_point(x.f0, x.f1, x.f2, h.p);
@@ -246,6 +253,15 @@ template <int D, bool C> struct G {
     const DScene& S = g.S;
     PrivStack stk;
     HitG best = hit_miss();
+    if (g.exact_bih) {  // a ray that is not unit length: the reference's own visits, every item with tmax = far (Bih.hs:332-368)
+      bih_traverse<0, C>(S, rec.y, r, d, stk, kGenericStack, g.cnt,
+        [&](uint32_t frec, uint32_t, uint32_t count, float tmax) {
+          for (uint32_t k = 0; k < count; k++) best = nearest_hit(best, rayint_g<D - 1>(g, ldu4(S.recs, frec + k), r, tmax, tex));
+          return false;
+        },
+        [&]() { return kInf * 4.0f; });
+      return best;
+    }
     bih_traverse<1, C>(S, rec.y, r, d, stk, kGenericStack, g.cnt,
       [&](uint32_t frec, uint32_t, uint32_t count, float tmax) {
         for (uint32_t k = 0; k < count; k++) {

@@ -41,7 +41,7 @@ struct HostGenericTier {
   int nlights;
   Cnt cnt;
   unsigned int err = 0;
-  HitG closest(const Ray& r, float tmax, uint32_t root) { GPool pool; GCtx<true> g{S, cnt, err, pool}; HitG h = rayint_g<kGenericDepth>(g, S.recs[root], r, tmax, (TexStack)0); err = g.err; return h; }
+  HitG closest(const Ray& r, float tmax, uint32_t root) { GPool pool; GCtx<true> g{S, cnt, err, pool}; g.exact_bih = !unit_length(r.d); HitG h = rayint_g<kGenericDepth>(g, S.recs[root], r, tmax, (TexStack)0); err = g.err; return h; }
   bool occluded(const Ray& r, float d, uint32_t root) { GPool pool; GCtx<true> g{S, cnt, err, pool}; bool o = shadow_g<kGenericDepth>(g, S.recs[root], r, d); err = g.err; return o; }
   HitG closest(const Ray& r, float tmax) { return closest(r, tmax, S.root_rec); }
   bool occluded(const Ray& r, float d) { return occluded(r, d, S.root_rec); }
@@ -60,6 +60,13 @@ struct HostStack {
     return s;
   }
 };
+
+// the product's launch rule (glome_device.hip launch_render): a flat-tier frame of a scene with a Refract material, traced
+// deeper than the primary ray, is traversed as the reference traverses (its transmitted rays are not unit length)
+static bool refract_scene(const SimScene* s) {
+  for (uint32_t k = 0; k < s->D.n_mats; k++) { uint32_t kind; memcpy(&kind, &s->D.mats[3 * k].x, 4); if (kind == DM_REFRACT) return true; }
+  return false;
+}
 
 extern "C" {
 void* hostsim_commit(glome_sb* sb, int root, char* errbuf, int cap) {
@@ -98,6 +105,7 @@ int hostsim_rayint(void* sv, int tier, int analysis, size_t n, const float* ox, 
     HitG h;
     if (tier == 0) {
       if (analysis & 1) { HostFlatTier<true, true, false> T{s->D, nullptr, 0, hs.lane(kFlatStack), Cnt()}; h = (analysis & 2) ? T.closest_wave(r, tmax[i], true) : T.closest(r, tmax[i]); total.bih += T.cnt.bih; total.prim += T.cnt.prim; total.mesh += T.cnt.mesh; }
+      else if (!unit_length(r.d)) { HostFlatTier<true, false, false> T{s->D, nullptr, 0, hs.lane(kFlatStack), Cnt()}; h = T.closest(r, tmax[i]); }  // (k_rayint_batch_flat's rule for a caller's non-unit ray)
       else { HostFlatTier<false, false, false> T{s->D, nullptr, 0, hs.lane(kFlatStack), Cnt()}; h = (analysis & 2) ? T.closest_wave(r, tmax[i], true) : T.closest(r, tmax[i]); }
     } else {
       HostGenericTier T{s->D, nullptr, 0, Cnt()};
@@ -144,13 +152,15 @@ int hostsim_render(void* sv, int tier, const float* cam, const float* lights, in
   HostStack hs;
   Cnt total;
   unsigned int err = 0;
+  const bool exact = refract_scene(s) && maxdepth > 1;
   for (int py = 0; py < height; py++)
     for (int px = 0; px < width; px++) {
       float xc, yc;
       get_coordsf(width, height, (float)px, (float)py, xc, yc);
       Ray ray = primary_ray(C, xc, yc);
       HitG h; CA c;
-      if (tier == 0) { HostFlatTier<false, false, true> T{s->D, L, nl, hs.lane(kFlatStack), Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, true, &h); total.shadow += T.cnt.shadow; total.secondary += T.cnt.secondary; }
+      if (tier == 0 && exact) { HostFlatTier<true, false, true> T{s->D, L, nl, hs.lane(kFlatStack), Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, true, &h); total.shadow += T.cnt.shadow; total.secondary += T.cnt.secondary; }
+      else if (tier == 0) { HostFlatTier<false, false, true> T{s->D, L, nl, hs.lane(kFlatStack), Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, true, &h); total.shadow += T.cnt.shadow; total.secondary += T.cnt.secondary; }
       else { HostGenericTier T{s->D, L, nl, Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, true, &h); err |= T.err; total.shadow += T.cnt.shadow; total.secondary += T.cnt.secondary; }
       float* o = out5 + ((size_t)py * width + px) * 5;
       o[0] = c.r; o[1] = c.g; o[2] = c.b; o[3] = c.a; o[4] = h.hit ? h.t : kInf;
@@ -202,12 +212,14 @@ int hostsim_render_subsample(void* sv, int tier, const float* cam, const float* 
   HostStack hs;
   unsigned long long nprim = 0, nshadow = 0, nsec = 0;
   unsigned int err = 0;
+  const bool exact = refract_scene(s) && maxdepth > 1;
   auto sample = [&](float xp, float yp) {
     float xc, yc; get_coordsf(width, height, xp, yp, xc, yc);
     Ray ray = primary_ray(C, xc, yc);
     HitG h; CA c;
     nprim++;
-    if (tier == 0) { HostFlatTier<false, false, true> T{s->D, L, nl, hs.lane(kFlatStack), Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, true, &h); nshadow += T.cnt.shadow; nsec += T.cnt.secondary; }
+    if (tier == 0 && exact) { HostFlatTier<true, false, true> T{s->D, L, nl, hs.lane(kFlatStack), Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, true, &h); nshadow += T.cnt.shadow; nsec += T.cnt.secondary; }
+    else if (tier == 0) { HostFlatTier<false, false, true> T{s->D, L, nl, hs.lane(kFlatStack), Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, true, &h); nshadow += T.cnt.shadow; nsec += T.cnt.secondary; }
     else { HostGenericTier T{s->D, L, nl, Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, true, &h); err |= T.err; nshadow += T.cnt.shadow; nsec += T.cnt.secondary; }
     return tc(c.r, c.g, c.b, c.a, h.hit ? h.t : kInf);
   };

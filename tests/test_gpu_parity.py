@@ -854,11 +854,12 @@ def test_refused_parameters_fail_with_a_status_not_a_frame(gpu_ctx):
     sc.release()
 
 
-@pytest.mark.parametrize("seed", [0, 4, 7, 23, 36, 56])
-def test_random_composite_scenes_on_the_gpu(gpu_ctx, seed):
+@pytest.mark.parametrize("gen,seed", [("composites", 0), ("composites", 4), ("composites", 7), ("composites", 23), ("composites", 36), ("composites", 56),
+                                      ("flat", 3), ("flat", 12), ("flat", 51), ("flat", 77)])
+def test_random_composite_scenes_on_the_gpu(gpu_ctx, gen, seed):
     """The fuzz of tests/test_hostsim_parity.py (zoo.random_composites) through the C ABI: seeds that exposed differences on the
     host compile of the device headers, and a few that never did."""
-    sd = zoo.random_composites(seed)
+    sd = (zoo.random_composites if gen == "composites" else zoo.random_flat)(seed)
     b, nm, sc = commit(gpu_ctx, sd)
     parity.check_rays(lambda o, d: sc.rayint(o, d), lambda o, d, t: sc.shadow(o, d, t), sc.inside, sd, nm, n=20000)
     cam, lights = product_camera_lights(sd)

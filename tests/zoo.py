@@ -312,3 +312,53 @@ def random_composites(seed, n_items=9, max_depth=3):
     items = [node((U(-5, 5), U(0.6, 2.6), U(-4, 4)), max_depth, [4]) for _ in range(n_items)]
     pl = sd.tex(sd.plane((0, 0, 0), (0, 1, 0)), scenes.matte(sd, (0, 0.8, 0.3)))
     return _finish(sd, sd.group([pl, sd.bih(items)]))
+
+
+def random_flat(seed, n_items=14):
+    """A random scene the flat tier renders: primitives of every family under Tex stacks and shadow flags, cylinders / cones,
+    Differences / Intersections over primitives and Instances of those (the flat CSG class), under one `bih`, plus items
+    outside it and, sometimes, a second `bih` of triangles only (the packet walk) or of spheres only."""
+    rng = np.random.default_rng(1000 + seed)
+    sd = SceneDesc()
+    m = scenes.materials(sd)
+    mats = [m["shiny_white"], m["shiny_red"], m["mirror"], scenes.matte(sd, (0.2, 0.3, 0.9)), sd.material_refract(0.3, 0.7, 1.4)]
+    U = lambda a, b: float(rng.uniform(a, b))
+    C = lambda: (U(-5, 5), U(0.5, 2.8), U(-4, 4))
+    near = lambda c, s: (c[0] + U(-s, s), c[1] + U(-s, s), c[2] + U(-s, s))
+
+    def solid(c):
+        k = int(rng.integers(0, 3))
+        if k == 0: return sd.sphere(c, U(0.5, 1.1))
+        if k == 1: return sd.box((c[0] - U(0.4, 0.9), c[1] - U(0.4, 0.9), c[2] - U(0.4, 0.9)), (c[0] + U(0.4, 0.9), c[1] + U(0.4, 0.9), c[2] + U(0.4, 0.9)))
+        return sd.cone((c[0], c[1] - 0.7, c[2]), U(0.5, 0.9), (c[0], c[1] + U(0.6, 1.1), c[2]), U(0.0, 0.3))
+
+    def tex(n, k=None):
+        for _ in range(int(rng.integers(0, 3)) if k is None else k): n = sd.tex(n, mats[int(rng.integers(0, len(mats)))])
+        return n
+
+    def item():
+        c = C()
+        k = int(rng.integers(0, 10))
+        if k == 0: return tex(sd.sphere(c, U(0.4, 1.0)))
+        if k == 1: return tex(sd.box((c[0] - 0.6, c[1] - 0.5, c[2] - 0.7), (c[0] + U(0.3, 0.9), c[1] + U(0.3, 0.9), c[2] + U(0.3, 0.9))))
+        if k == 2: return tex(sd.triangle((c[0] - 0.9, c[1] - 0.4, c[2]), (c[0] + 0.9, c[1] - 0.3, c[2] + U(-0.4, 0.4)), (c[0], c[1] + 1.0, c[2] + U(-0.3, 0.3))))
+        if k == 3: return tex(sd.cylinder((c[0] - 0.5, c[1], c[2]), (c[0] + U(0.3, 0.9), c[1] + U(-0.3, 0.6), c[2]), U(0.25, 0.6)))
+        if k == 4: return tex(sd.cone((c[0], c[1] - 0.6, c[2]), U(0.4, 0.9), (c[0] + U(-0.3, 0.3), c[1] + U(0.5, 1.2), c[2]), U(0.0, 0.35)))
+        if k == 5: return tex(sd.disc(c, (0.0, 0.6, 0.8), U(0.4, 0.9)))
+        if k == 6: return tex(sd.difference(tex(solid(c), 1), tex(solid(near(c, 0.6)), int(rng.integers(0, 2)))), int(rng.integers(0, 2)))
+        if k == 7: return tex(sd.intersection([tex(solid(near(c, 0.35)), int(rng.integers(0, 2))) for _ in range(int(rng.integers(2, 4)))]), 1)
+        if k == 8:
+            ax = np.array([U(-1, 1), U(-1, 1), U(0.2, 1)]); ax = ax / np.sqrt(ax @ ax)
+            inner = tex(solid(c), 1) if rng.uniform() < 0.5 else sd.difference(tex(solid(c), 1), solid(near(c, 0.5)))
+            return tex(sd.transform(inner, [api.rotate(tuple(float(x) for x in ax), U(-1, 1)), api.scale((U(0.7, 1.4), U(0.7, 1.4), U(0.7, 1.4)))]), int(rng.integers(0, 2)))
+        w = tex(sd.sphere(c, U(0.4, 0.9)), 1)
+        return sd.noshadow(w) if rng.uniform() < 0.5 else sd.onlyshadow(w)
+
+    pl = sd.tex(sd.plane((0, 0, 0), (0, 1, 0)), scenes.matte(sd, (0, 0.8, 0.3)))
+    parts = [pl, sd.bih([item() for _ in range(n_items)]), item(), item()]
+    extra = int(rng.integers(0, 3))
+    if extra == 1:
+        parts.append(sd.tex(sd.bih([sd.triangle((x, 0.2 + 0.3 * ((x * 7 + z * 3) % 5), z), (x + 1, 0.3, z), (x, 0.4, z + 1)) for x in range(-4, 4) for z in range(-9, -5)]), mats[3]))
+    if extra == 2:
+        parts.append(sd.bih([sd.tex(sd.sphere((float(x), 0.4, float(z)), 0.35), mats[(x + z) % 2]) for x in range(-4, 4) for z in range(5, 8)]))
+    return _finish(sd, sd.group(parts))
