@@ -463,7 +463,13 @@ struct PrivStack {
 // the reference held in its parent: reaching it costs no memory fetch, and an empty leaf (a quarter of the leaves the
 // reference builder makes) is never visited at all.  Branch references are plain node indices.
 constexpr uint32_t BREF_LEAF = 1u << 29, BREF_MASK = (1u << 30) - 1u, BREF_FIRST = (1u << 26) - 1u, BREF_CONT = 1u << 30;
-template <int MODE, bool COUNT, class STK, class LEAF, class BEST>
+// CLAMP (MODE 1): whether a leaf's items may be tested with tmax = min(far, best so far).  That is exact for items whose
+// rayint reports the same hit for every tmax beyond it (spheres, triangles, boxes, planes, discs).  The reference's cylinder
+// and cone are not like that: with the origin inside the infinite quadric, `dist = t1` (the far root) is compared with tmax
+// BEFORE the end discs are looked at (Cone.hs:122-139, 176-191), so a tighter tmax turns a cap hit into a miss.  With CLAMP
+// false the running best only decides which nodes are still worth entering; the items see the node's own `far`, as in the
+// reference (`rayint s r far`, Bih.hs:339).
+template <int MODE, bool COUNT, bool CLAMP = true, class STK, class LEAF, class BEST>
 GD void bih_traverse(const DScene& S, uint32_t hdr, const Ray& r, float d, STK& stk, int stack_cap, Cnt& cnt, LEAF&& leaf, BEST&& best_t) {
   F4 h0 = ld4(S.bihhdr, 3 * hdr), h1 = ld4(S.bihhdr, 3 * hdr + 1);
   const uint32_t delta = as_u(ld4(S.bihhdr, 3 * hdr + 2).x);  // first_prim - first_rec: constant per homogeneous BIH
@@ -480,6 +486,7 @@ GD void bih_traverse(const DScene& S, uint32_t hdr, const Ray& r, float d, STK& 
   int sp = 0;
   for (;;) {
     bool popit = true;
+    float geo_far = farv;  // the node's interval as the planes cut it (what its items are tested with when !CLAMP)
     if (MODE == 1) farv = gminf(farv, best_t());
     if (ref & BREF_LEAF) {
       // BihLeaf: `rayint s r far` -- the reference tests a leaf it has reached without looking at near > far
@@ -488,7 +495,7 @@ GD void bih_traverse(const DScene& S, uint32_t hdr, const Ray& r, float d, STK& 
       uint32_t count = (ref >> 26) & 7u, first = ref & BREF_FIRST;
       if (count == 7u) { F4 n = ld4(S.bihnodes, first); count = as_u(n.z); first = as_u(n.w); }
       if (count != 0 && (MODE == 0 || root_leaf || !(nearv > farv))) {
-        if (leaf(first, first + delta, count, farv)) return;
+        if (leaf(first, first + delta, count, (MODE == 1 && !CLAMP) ? geo_far : farv)) return;
       }
     } else {
       if (COUNT) cnt.bih++;  // rayint_debug_bih counts every branch entered, before the near > far test (Bih.hs:389-410)
@@ -505,6 +512,10 @@ GD void bih_traverse(const DScene& S, uint32_t hdr, const Ray& r, float d, STK& 
         // an empty leaf holds nothing to test: never visit it (no effect on results or on the branch-visit counts)
         go1 = go1 && c1 != BREF_LEAF;
         go2 = go2 && c2 != BREF_LEAF;
+        if (MODE == 1 && !CLAMP) {  // the children keep the interval the planes give them; `best` only decided go1 / go2
+          c1far = gminf(dirr > 0 ? dl : dr, geo_far);
+          farv = geo_far;
+        }
         if (go1) {
           if (go2 && sp < stack_cap) { stk.push(sp, c2, c2near, farv); sp++; }
           ref = c1; farv = c1far; popit = false;
@@ -1199,11 +1210,12 @@ GD Cand closest_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt,
         else bih_tri<FAITHFUL ? 0 : 1, COUNT, 1>(S, rec.y, r, dd, stk, cnt, bt, brec);
         if (brec != CAND_NONE) { best.t = bt; best.id = brec; best.aux = e; }
       } else if ((CLS & CLS_CSG) && cls == BC_CSG) {  // primitives and CSG over primitives: every item evaluated in full
-        bih_traverse<FAITHFUL ? 0 : 1, COUNT>(S, rec.y, r, dd, stk, stk.total_cap(), cnt,
+        // (items here may be cylinders / cones, whose rayint depends on tmax beyond the hit: no clamping, see bih_traverse)
+        bih_traverse<FAITHFUL ? 0 : 1, COUNT, false>(S, rec.y, r, d, stk, stk.total_cap(), cnt,
           [&](uint32_t frec, uint32_t, uint32_t count, float tmax) {
             for (uint32_t k = 0; k < count; k++) {
               const HitG h = csg_item_rayint<COUNT>(S, cnt, *err, ldu4(S.recs, frec + k), r, tmax, (TexStack)ent.y);  // `rayint s r far`
-              if (h.hit && (best.id == CAND_NONE || !(best.t < h.t))) { best.t = h.t; best.id = frec + k; best.aux = e | CAND_CSG; *csgh = h; if (!FAITHFUL) tmax = gminf(tmax, best.t); }
+              if (h.hit && (best.id == CAND_NONE || !(best.t < h.t))) { best.t = h.t; best.id = frec + k; best.aux = e | CAND_CSG; *csgh = h; }
             }
             return false;
           }, bestt);
@@ -1225,7 +1237,7 @@ GD Cand closest_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt,
       mesh_closest<COUNT>(S, rec.y, r, d, stk, stk.total_cap(), cnt, mt, mtri);  // depth = the list's d (Q12)
       if (mtri != 0xffffffffu && (best.id == CAND_NONE || !(best.t < mt))) { best.t = mt; best.id = mtri; best.aux = e | CAND_MESH; }
     } else if ((CLS & CLS_CSG) && (kind == R_DIFF || kind == R_ISECT || kind == R_INSTANCE || kind == R_TEX)) {  // a CSG item in the root list
-      const HitG h = csg_item_rayint<COUNT>(S, cnt, *err, rec, r, dd, (TexStack)ent.y);
+      const HitG h = csg_item_rayint<COUNT>(S, cnt, *err, rec, r, d, (TexStack)ent.y);  // (every list item with the same d, Solid.hs:327: a cone's answer depends on it)
       if (h.hit && (best.id == CAND_NONE || !(best.t < h.t))) { best.t = h.t; best.id = ent.x; best.aux = e | CAND_CSG; *csgh = h; }
     } else if ((CLS & CLS_PRIMS) && kind != R_VOID && kind != R_MESH && kind <= R_CONE) {
       float t; V3 n;

@@ -262,12 +262,18 @@ template <int D, bool C> struct G {
         [&]() { return kInf * 4.0f; });
       return best;
     }
-    bih_traverse<1, C>(S, rec.y, r, d, stk, kGenericStack, g.cnt,
+    // ordered early-out: the best hit so far decides which nodes are still worth entering, but every item is tested with its
+    // node's own `far` (`rayint s r far`, Bih.hs:339) -- an item may be a cylinder or a cone, whose answer depends on tmax
+    // beyond the hit (rt_device.hpp bih_traverse, CLAMP)
+    bih_traverse<1, C, false>(S, rec.y, r, d, stk, kGenericStack, g.cnt,
       [&](uint32_t frec, uint32_t, uint32_t count, float tmax) {
         for (uint32_t k = 0; k < count; k++) {
-          HitG h = rayint_g<D - 1>(g, ldu4(S.recs, frec + k), r, tmax, tex);  // `rayint s r far`
-          best = nearest_hit(best, h);
-          if (best.hit) tmax = gminf(tmax, best.t);
+          const U4 it = ldu4(S.recs, frec + k);
+          // a plain primitive other than a quadric (under any Tex wrappers) answers the same for every tmax beyond its hit:
+          // it may be tested against the best so far (the lattice of GlomeView's default scene is 9261 such spheres)
+          const uint32_t ik = skip_tex(S, it).x & RF_KINDMASK;
+          const bool clampable = best.hit && ik >= R_SPHERE && ik <= R_CONE && ik != R_CYL && ik != R_CONE;
+          best = nearest_hit(best, rayint_g<D - 1>(g, it, r, clampable ? gminf(tmax, best.t) : tmax, tex));
         }
         return false;
       },

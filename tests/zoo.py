@@ -326,11 +326,9 @@ def random_flat(seed, n_items=14):
     C = lambda: (U(-5, 5), U(0.5, 2.8), U(-4, 4))
     near = lambda c, s: (c[0] + U(-s, s), c[1] + U(-s, s), c[2] + U(-s, s))
 
-    def solid(c):
-        k = int(rng.integers(0, 3))
-        if k == 0: return sd.sphere(c, U(0.5, 1.1))
-        if k == 1: return sd.box((c[0] - U(0.4, 0.9), c[1] - U(0.4, 0.9), c[2] - U(0.4, 0.9)), (c[0] + U(0.4, 0.9), c[1] + U(0.4, 0.9), c[2] + U(0.4, 0.9)))
-        return sd.cone((c[0], c[1] - 0.7, c[2]), U(0.5, 0.9), (c[0], c[1] + U(0.6, 1.1), c[2]), U(0.0, 0.3))
+    def solid(c):  # CSG operands of the flat tier are primitives proper (a cone is an Instance: the composite fuzz covers those)
+        if rng.uniform() < 0.5: return sd.sphere(c, U(0.5, 1.1))
+        return sd.box((c[0] - U(0.4, 0.9), c[1] - U(0.4, 0.9), c[2] - U(0.4, 0.9)), (c[0] + U(0.4, 0.9), c[1] + U(0.4, 0.9), c[2] + U(0.4, 0.9)))
 
     def tex(n, k=None):
         for _ in range(int(rng.integers(0, 3)) if k is None else k): n = sd.tex(n, mats[int(rng.integers(0, len(mats)))])
