@@ -287,9 +287,32 @@ def random_composites(seed, n_items=9, max_depth=3):
             if budget[0] > 0: n = sd.tex(n, mats[int(rng.integers(0, len(mats)))]); budget[0] -= 1
         return n
 
+    def small_mesh(c):  # a fan of triangles, flat or with vertex normals, some with their own texture (Mesh.hs:27-29)
+        nv = int(rng.integers(4, 8))
+        verts = [(c[0], c[1] + 0.8, c[2])] + [(c[0] + 1.1 * np.cos(2 * np.pi * q / nv), c[1] + U(-0.2, 0.2), c[2] + 1.1 * np.sin(2 * np.pi * q / nv)) for q in range(nv)]
+        smooth = rng.uniform() < 0.5
+        norms = []
+        if smooth:
+            for v in verts:
+                nn = np.array([v[0] - c[0], v[1] - c[1] + 0.6, v[2] - c[2]]); norms.append(tuple(float(x) for x in nn / np.sqrt(nn @ nn)))
+        mm = [mats[int(rng.integers(0, len(mats)))] for _ in range(2)]
+        tris = []
+        for q in range(nv):
+            a_, b_, c_ = 0, 1 + q, 1 + (q + 1) % nv
+            tris.append((a_, b_, c_) + ((a_, b_, c_) if smooth else (-1, -1, -1)) + (int(rng.integers(-1, 2)), -1))
+        return sd.mesh(verts, norms, tris, mm)
+
     def node(c, depth, budget):
-        k = int(rng.integers(0, 7)) if depth > 0 else 0
+        k = int(rng.integers(0, 10)) if depth > 0 else 0
         if k <= 1: return tex(prim(c), budget)
+        if k == 7:  # Bound / InnerBound (Bound.hs): a bounding solid around, or inside, something
+            inner = node(c, depth - 1, [budget[0]])
+            if rng.uniform() < 0.6: return sd.bound_object(sd.sphere(c, U(1.6, 2.6)), inner)
+            return sd.innerbound(tex(sd.sphere(c, U(0.2, 0.5)), [0]), inner)
+        if k == 8:
+            w = node(c, depth - 1, [budget[0]])
+            return sd.noshadow(w) if rng.uniform() < 0.5 else sd.onlyshadow(w)
+        if k == 9: return tex(small_mesh(c), [max(0, budget[0] - 1)])
         near = lambda s: (c[0] + U(-s, s), c[1] + U(-s, s), c[2] + U(-s, s))
         sub = lambda: [budget[0]]  # every child path starts from what is left here
         def wrap(make):  # textures outside a composite come out of the budget its children may use
