@@ -1728,10 +1728,18 @@ template <class TIER> GD CA trace_primary(TIER& T, const Ray& ray, float tmax, i
 }
 
 // ------------------------------------------------------------------ pixel mapping (Glome.hs:27-33, 119-140; Q19)
+// The three quotients are IEEE divisions also on the device (the kernels are built with the fast fp32 division, whose
+// reciprocal is an ulp off): 96 / 192 must be exactly 0.5.  The centre column of an even-width frame then gets xc = 0 and,
+// with an axis-aligned camera, rays with an exactly zero x component -- for which the reference's slab test misses every box
+// and every bih (Q1: (hi - o) / 0 = +inf on the entry side).  The reference renders that column empty; an ulp of error in xc
+// would fill it in.
+// (through fp64: the quotient of two floats taken in double and rounded once more is the correctly rounded fp32 quotient
+// -- 53 >= 2 * 24 + 2 bits -- whatever the fp32 division of the build is; __fdiv_rn follows the build's setting)
+GD float div_ieee(float a, float b) { return (float)((double)a / (double)b); }
 GD void get_coordsf(int width, int height, float xf, float yf, float& xc, float& yc) {
   float widthf = (float)width, heightf = (float)height;
-  xc = (((xf / widthf) * 2) - 1) * (widthf / heightf);
-  yc = -(((yf / heightf) * 2) - 1);
+  xc = (((div_ieee(xf, widthf)) * 2) - 1) * div_ieee(widthf, heightf);
+  yc = -(((div_ieee(yf, heightf)) * 2) - 1);
 }
 GD Ray primary_ray(const DCamera& c, float xc, float yc) {  // get_rayint, Glome.hs:27-33
   V3 fwd = v3(c.fwd[0], c.fwd[1], c.fwd[2]), right = v3(c.right[0], c.right[1], c.right[2]), up = v3(c.up[0], c.up[1], c.up[2]);

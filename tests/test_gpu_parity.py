@@ -878,3 +878,30 @@ def test_random_composite_scenes_on_the_gpu(gpu_ctx, gen, seed):
     assert both.mean() <= 2e-3, (int(both.sum()), np.argwhere(both)[:6].tolist())
     assert st["rays_primary"] == rc["rays_primary"] and abs(st["rays_shadow"] - rc["rays_shadow"]) <= max(8, rc["rays_shadow"] // 100)
     sc.release()
+
+
+def test_axis_aligned_camera_reproduces_the_centre_column(gpu_ctx):
+    """GlomeView's camera looking straight down -z at an even-width frame: the centre column's rays have an x component of
+    exactly +0, for which the reference's slab test (bbclip_ub, Vec.hs:743-762; Q1) misses every box and every bih -- (hi - o)
+    / 0 = +inf on the entry side -- while spheres, cones and instances are hit as usual.  The reference renders that column
+    empty behind boxes and bihs; so must we: the pixel coordinate 96 / 192 has to come out as exactly 0.5 on the device (the
+    kernels are built with the fast fp32 division, which is an ulp off), and the direction's zero keeps its sign."""
+    from glome_amd.scene import SceneDesc
+    W, H = 192, 108
+    for kind in ("box", "bih", "sphere", "cone"):
+        sd = SceneDesc()
+        m = scenes.materials(sd)
+        it = {"box": lambda: sd.box((-2, 0.5, -1), (2, 3.5, 1)), "sphere": lambda: sd.sphere((0, 2, 0), 1.5), "cone": lambda: sd.cone((0, 0.5, 0), 1.5, (0, 3.5, 0), 0.2),
+              "bih": lambda: sd.bih([sd.sphere((-1.0, 2, 0), 1.2), sd.sphere((1.0, 2, 0), 1.2), sd.sphere((0, 3.5, 0), 0.7)])}[kind]()
+        sd.set_root(sd.group([sd.tex(it, m["shiny_red"])]))
+        sd.add_light(*scenes.LIGHTS[0]); sd.set_camera((0.0, 2.0, 12.0), (0.0, 2.0, 0.0), (0, 1, 0), 45.0)
+        b, nm, sc = commit(gpu_ctx, sd)
+        cam, lights = product_camera_lights(sd)
+        o, om, _ = oracle_for(sd)
+        for mode in (0, 1):
+            img, _, st = sc.render(cam, lights, api.render_params(width=W, height=H, maxdepth=1, mode=mode))
+            ref, _, rc = o.render(W, H, maxdepth=1, mode=mode, want_packed=False)
+            assert np.array_equal(img[..., 3] > 0, ref[..., 3] > 0), (kind, mode)  # the same pixels are covered, column 96 included
+            if mode == 0:
+                assert (ref[:, 96, 3] > 0).sum() == (0 if kind in ("box", "bih") else (ref[:, 95, 3] > 0).sum())
+        sc.release()

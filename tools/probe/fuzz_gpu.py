@@ -1,0 +1,50 @@
+"""GPU fuzz soak: zoo.random_flat / zoo.random_composites scenes through the C ABI against the fp64 oracle and the same oracle in
+fp32 (a pixel away from both is logic, not rounding), renderTile and renderTileSubsample, plus early-out vs faithful frames.
+usage: python fuzz_gpu.py [n_flat] [n_composites]"""
+import os, sys, time
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+import numpy as np
+import zoo
+from helpers import oracle_for, product_camera_lights
+from glome_amd import api
+nf = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+nc = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+ctx = api.Context(0)
+W, H = 192, 108
+worst, bad, refused = 0, [], 0
+t0 = time.time()
+err = lambda a, r: (np.abs(a[..., :4] - r[..., :4]) / np.maximum(1, np.abs(r[..., :4]))).max(-1)
+for gen, n in ((zoo.random_flat, nf), (zoo.random_composites, nc)):
+    for seed in range(100, 100 + n):
+        sd = gen(seed)
+        b = api.Builder(); nm, _ = sd.replay(b)
+        try:
+            sc = ctx.commit(b, nm[sd.root])
+        except api.GlomeError:
+            refused += 1; continue
+        # a random view and light rig per scene: axis-aligned and inside-the-scene cameras, 1-4 lights, some without shadows, some of finite reach
+        rng = np.random.default_rng(7000 + seed)
+        k = int(rng.integers(0, 4))
+        if k == 0: sd.set_camera((0.0, 2.0, 12.0), (0.0, 2.0, 0.0), (0, 1, 0), 45.0)          # rays with a zero x component down the middle column
+        elif k == 1: sd.set_camera((float(rng.uniform(-3, 3)), float(rng.uniform(0.5, 3)), float(rng.uniform(-3, 3))), (0.0, 1.0, 0.0), (0, 1, 0), 70.0)  # inside the scene
+        elif k == 2: sd.set_camera((float(rng.uniform(-9, 9)), float(rng.uniform(3, 9)), float(rng.uniform(8, 14))), (0.0, 1.0, 0.0), (0, 1, 0), float(rng.uniform(30, 60)))
+        sd.lights = []
+        for _ in range(int(rng.integers(1, 5))):
+            sd.add_light((float(rng.uniform(-30, 30)), float(rng.uniform(5, 60)), float(rng.uniform(-10, 60))), tuple(float(x) for x in rng.uniform(20, 900, 3)),
+                         rad=float(rng.uniform(15, 60)) if rng.uniform() < 0.3 else 1000000.0, shadow=bool(rng.uniform() < 0.8))
+        cam, lights = product_camera_lights(sd)
+        o, om, _ = oracle_for(sd); of, _, _ = oracle_for(sd, use_float=True)
+        img, _, st = sc.render(cam, lights, api.render_params(width=W, height=H, maxdepth=3))
+        f, _, sf = sc.render(cam, lights, api.render_params(width=W, height=H, maxdepth=3, faithful=1))
+        ref, _, rc = o.render(W, H, maxdepth=3, want_packed=False); r32, _, _ = of.render(W, H, maxdepth=3, want_packed=False)
+        both = (err(img, ref) > 1e-4) & (err(img, r32) > 1e-4)
+        worst = max(worst, int(both.sum()))
+        if both.mean() > 1e-3: bad.append((gen.__name__, seed, "frame", int(both.sum())))
+        if sc.info()["tier"] == 0 and not np.array_equal(img, f): bad.append((gen.__name__, seed, "early-out != faithful", int((img != f).any(-1).sum())))
+        sub, _, ss = sc.render(cam, lights, api.render_params(width=W, height=H, maxdepth=3, mode=1))
+        refs, _, rcs = o.render(W, H, maxdepth=3, mode=1, want_packed=False); r32s, _, _ = of.render(W, H, maxdepth=3, mode=1, want_packed=False)
+        boths = (err(sub, refs) > 1e-4) & (err(sub, r32s) > 1e-4)
+        if boths.mean() > 6e-3: bad.append((gen.__name__, seed, "adaptive frame", int(boths.sum()), int((err(r32s, refs) > 1e-4).sum())))
+        sc.release()
+print("scenes", nf + nc - refused, "refused", refused, "worst pixels off both (of %d)" % (W * H), worst, "bad", bad, "secs", round(time.time() - t0, 1), flush=True)
