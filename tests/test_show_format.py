@@ -105,6 +105,31 @@ def test_round_trip_is_the_same_scene(built, name):
     assert np.array_equal(h1.shadow(ro, rd, 20.0), h2.shadow(ro, rd, 20.0))
 
 
+def test_round_trip_of_random_scenes(built):
+    # random wrapper/CSG/instance nestings: either the text is refused for one of the two documented reasons (`show` prints
+    # neither vertex normals nor a mesh's default material) or the copy built from it answers every ray identically
+    refusals = ("does not print the normals", "needs a default material")
+    same = 0
+    for gen, seeds in ((zoo.random_composites, range(30)), (zoo.random_flat, range(30))):
+        for seed in seeds:
+            b, root, _ = _build(gen(seed))
+            text = b.show(root)
+            try:
+                root2, _ = b.load_show(text, b.show_tex_materials(root))
+            except api.GlomeError as e:
+                assert any(r in str(e) for r in refusals), (gen.__name__, seed, str(e))
+                continue
+            assert b.show(root2) == text, (gen.__name__, seed)
+            h1, h2 = HostSim(b, root), HostSim(b, root2)
+            ro, rd = random_rays(300, seed)
+            r1, r2 = h1.rayint(ro, rd), h2.rayint(ro, rd)
+            for k in ("t", "n", "tex"):
+                assert np.array_equal(r1[k], r2[k]), (gen.__name__, seed, k)
+            assert np.array_equal(h1.shadow(ro, rd, 20.0), h2.shadow(ro, rd, 20.0)), (gen.__name__, seed)
+            same += 1
+    assert same >= 20
+
+
 def test_bih_text_is_the_builders_tree(built):
     # the tree the text spells out == glome_sb_bih_dump's arrays (split planes, axes, leaf sizes), preorder
     rng = np.random.default_rng(8)
