@@ -29,7 +29,7 @@
 #include "flatten.hpp"
 #include "tiles.hpp"
 #include "rt_device.hpp"
-#include "rt_generic.hpp"
+#include "rt_generic_vm.hpp"
 #include "bih_build_device.hpp"
 
 using namespace glome;
@@ -79,21 +79,10 @@ struct GenericTier {
   int nlights;
   Cnt cnt;
   unsigned int err = 0;
-  GPool pool;  // the interpreter's frame / advance pools: one per lane for the whole kernel
+  uint32_t vm[kVmWords];  // the interpreter's frames: one word stack per lane for the whole kernel (scratch)
   // `root`: the record the trace runs over -- the scene's, or the frame / scene of a Warp material
-  __device__ __forceinline__ HitG closest(const Ray& r, float tmax, uint32_t root) {
-    GCtx<true> g{S, cnt, err, pool};
-    g.exact_bih = !unit_length(r.d);  // (Refract's transmitted ray: rt_generic.hpp GCtx)
-    HitG h = rayint_g<kGenericDepth>(g, ldu4(S.recs, root), r, tmax, (TexStack)0);
-    err = g.err;
-    return h;
-  }
-  __device__ __forceinline__ bool occluded(const Ray& r, float d, uint32_t root) {
-    GCtx<true> g{S, cnt, err, pool};
-    bool o = shadow_g<kGenericDepth>(g, ldu4(S.recs, root), r, d);
-    err = g.err;
-    return o;
-  }
+  __device__ __forceinline__ HitG closest(const Ray& r, float tmax, uint32_t root) { return vm_closest<true>(S, cnt, err, vm, r, tmax, root); }
+  __device__ __forceinline__ bool occluded(const Ray& r, float d, uint32_t root) { return vm_occluded<true>(S, cnt, err, vm, r, d, root); }
   __device__ __forceinline__ HitG closest(const Ray& r, float tmax) { return closest(r, tmax, S.root_rec); }
   __device__ __forceinline__ bool occluded(const Ray& r, float d) { return occluded(r, d, S.root_rec); }
   __device__ __forceinline__ HitG closest_wave(const Ray& r, float tmax, bool valid, uint32_t root) { return valid ? closest(r, tmax, root) : hit_miss(); }
@@ -499,8 +488,7 @@ __global__ void __launch_bounds__(64, 2) k_shadow_batch_generic(DScene S, size_t
 }
 __global__ void __launch_bounds__(64, 2) k_inside_batch(DScene S, size_t n, const float* px, const float* py, const float* pz, uint8_t* in, DCounters* c) {
   Cnt cnt; unsigned int err = 0;
-  GPool pool;
-  GCtx<true> g{S, cnt, err, pool};
+  GCtx<true> g{S, cnt, err};
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     in[i] = inside_g<kGenericDepth>(g, ldu4(S.recs, S.root_rec), v3(px[i], py[i], pz[i])) ? 1 : 0;
   if (g.err) atomicOr(&c->error, 1u);

@@ -1,0 +1,539 @@
+// rt_generic_vm.hpp -- the generic tier's rayint / shadow as ONE loop over explicit frames (no recursion, no nesting
+// budget): the reference's class-method calls (Solid.hs:138-254) become CALL / RETURN steps of a small state machine whose
+// frames live in one word stack per ray.  A wave's lanes are usually at different depths of different composites; a loop
+// whose body is "one step of whatever this lane is doing" lets all the lanes that are testing a primitive, or stepping
+// through a BIH, or returning to a list, do so together whatever their depth -- the recursive form (rt_generic.hpp, which
+// still answers `inside` and `get_metainfo`, both pure functions of a point) instantiates every method once per depth, and
+// lanes at different depths execute different copies of the same code one after the other.
+//
+// Conventions between caller and callee (what a frame must keep to go on after a call):
+//   r    the callee restores it: only Instance (local ray) and the CSG nodes (advanced origin) change it, and they put it back
+//   d    the caller keeps it (a BIH hands its items the node's `far`, not its own d)
+//   tex  the caller keeps it (Tex wrappers push on it on the way down)
+// Results: `rh` (rayint) or `rb` (shadow).
+#pragma once
+#include "rt_generic.hpp"
+
+namespace glome {
+
+constexpr int kVmWords = 768;  // frame words per ray (scratch); running out raises the context's error flag
+constexpr int kHitWords = 17;
+
+enum : uint32_t {
+  VT_DONE = 0, VT_LIST_R, VT_LIST_S, VT_INST_R, VT_INST_S, VT_BOUND_R, VT_BOUND_S, VT_IB_R, VT_IB_S,
+  VT_DIFF_B, VT_DIFF_A, VT_DIFF_AB, VT_ISECT_HS, VT_ISECT_S1, VT_ISECT_S2, VT_BIH_R, VT_BIH_S, VT_S_OF_R
+};
+enum : int { ST_CALL_R = 0, ST_CALL_S, ST_RET, ST_BIH, ST_BIH_ITEM, ST_DIFF, ST_ISECT, ST_ENTER_CSG };
+
+GD void vm_st_hit(uint32_t* m, int i, const HitG& h) {
+  m[i] = h.hit ? 1u : 0u; m[i + 1] = as_u(h.t);
+  m[i + 2] = as_u(h.p.x); m[i + 3] = as_u(h.p.y); m[i + 4] = as_u(h.p.z);
+  m[i + 5] = as_u(h.n.x); m[i + 6] = as_u(h.n.y); m[i + 7] = as_u(h.n.z);
+  m[i + 8] = (uint32_t)h.tex; m[i + 9] = (uint32_t)(h.tex >> 32); m[i + 10] = h.uid;
+  m[i + 11] = as_u(h.lo.x); m[i + 12] = as_u(h.lo.y); m[i + 13] = as_u(h.lo.z);
+  m[i + 14] = as_u(h.ld.x); m[i + 15] = as_u(h.ld.y); m[i + 16] = as_u(h.ld.z);
+}
+GD HitG vm_ld_hit(const uint32_t* m, int i) {
+  HitG h;
+  h.hit = m[i] != 0; h.t = as_f(m[i + 1]);
+  h.p = v3(as_f(m[i + 2]), as_f(m[i + 3]), as_f(m[i + 4]));
+  h.n = v3(as_f(m[i + 5]), as_f(m[i + 6]), as_f(m[i + 7]));
+  h.tex = (TexStack)m[i + 8] | ((TexStack)m[i + 9] << 32); h.uid = m[i + 10];
+  h.lo = v3(as_f(m[i + 11]), as_f(m[i + 12]), as_f(m[i + 13]));
+  h.ld = v3(as_f(m[i + 14]), as_f(m[i + 15]), as_f(m[i + 16]));
+  return h;
+}
+
+// rayint_mesh, Mesh.hs:136-198: a leaf of the interpreter (no calls below it)
+template <bool C> GD HitG vm_mesh_rayint(const DScene& S, Cnt& cnt, U4 rec, const Ray& r, float d, TexStack tex) {
+  PrivStack stk;
+  float mt; uint32_t ti;
+  mesh_closest<C>(S, rec.y, r, d, stk, kGenericStack, cnt, mt, ti);
+  HitG h = hit_miss();
+  if (ti == 0xffffffffu) return h;
+  h.hit = true; h.t = mt; h.p = vscaleadd(r.o, r.d, mt); h.uid = rec.w; h.lo = r.o; h.ld = r.d;
+  U4 meta = ldu4(S.mtrimeta, ti);
+  F4 q0 = ld4(S.mtris, 3 * ti), q1 = ld4(S.mtris, 3 * ti + 1), q2 = ld4(S.mtris, 3 * ti + 2);
+  if (meta.x == 0) h.n = v3(q0.w, q1.w, q2.w);
+  else {
+    float t, b1, b2;
+    tri_test(q0, q1, q2, r, kInf * 8.0f, t, b1, b2);
+    uint32_t nb = meta.x - 1;
+    V3 n1 = v3(ld4(S.trinorms, nb)), n2 = v3(ld4(S.trinorms, nb + 1)), n3 = v3(ld4(S.trinorms, nb + 2));
+    V3 a1 = n1 * (1 - (b1 + b2)), a2 = n2 * b1, a3 = n3 * b2;
+    h.n = vnorm(v3(a1.x + a2.x + a3.x, a1.y + a2.y + a3.y, a1.z + a2.z + a3.z));
+  }
+  h.tex = meta.y ? tex_cat((TexStack)meta.y, tex) : tex;
+  return h;
+}
+
+// Frame layouts (word offsets from the frame base fb; word 0 = tag | previous fb << 8):
+//   LIST_R   1 first record, 2 n, 3 k, 4 d, 5-6 tex, 7.. best hit            LIST_S  1 first, 2 n, 3 k, 4 d
+//   INST_R   1-6 outer ray, 7 1/lenscale, 8 exact, 9 transform               INST_S  1-6 outer ray
+//   BOUND_R  1 record b, 2 d, 3-4 tex                                         BOUND_S 1 record b, 2 d
+//   IB_R     1 record b, 2-3 tex                                              IB_S    1 record b, 2 d
+//   DIFF     1 record a, 2 record b, 3-4 tex, 5-7 entry origin, 8 d (current), 9 advances, 10.. hit of a, 27.. the advances
+//   ISECT    1 first record, 2 n, 3 from, 4-5 tex, 6-8 origin, 9 d, 10 aux    (one frame per IFrame of the recursive form)
+//   BIH      1-2 tex, 3 flags (1 root is a leaf, 2 exact walk, 4 shadow), 4 d, 5-7 1/direction, 8 leaf cursor, 9 items left,
+//            10 the leaf's tmax, 11 traversal entries, [12.. best hit (rayint only)], then the entries (node, near, far)
+constexpr int kBihFixedS = 12, kBihFixedR = 12 + kHitWords, kDiffFixed = 10 + kHitWords, kIsectWords = 11;
+
+template <bool C>
+GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, int st, U4 rec, Ray r, float d, bool exact, HitG& rh, bool& rb) {
+  GCtx<C> g{S, cnt, err};  // for inside / get_metainfo (rt_generic.hpp)
+  int sp = 1, fb = 0;
+  m[0] = VT_DONE;
+  TexStack tex = 0;
+  rh = hit_miss(); rb = false;
+  uint32_t ref = 0; float nearv = 0, farv = 0, bt = 0;  // the BIH walk's registers (live between ST_BIH steps only)
+#define VM_NEED(n) if (sp + (n) > kVmWords) { err = 1; rh = hit_miss(); rb = false; return; }
+#define VM_PUSH(tag, n) { VM_NEED(n); m[sp] = (uint32_t)(tag) | ((uint32_t)fb << 8); fb = sp; sp += (n); }
+#define VM_POP() { sp = fb; fb = (int)(m[fb] >> 8); }
+#define VM_TAG(tag) m[fb] = (m[fb] & ~0xffu) | (uint32_t)(tag)
+#define VM_TEX(i) ((TexStack)m[fb + (i)] | ((TexStack)m[fb + (i) + 1] << 32))
+#define VM_SET_TEX(i, t) { m[fb + (i)] = (uint32_t)(t); m[fb + (i) + 1] = (uint32_t)((t) >> 32); }
+  for (;;) {
+    // One pass runs the states in an order that lets the common chains finish inside it: leaf item -> call of a primitive ->
+    // return to the BIH frame; return to a list -> call of the next child -> its return.
+    if (st == ST_BIH_ITEM) do {  // the next item of the leaf the walk stands on
+      const uint32_t left = m[fb + 9];
+      if (left == 0) { ref = 0xffffffffu; st = ST_BIH; break; }
+      const uint32_t flags = m[fb + 3];
+      const U4 it = ldu4(S.recs, m[fb + 8]);
+      m[fb + 8]++; m[fb + 9] = left - 1;
+      const float tmax = as_f(m[fb + 10]);
+      rec = it;
+      if (flags & 4u) { d = gminf(as_f(m[fb + 4]), tmax); st = ST_CALL_S; break; }
+      tex = VM_TEX(1);
+      d = tmax;
+      if (!(flags & 2u) && m[fb + 12] != 0) {
+        // a plain primitive other than a quadric (under any Tex wrappers) answers the same for every tmax beyond its hit:
+        // it may be tested against the best so far (the lattice of GlomeView's default scene is 9261 such spheres)
+        const uint32_t ik = skip_tex(S, it).x & RF_KINDMASK;
+        if (ik >= R_SPHERE && ik <= R_CONE && ik != R_CYL && ik != R_CONE) d = gminf(tmax, as_f(m[fb + 13]));
+      }
+      st = ST_CALL_R;
+    } while (0);
+    if (st == ST_ENTER_CSG) do {
+      if ((rec.x & RF_KINDMASK) == R_DIFF) {  // rayint_difference, Csg.hs:33-54 (Q13)
+        VM_PUSH(VT_DIFF_B, kDiffFixed);
+        m[fb + 1] = rec.y; m[fb + 2] = rec.z; VM_SET_TEX(3, tex);
+        m[fb + 5] = as_u(r.o.x); m[fb + 6] = as_u(r.o.y); m[fb + 7] = as_u(r.o.z);
+        m[fb + 8] = as_u(d); m[fb + 9] = 0;
+        st = ST_DIFF;
+      } else {  // rayint_intersection, Csg.hs:68-90 (Q14)
+        VM_PUSH(VT_ISECT_HS, kIsectWords);
+        m[fb + 1] = rec.y; m[fb + 2] = rec.z; m[fb + 3] = 0; VM_SET_TEX(4, tex);
+        m[fb + 6] = as_u(r.o.x); m[fb + 7] = as_u(r.o.y); m[fb + 8] = as_u(r.o.z);
+        m[fb + 9] = as_u(d); m[fb + 10] = 0;
+        st = ST_ISECT;
+      }
+    } while (0);
+    if (st == ST_DIFF) do {  // one round of the advance loop (the self-recursion through rayint_advance, Solid.hs:85-91)
+      const U4 rbrec = ldu4(S.recs, m[fb + 2]);
+      tex = VM_TEX(3); d = as_f(m[fb + 8]);
+      if (inside_g<kGenericDepth>(g, rbrec, r.o)) { VM_TAG(VT_DIFF_B); rec = rbrec; }
+      else { VM_TAG(VT_DIFF_A); rec = ldu4(S.recs, m[fb + 1]); }
+      st = ST_CALL_R;
+    } while (0);
+    if (st == ST_ISECT) do {  // a fresh frame: `rayint (Intersection slds) r d` at list position `from`
+      const uint32_t from = m[fb + 3], n = m[fb + 2];
+      const float fd = as_f(m[fb + 9]);
+      r.o = v3(as_f(m[fb + 6]), as_f(m[fb + 7]), as_f(m[fb + 8]));
+      if (from >= n || fd < 0) { rh = hit_miss(); VM_POP(); st = ST_RET; break; }  // null slds || d < 0
+      rec = ldu4(S.recs, m[fb + 1] + from); tex = VM_TEX(4); d = fd;
+      VM_TAG(VT_ISECT_HS);
+      st = ST_CALL_R;
+    } while (0);
+    if (st == ST_CALL_R) do {
+      bool novis = false;
+      for (;;) {  // Tex s tex: rayint s r d (tex:texs) tags, Tex.hs:66; OnlyShadow misses (Tex.hs:89)
+        if (rec.x & RF_NOVIS) { novis = true; break; }
+        if ((rec.x & RF_KINDMASK) != R_TEX) break;
+        tex = tex_push(tex, rec.z);
+        rec = ldu4(S.recs, rec.y);
+      }
+      st = ST_RET;
+      if (novis) { rh = hit_miss(); break; }
+      const uint32_t kind = rec.x & RF_KINDMASK;
+      if (kind >= R_SPHERE && kind <= R_CONE) {
+        rh = hit_miss();
+        if (C) cnt.prim++;
+        float t; V3 n;
+        if (prim_test<true>(S, kind, rec.y, r, d, t, n)) {
+          rh.hit = true; rh.t = t; rh.n = n; rh.p = vscaleadd(r.o, r.d, t); rh.lo = r.o; rh.ld = r.d;
+          rh.tex = tex_cat(own_stack_rayint(rec.z), tex); rh.uid = rec.w;
+        }
+        break;
+      }
+      switch (kind) {
+        case R_LIST: {  // foldl' nearest RayMiss, every item with the same d (Solid.hs:327, Q9)
+          rh = hit_miss();
+          if (rec.z == 0) break;
+          VM_PUSH(VT_LIST_R, 7 + kHitWords);
+          m[fb + 1] = rec.y; m[fb + 2] = rec.z; m[fb + 3] = 0; m[fb + 4] = as_u(d); VM_SET_TEX(5, tex); m[fb + 7] = 0;
+          rec = ldu4(S.recs, rec.y); st = ST_CALL_R;
+          break;
+        }
+        case R_INSTANCE: {  // rayint_instance, Solid.hs:388-403 (Q8)
+          Xf6 x = load_xf(S, rec.z);
+          V3 newdir = mat_vec(x.i0, x.i1, x.i2, r.d), neworig = mat_point(x.i0, x.i1, x.i2, r.o);
+          float lenscale = sqrtf(vdot(newdir, newdir)), invlenscale = 1.0f / lenscale;
+          VM_PUSH(VT_INST_R, 10);
+          m[fb + 1] = as_u(r.o.x); m[fb + 2] = as_u(r.o.y); m[fb + 3] = as_u(r.o.z);
+          m[fb + 4] = as_u(r.d.x); m[fb + 5] = as_u(r.d.y); m[fb + 6] = as_u(r.d.z);
+          m[fb + 7] = as_u(invlenscale); m[fb + 8] = exact ? 1u : 0u; m[fb + 9] = rec.z;
+          r.o = neworig; r.d = newdir * invlenscale; d = d * lenscale;
+          exact = false;  // (the local ray is unit length)
+          rec = ldu4(S.recs, rec.y); st = ST_CALL_R;
+          break;
+        }
+        case R_DIFF: case R_ISECT: st = ST_ENTER_CSG; break;
+        case R_BOUND: {  // rayint_bound, Bound.hs:30-35
+          U4 sa = ldu4(S.recs, rec.y);
+          if (inside_g<kGenericDepth>(g, sa, r.o)) { rec = ldu4(S.recs, rec.z); st = ST_CALL_R; break; }
+          VM_PUSH(VT_BOUND_R, 5);
+          m[fb + 1] = rec.z; m[fb + 2] = as_u(d); VM_SET_TEX(3, tex);
+          rec = sa; st = ST_CALL_S;
+          break;
+        }
+        case R_INNERBOUND: {  // rayint_innerbound, Bound.hs:97-99
+          VM_PUSH(VT_IB_R, 4);
+          m[fb + 1] = rec.z; VM_SET_TEX(2, tex);
+          rec = ldu4(S.recs, rec.y); tex = 0; st = ST_CALL_R;
+          break;
+        }
+        case R_BIH: {  // rayint_bih, Bih.hs:332-368
+          F4 h0 = ld4(S.bihhdr, 3 * rec.y), h1 = ld4(S.bihhdr, 3 * rec.y + 1);
+          bbclip_ub(r, v3(h0), v3(h1), nearv, farv);
+          farv = gminf(d, farv);  // `traverse root near (fmin d far)`, Bih.hs:368
+          ref = as_u(h0.w);
+          VM_PUSH(VT_BIH_R, kBihFixedR);
+          VM_SET_TEX(1, tex);
+          m[fb + 3] = ((ref & BREF_LEAF) ? 1u : 0u) | (exact ? 2u : 0u); m[fb + 4] = as_u(d);
+          m[fb + 5] = as_u(1.0f / r.d.x); m[fb + 6] = as_u(1.0f / r.d.y); m[fb + 7] = as_u(1.0f / r.d.z);
+          m[fb + 9] = 0; m[fb + 11] = 0; m[fb + 12] = 0;
+          bt = kInf * 4.0f;
+          st = ST_BIH;
+          break;
+        }
+        case R_MESH: rh = vm_mesh_rayint<C>(S, cnt, rec, r, d, tex); break;
+        default: rh = hit_miss(); break;
+      }
+    } while (0);
+    if (st == ST_CALL_S) do {
+      bool noshadow = false;
+      for (;;) {  // shadow (Tex s _) = shadow s; NoShadow -> False (Tex.hs:69, 81)
+        if (rec.x & RF_NOSHADOW) { noshadow = true; break; }
+        if ((rec.x & RF_KINDMASK) != R_TEX) break;
+        rec = ldu4(S.recs, rec.y);
+      }
+      st = ST_RET;
+      rb = false;
+      if (noshadow) break;
+      const uint32_t kind = rec.x & RF_KINDMASK;
+      if (kind >= R_SPHERE && kind <= R_CONE) { if (C) cnt.prim++; rb = prim_shadow(S, kind, rec.y, r, d); break; }
+      switch (kind) {
+        case R_LIST: {  // foldl' (||) False (Solid.hs:330)
+          if (rec.z == 0) break;
+          VM_PUSH(VT_LIST_S, 5);
+          m[fb + 1] = rec.y; m[fb + 2] = rec.z; m[fb + 3] = 0; m[fb + 4] = as_u(d);
+          rec = ldu4(S.recs, rec.y); st = ST_CALL_S;
+          break;
+        }
+        case R_INSTANCE: {  // shadow_instance, Solid.hs:464-471
+          Xf6 x = load_xf(S, rec.z);
+          V3 newdir = mat_vec(x.i0, x.i1, x.i2, r.d), neworig = mat_point(x.i0, x.i1, x.i2, r.o);
+          float lenscale = sqrtf(vdot(newdir, newdir)), invlenscale = 1.0f / lenscale;
+          VM_PUSH(VT_INST_S, 7);
+          m[fb + 1] = as_u(r.o.x); m[fb + 2] = as_u(r.o.y); m[fb + 3] = as_u(r.o.z);
+          m[fb + 4] = as_u(r.d.x); m[fb + 5] = as_u(r.d.y); m[fb + 6] = as_u(r.d.z);
+          r.o = neworig; r.d = newdir * invlenscale; d = d * lenscale;
+          rec = ldu4(S.recs, rec.y); st = ST_CALL_S;
+          break;
+        }
+        // Difference / Intersection have no shadow method: the class default runs rayint (Solid.hs:218-221, Q15).
+        // The default sees the node itself, so an OnlyShadow flag on it does not hide it here.
+        case R_DIFF: case R_ISECT: {
+          VM_PUSH(VT_S_OF_R, 1);
+          tex = 0; st = ST_ENTER_CSG;
+          break;
+        }
+        case R_BOUND: {  // shadow_bound, Bound.hs:44-49
+          U4 sa = ldu4(S.recs, rec.y);
+          if (inside_g<kGenericDepth>(g, sa, r.o)) { rec = ldu4(S.recs, rec.z); st = ST_CALL_S; break; }
+          VM_PUSH(VT_BOUND_S, 3);
+          m[fb + 1] = rec.z; m[fb + 2] = as_u(d);
+          rec = sa; st = ST_CALL_S;
+          break;
+        }
+        case R_INNERBOUND: {  // Bound.hs:101-103
+          VM_PUSH(VT_IB_S, 3);
+          m[fb + 1] = rec.z; m[fb + 2] = as_u(d);
+          rec = ldu4(S.recs, rec.y); st = ST_CALL_S;
+          break;
+        }
+        case R_BIH: {  // shadow_bih, Bih.hs:510-544
+          F4 h0 = ld4(S.bihhdr, 3 * rec.y), h1 = ld4(S.bihhdr, 3 * rec.y + 1);
+          bbclip_ub(r, v3(h0), v3(h1), nearv, farv);
+          farv = gminf(d, farv);
+          ref = as_u(h0.w);
+          VM_PUSH(VT_BIH_S, kBihFixedS);
+          m[fb + 3] = ((ref & BREF_LEAF) ? 1u : 0u) | 4u; m[fb + 4] = as_u(d);
+          m[fb + 5] = as_u(1.0f / r.d.x); m[fb + 6] = as_u(1.0f / r.d.y); m[fb + 7] = as_u(1.0f / r.d.z);
+          m[fb + 9] = 0; m[fb + 11] = 0;
+          bt = 0;
+          st = ST_BIH;
+          break;
+        }
+        default: break;  // Mesh: `shadow s r d = False` (Mesh.hs:210); Void
+      }
+    } while (0);
+    if (st == ST_RET) do {
+      switch (m[fb] & 0xffu) {
+        case VT_DONE: return;
+        case VT_LIST_R: {
+          if (rh.hit && (m[fb + 7] == 0 || !(as_f(m[fb + 8]) < rh.t))) vm_st_hit(m, fb + 7, rh);  // nearest: ties -> the later item
+          const uint32_t k = m[fb + 3] + 1;
+          if (k < m[fb + 2]) {
+            m[fb + 3] = k; d = as_f(m[fb + 4]); tex = VM_TEX(5);
+            rec = ldu4(S.recs, m[fb + 1] + k); st = ST_CALL_R;
+          } else { rh = vm_ld_hit(m, fb + 7); if (!rh.hit) rh = hit_miss(); VM_POP(); }
+          break;
+        }
+        case VT_LIST_S: {
+          const uint32_t k = m[fb + 3] + 1;
+          if (!rb && k < m[fb + 2]) { m[fb + 3] = k; d = as_f(m[fb + 4]); rec = ldu4(S.recs, m[fb + 1] + k); st = ST_CALL_S; }
+          else VM_POP();
+          break;
+        }
+        case VT_INST_R: {
+          r.o = v3(as_f(m[fb + 1]), as_f(m[fb + 2]), as_f(m[fb + 3]));
+          r.d = v3(as_f(m[fb + 4]), as_f(m[fb + 5]), as_f(m[fb + 6]));
+          exact = m[fb + 8] != 0;
+          if (rh.hit) {
+            Xf6 x = load_xf(S, m[fb + 9]);
+            rh.t = rh.t * as_f(m[fb + 7]);
+            rh.p = mat_point(x.f0, x.f1, x.f2, rh.p);
+            rh.n = vnorm(mat_tvec(x.i0, x.i1, x.i2, rh.n));
+          }
+          VM_POP();
+          break;
+        }
+        case VT_INST_S: {
+          r.o = v3(as_f(m[fb + 1]), as_f(m[fb + 2]), as_f(m[fb + 3]));
+          r.d = v3(as_f(m[fb + 4]), as_f(m[fb + 5]), as_f(m[fb + 6]));
+          VM_POP();
+          break;
+        }
+        case VT_BOUND_R: {
+          if (rb) { rec = ldu4(S.recs, m[fb + 1]); d = as_f(m[fb + 2]); tex = VM_TEX(3); st = ST_CALL_R; }
+          else rh = hit_miss();
+          VM_POP();
+          break;
+        }
+        case VT_BOUND_S: {
+          if (rb) { rec = ldu4(S.recs, m[fb + 1]); d = as_f(m[fb + 2]); st = ST_CALL_S; }
+          VM_POP();
+          break;
+        }
+        case VT_IB_R: {
+          d = rh.hit ? rh.t : kInf;
+          rec = ldu4(S.recs, m[fb + 1]); tex = VM_TEX(2); st = ST_CALL_R;
+          VM_POP();
+          break;
+        }
+        case VT_IB_S: {
+          if (!rb) { rec = ldu4(S.recs, m[fb + 1]); d = as_f(m[fb + 2]); st = ST_CALL_S; }
+          VM_POP();
+          break;
+        }
+        case VT_S_OF_R: rb = rh.hit; VM_POP(); break;
+        case VT_DIFF_B: case VT_DIFF_AB: case VT_DIFF_A: {
+          const uint32_t tag = m[fb] & 0xffu;
+          HitG res = hit_miss();
+          bool finish = true;
+          float adv = 0;
+          if (tag == VT_DIFF_B) {
+            if (rh.hit) {
+              const U4 ra = ldu4(S.recs, m[fb + 1]), rbrec = ldu4(S.recs, m[fb + 2]);
+              if (inside_g<kGenericDepth>(g, ra, rh.p) && !inside_g<kGenericDepth>(g, rbrec, vscaleadd(rh.p, r.d, kDel))) {
+                res = rh;
+                res.n = vneg(rh.n);
+                res.tex = meta_g<kGenericDepth>(g, ra, rh.p);  // `difference` = Difference a b True: textures of A at the carved point
+              } else { finish = false; adv = rh.t; }
+            }
+          } else if (tag == VT_DIFF_A) {
+            if (rh.hit) {
+              vm_st_hit(m, fb + 10, rh);
+              VM_TAG(VT_DIFF_AB);
+              rec = ldu4(S.recs, m[fb + 2]); tex = VM_TEX(3); d = as_f(m[fb + 8]);
+              st = ST_CALL_R;
+              break;
+            }
+          } else {
+            const HitG ha = vm_ld_hit(m, fb + 10);
+            if (!rh.hit || ha.t < rh.t) res = ha;
+            else { finish = false; adv = rh.t; }
+          }
+          uint32_t na = m[fb + 9];
+          if (!finish) {
+            if (na >= (uint32_t)kCsgMaxAdvance) { err = 1; finish = true; }
+            else {
+              VM_NEED(1);
+              const float a = adv + kDel;
+              m[sp++] = as_u(a); m[fb + 9] = na + 1;
+              r.o = vscaleadd(r.o, r.d, a);  // ray_move
+              m[fb + 8] = as_u(as_f(m[fb + 8]) - a);
+              st = ST_DIFF;
+              break;
+            }
+          }
+          if (res.hit) for (int k = (int)na - 1; k >= 0; k--) res.t = res.t + as_f(m[fb + kDiffFixed + k]);  // RayHit (depth+a) ..., innermost first
+          r.o = v3(as_f(m[fb + 5]), as_f(m[fb + 6]), as_f(m[fb + 7]));
+          rh = res;
+          VM_POP();
+          break;
+        }
+        case VT_ISECT_HS: {
+          const uint32_t from = m[fb + 3], n = m[fb + 2];
+          const V3 o = v3(as_f(m[fb + 6]), as_f(m[fb + 7]), as_f(m[fb + 8]));
+          const float fd = as_f(m[fb + 9]);
+          if (from + 1 == n) { VM_POP(); break; }  // [] -> rayint s r d t tags
+          const U4 s = ldu4(S.recs, m[fb + 1] + from);
+          uint32_t nfrom; V3 no; float nd;
+          if (inside_g<kGenericDepth>(g, s, o)) {
+            if (!rh.hit) { m[fb + 3] = from + 1; st = ST_ISECT; break; }  // RayMiss -> rayint (Intersection ss) r d: a tail call
+            m[fb + 10] = as_u(rh.t); VM_TAG(VT_ISECT_S1);  // rest = rayint (Intersection ss) r sd
+            nfrom = from + 1; no = o; nd = rh.t;
+          } else {
+            if (!rh.hit) { rh = hit_miss(); VM_POP(); break; }
+            bool rest = true;  // inside (Intersection ss) sp: foldl' (&&) True
+            for (uint32_t k = from + 1; k < n; k++) rest = rest && inside_g<kGenericDepth>(g, ldu4(S.recs, m[fb + 1] + k), rh.p);
+            if (rest) { VM_POP(); break; }  // RayHit sd sp sn r vzero st stags
+            const float a = rh.t + kDel;  // rayint_advance (Intersection slds) r d t tags sd
+            m[fb + 10] = as_u(a); VM_TAG(VT_ISECT_S2);
+            nfrom = from; no = vscaleadd(o, r.d, a); nd = fd - a;
+          }
+          const int pf = fb;
+          VM_PUSH(VT_ISECT_HS, kIsectWords);
+          m[fb + 1] = m[pf + 1]; m[fb + 2] = n; m[fb + 3] = nfrom; m[fb + 4] = m[pf + 4]; m[fb + 5] = m[pf + 5];
+          m[fb + 6] = as_u(no.x); m[fb + 7] = as_u(no.y); m[fb + 8] = as_u(no.z); m[fb + 9] = as_u(nd); m[fb + 10] = 0;
+          st = ST_ISECT;
+          break;
+        }
+        case VT_ISECT_S1: {
+          const V3 o = v3(as_f(m[fb + 6]), as_f(m[fb + 7]), as_f(m[fb + 8]));
+          r.o = o;
+          if (rh.hit) { VM_POP(); break; }  // hit -> hit
+          const float a = as_f(m[fb + 10]) + kDel;
+          m[fb + 10] = as_u(a); VM_TAG(VT_ISECT_S2);
+          const float nd = as_f(m[fb + 9]) - a;
+          const V3 no = vscaleadd(o, r.d, a);
+          const int pf = fb;
+          VM_PUSH(VT_ISECT_HS, kIsectWords);
+          m[fb + 1] = m[pf + 1]; m[fb + 2] = m[pf + 2]; m[fb + 3] = m[pf + 3]; m[fb + 4] = m[pf + 4]; m[fb + 5] = m[pf + 5];
+          m[fb + 6] = as_u(no.x); m[fb + 7] = as_u(no.y); m[fb + 8] = as_u(no.z); m[fb + 9] = as_u(nd); m[fb + 10] = 0;
+          st = ST_ISECT;
+          break;
+        }
+        case VT_ISECT_S2: {
+          r.o = v3(as_f(m[fb + 6]), as_f(m[fb + 7]), as_f(m[fb + 8]));
+          if (rh.hit) rh.t = rh.t + as_f(m[fb + 10]);  // RayHit (depth+a) ...
+          VM_POP();
+          break;
+        }
+        case VT_BIH_R: {
+          if (rh.hit && (m[fb + 12] == 0 || !(as_f(m[fb + 13]) < rh.t))) vm_st_hit(m, fb + 12, rh);
+          bt = (!(m[fb + 3] & 2u) && m[fb + 12] != 0) ? as_f(m[fb + 13]) : kInf * 4.0f;
+          st = ST_BIH_ITEM;
+          break;
+        }
+        default: {  // VT_BIH_S
+          if (rb) { VM_POP(); break; }
+          st = ST_BIH_ITEM;
+          break;
+        }
+      }
+    } while (0);
+    if (st == ST_BIH) do {
+      const uint32_t flags = m[fb + 3];
+      const bool root_leaf = flags & 1u, exactm = flags & 2u, shadowm = flags & 4u, ordered = !exactm && !shadowm;
+      const int fixed = shadowm ? kBihFixedS : kBihFixedR;
+      if (ref == 0xffffffffu) {  // take the next entry, or finish
+        int ne = (int)m[fb + 11];
+        if (ne == 0) {
+          if (!shadowm) rh = vm_ld_hit(m, fb + 12); else rb = false;
+          VM_POP(); st = ST_RET;
+          break;
+        }
+        ne--;
+        const int e = fb + fixed + 3 * ne;
+        ref = m[e]; nearv = as_f(m[e + 1]); farv = as_f(m[e + 2]);
+        m[fb + 11] = (uint32_t)ne; sp = e;
+      }
+      bool popit = true;
+      const float geo_far = farv;  // the node's interval as the planes cut it (what its items are tested with)
+      if (ordered) farv = gminf(farv, bt);
+      if (ref & BREF_LEAF) {
+        uint32_t count = (ref >> 26) & 7u, first = ref & BREF_FIRST;
+        if (count == 7u) { F4 nn = ld4(S.bihnodes, first); count = as_u(nn.z); first = as_u(nn.w); }
+        if (count != 0 && (exactm || root_leaf || !(nearv > farv))) {
+          m[fb + 8] = first; m[fb + 9] = count; m[fb + 10] = as_u(ordered ? geo_far : farv);
+          st = ST_BIH_ITEM;
+          break;
+        }
+      } else {
+        if (C) cnt.bih++;
+        if (!(nearv > farv)) {
+          F4 nn = ld4(S.bihnodes, ref);
+          uint32_t w0 = as_u(nn.z), w1 = as_u(nn.w);
+          uint32_t axis = w0 & 3u;
+          float dirr = as_f(m[fb + 5 + axis]), o = vcomp(r.o, axis);
+          float dl = (nn.x - o) * dirr, dr = (nn.y - o) * dirr;
+          uint32_t left = w0 >> 2, right = w1;
+          uint32_t c1, c2; float c1far, c2near; bool go1, go2;
+          if (dirr > 0) { c1 = left; go1 = nearv < dl; c1far = gminf(dl, farv); c2 = right; go2 = dr < farv; c2near = gmaxf(dr, nearv); }
+          else { c1 = right; go1 = nearv < dr; c1far = gminf(dr, farv); c2 = left; go2 = dl < farv; c2near = gmaxf(dl, nearv); }
+          go1 = go1 && c1 != BREF_LEAF;
+          go2 = go2 && c2 != BREF_LEAF;
+          if (ordered) {  // the children keep the interval the planes give them; `best` only decided go1 / go2
+            c1far = gminf(dirr > 0 ? dl : dr, geo_far);
+            farv = geo_far;
+          }
+          if (go1) {
+            if (go2) {
+              VM_NEED(3);
+              m[sp] = c2; m[sp + 1] = as_u(c2near); m[sp + 2] = as_u(farv); sp += 3; m[fb + 11]++;
+            }
+            ref = c1; farv = c1far; popit = false;
+          } else if (go2) {
+            ref = c2; nearv = c2near; popit = false;
+          }
+        }
+      }
+      if (popit) ref = 0xffffffffu;
+    } while (0);
+  }
+#undef VM_NEED
+#undef VM_PUSH
+#undef VM_POP
+#undef VM_TAG
+#undef VM_TEX
+#undef VM_SET_TEX
+}
+
+template <bool C> GD HitG vm_closest(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, const Ray& r, float tmax, uint32_t root) {
+  HitG h; bool b;
+  // a ray that is not unit length (Refract's transmitted ray, Shader.hs:141): BIHs are walked exactly as the reference
+  // walks them (rt_generic.hpp GCtx, rt_device.hpp bih_traverse)
+  vm_run<C>(S, cnt, err, m, ST_CALL_R, ldu4(S.recs, root), r, tmax, !unit_length(r.d), h, b);
+  return h;
+}
+template <bool C> GD bool vm_occluded(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, const Ray& r, float d, uint32_t root) {
+  HitG h; bool b;
+  vm_run<C>(S, cnt, err, m, ST_CALL_S, ldu4(S.recs, root), r, d, false, h, b);
+  return b;
+}
+
+}  // namespace glome

@@ -8,7 +8,7 @@
 #include "../../glome_amd/csrc/capi_shared.hpp"
 #include "../../glome_amd/csrc/flatten.hpp"
 #include "../../glome_amd/csrc/rt_device.hpp"
-#include "../../glome_amd/csrc/rt_generic.hpp"
+#include "../../glome_amd/csrc/rt_generic_vm.hpp"
 
 using namespace glome;
 
@@ -41,8 +41,9 @@ struct HostGenericTier {
   int nlights;
   Cnt cnt;
   unsigned int err = 0;
-  HitG closest(const Ray& r, float tmax, uint32_t root) { GPool pool; GCtx<true> g{S, cnt, err, pool}; g.exact_bih = !unit_length(r.d); HitG h = rayint_g<kGenericDepth>(g, S.recs[root], r, tmax, (TexStack)0); err = g.err; return h; }
-  bool occluded(const Ray& r, float d, uint32_t root) { GPool pool; GCtx<true> g{S, cnt, err, pool}; bool o = shadow_g<kGenericDepth>(g, S.recs[root], r, d); err = g.err; return o; }
+  uint32_t vm[kVmWords];
+  HitG closest(const Ray& r, float tmax, uint32_t root) { return vm_closest<true>(S, cnt, err, vm, r, tmax, root); }
+  bool occluded(const Ray& r, float d, uint32_t root) { return vm_occluded<true>(S, cnt, err, vm, r, d, root); }
   HitG closest(const Ray& r, float tmax) { return closest(r, tmax, S.root_rec); }
   bool occluded(const Ray& r, float d) { return occluded(r, d, S.root_rec); }
   HitG closest_wave(const Ray& r, float tmax, bool valid, uint32_t root) { return valid ? closest(r, tmax, root) : hit_miss(); }
@@ -137,7 +138,7 @@ int hostsim_shadow(void* sv, int tier, size_t n, const float* ox, const float* o
 int hostsim_inside(void* sv, size_t n, const float* px, const float* py, const float* pz, unsigned char* in) {
   SimScene* s = (SimScene*)sv;
   Cnt cnt; unsigned int err = 0;
-  GPool pool; GCtx<true> g{s->D, cnt, err, pool};
+  GCtx<true> g{s->D, cnt, err};
   for (size_t i = 0; i < n; i++) in[i] = inside_g<kGenericDepth>(g, s->D.recs[s->D.root_rec], v3(px[i], py[i], pz[i]));
   return g.err ? -2 : 0;
 }
