@@ -23,7 +23,7 @@ enum : uint32_t {
   VT_DONE = 0, VT_LIST_R, VT_LIST_S, VT_INST_R, VT_INST_S, VT_BOUND_R, VT_BOUND_S, VT_IB_R, VT_IB_S,
   VT_DIFF_B, VT_DIFF_A, VT_DIFF_AB, VT_ISECT_HS, VT_ISECT_S1, VT_ISECT_S2, VT_BIH_R, VT_BIH_S, VT_S_OF_R
 };
-enum : int { ST_CALL_R = 0, ST_CALL_S, ST_RET, ST_BIH, ST_BIH_ITEM, ST_DIFF, ST_ISECT, ST_ENTER_CSG };
+enum : int { ST_CALL_R = 0, ST_CALL_S, ST_RET, ST_BIH, ST_BIH_ITEM, ST_DIFF, ST_ISECT, ST_ENTER_CSG, ST_LIST_R, ST_LIST_S };
 
 GD void vm_st_hit(uint32_t* m, int i, const HitG& h) {
   m[i] = h.hit ? 1u : 0u; m[i + 1] = as_u(h.t);
@@ -67,6 +67,44 @@ template <bool C> GD HitG vm_mesh_rayint(const DScene& S, Cnt& cnt, U4 rec, cons
   return h;
 }
 
+// A call whose callee is a primitive under Tex wrappers is answered in place (no frame, no pass through the loop): the
+// children of most lists and the items of most BIH leaves are such.  vm_resolve_r / _s strip the wrappers of a rayint /
+// shadow call: 0 = a primitive (rec is its record, tex has the wrappers' textures), 1 = answered by a flag (OnlyShadow
+// misses, NoShadow casts none: Tex.hs:81-89), 2 = a composite (rec and tex as they were: the call goes through the loop).
+GD int vm_resolve_r(const DScene& S, U4& rec, TexStack& tex) {
+  U4 c = rec; TexStack t = tex;
+  for (;;) {
+    if (c.x & RF_NOVIS) return 1;
+    if ((c.x & RF_KINDMASK) != R_TEX) break;
+    t = tex_push(t, c.z);
+    c = ldu4(S.recs, c.y);
+  }
+  const uint32_t kind = c.x & RF_KINDMASK;
+  if (kind >= R_SPHERE && kind <= R_CONE) { rec = c; tex = t; return 0; }
+  return 2;
+}
+GD int vm_resolve_s(const DScene& S, U4& rec) {
+  U4 c = rec;
+  for (;;) {
+    if (c.x & RF_NOSHADOW) return 1;
+    if ((c.x & RF_KINDMASK) != R_TEX) break;
+    c = ldu4(S.recs, c.y);
+  }
+  const uint32_t kind = c.x & RF_KINDMASK;
+  if (kind >= R_SPHERE && kind <= R_CONE) { rec = c; return 0; }
+  return 2;
+}
+template <bool C> GD HitG vm_prim_hit(const DScene& S, Cnt& cnt, const U4& rec, const Ray& r, float d, TexStack tex) {
+  HitG h = hit_miss();
+  if (C) cnt.prim++;
+  float t; V3 n;
+  if (prim_test<true>(S, rec.x & RF_KINDMASK, rec.y, r, d, t, n)) {
+    h.hit = true; h.t = t; h.n = n; h.p = vscaleadd(r.o, r.d, t); h.lo = r.o; h.ld = r.d;
+    h.tex = tex_cat(own_stack_rayint(rec.z), tex); h.uid = rec.w;
+  }
+  return h;
+}
+
 // Frame layouts (word offsets from the frame base fb; word 0 = tag | previous fb << 8):
 //   LIST_R   1 first record, 2 n, 3 k, 4 d, 5-6 tex, 7.. best hit            LIST_S  1 first, 2 n, 3 k, 4 d
 //   INST_R   1-6 outer ray, 7 1/lenscale, 8 exact, 9 transform               INST_S  1-6 outer ray
@@ -95,24 +133,43 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, int st
   for (;;) {
     // One pass runs the states in an order that lets the common chains finish inside it: leaf item -> call of a primitive ->
     // return to the BIH frame; return to a list -> call of the next child -> its return.
-    if (st == ST_BIH_ITEM) do {  // the next item of the leaf the walk stands on
-      const uint32_t left = m[fb + 9];
-      if (left == 0) { ref = 0xffffffffu; st = ST_BIH; break; }
+    if (st == ST_BIH_ITEM) do {  // the items of the leaf the walk stands on: primitives in place, a composite through a call
       const uint32_t flags = m[fb + 3];
-      const U4 it = ldu4(S.recs, m[fb + 8]);
-      m[fb + 8]++; m[fb + 9] = left - 1;
       const float tmax = as_f(m[fb + 10]);
-      rec = it;
-      if (flags & 4u) { d = gminf(as_f(m[fb + 4]), tmax); st = ST_CALL_S; break; }
-      tex = VM_TEX(1);
-      d = tmax;
-      if (!(flags & 2u) && m[fb + 12] != 0) {
-        // a plain primitive other than a quadric (under any Tex wrappers) answers the same for every tmax beyond its hit:
-        // it may be tested against the best so far (the lattice of GlomeView's default scene is 9261 such spheres)
-        const uint32_t ik = skip_tex(S, it).x & RF_KINDMASK;
-        if (ik >= R_SPHERE && ik <= R_CONE && ik != R_CYL && ik != R_CONE) d = gminf(tmax, as_f(m[fb + 13]));
+      uint32_t left = m[fb + 9], cur = m[fb + 8];
+      bool called = false;
+      if (flags & 4u) {  // shadow_bih: any item (Bih.hs:510-544)
+        const float dd = gminf(as_f(m[fb + 4]), tmax);
+        while (left != 0) {
+          U4 it = ldu4(S.recs, cur); cur++; left--;
+          const int what = vm_resolve_s(S, it);
+          if (what == 1) continue;
+          if (what == 2) { m[fb + 8] = cur; m[fb + 9] = left; rec = it; d = dd; st = ST_CALL_S; called = true; break; }
+          if (C) cnt.prim++;
+          if (prim_shadow(S, it.x & RF_KINDMASK, it.y, r, dd)) { rb = true; VM_POP(); st = ST_RET; called = true; break; }
+        }
+      } else {
+        const bool ordered = !(flags & 2u);
+        const TexStack ftex = VM_TEX(1);
+        bool besthit = m[fb + 12] != 0;
+        float bestt = besthit ? as_f(m[fb + 13]) : 0.0f;
+        while (left != 0) {
+          U4 it = ldu4(S.recs, cur); cur++; left--;
+          TexStack t = ftex;
+          const int what = vm_resolve_r(S, it, t);
+          if (what == 1) continue;
+          if (what == 2) { m[fb + 8] = cur; m[fb + 9] = left; rec = it; tex = ftex; d = tmax; st = ST_CALL_R; called = true; break; }
+          // a plain primitive other than a quadric answers the same for every tmax beyond its hit: it may be tested against
+          // the best so far (the lattice of GlomeView's default scene is 9261 such spheres); a cylinder or a cone sees the
+          // node's own `far` (rt_device.hpp bih_traverse, CLAMP)
+          const uint32_t ik = it.x & RF_KINDMASK;
+          const float dc = (ordered && besthit && ik != R_CYL && ik != R_CONE) ? gminf(tmax, bestt) : tmax;
+          const HitG h = vm_prim_hit<C>(S, cnt, it, r, dc, t);
+          if (h.hit && (!besthit || !(bestt < h.t))) { vm_st_hit(m, fb + 12, h); besthit = true; bestt = h.t; }  // nearest: ties -> the later item
+        }
+        if (!called) bt = (ordered && besthit) ? bestt : kInf * 4.0f;
       }
-      st = ST_CALL_R;
+      if (!called) { ref = 0xffffffffu; st = ST_BIH; }
     } while (0);
     if (st == ST_ENTER_CSG) do {
       if ((rec.x & RF_KINDMASK) == R_DIFF) {  // rayint_difference, Csg.hs:33-54 (Q13)
@@ -172,7 +229,7 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, int st
           if (rec.z == 0) break;
           VM_PUSH(VT_LIST_R, 7 + kHitWords);
           m[fb + 1] = rec.y; m[fb + 2] = rec.z; m[fb + 3] = 0; m[fb + 4] = as_u(d); VM_SET_TEX(5, tex); m[fb + 7] = 0;
-          rec = ldu4(S.recs, rec.y); st = ST_CALL_R;
+          st = ST_LIST_R;
           break;
         }
         case R_INSTANCE: {  // rayint_instance, Solid.hs:388-403 (Q8)
@@ -238,7 +295,7 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, int st
           if (rec.z == 0) break;
           VM_PUSH(VT_LIST_S, 5);
           m[fb + 1] = rec.y; m[fb + 2] = rec.z; m[fb + 3] = 0; m[fb + 4] = as_u(d);
-          rec = ldu4(S.recs, rec.y); st = ST_CALL_S;
+          st = ST_LIST_S;
           break;
         }
         case R_INSTANCE: {  // shadow_instance, Solid.hs:464-471
@@ -292,19 +349,13 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, int st
     if (st == ST_RET) do {
       switch (m[fb] & 0xffu) {
         case VT_DONE: return;
-        case VT_LIST_R: {
+        case VT_LIST_R: {  // a composite child has answered
           if (rh.hit && (m[fb + 7] == 0 || !(as_f(m[fb + 8]) < rh.t))) vm_st_hit(m, fb + 7, rh);  // nearest: ties -> the later item
-          const uint32_t k = m[fb + 3] + 1;
-          if (k < m[fb + 2]) {
-            m[fb + 3] = k; d = as_f(m[fb + 4]); tex = VM_TEX(5);
-            rec = ldu4(S.recs, m[fb + 1] + k); st = ST_CALL_R;
-          } else { rh = vm_ld_hit(m, fb + 7); if (!rh.hit) rh = hit_miss(); VM_POP(); }
+          st = ST_LIST_R;
           break;
         }
         case VT_LIST_S: {
-          const uint32_t k = m[fb + 3] + 1;
-          if (!rb && k < m[fb + 2]) { m[fb + 3] = k; d = as_f(m[fb + 4]); rec = ldu4(S.recs, m[fb + 1] + k); st = ST_CALL_S; }
-          else VM_POP();
+          if (rb) VM_POP() else st = ST_LIST_S;
           break;
         }
         case VT_INST_R: {
@@ -455,6 +506,44 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, int st
           break;
         }
       }
+    } while (0);
+    if (st == ST_LIST_R) do {  // the children from position k on: primitives in place, a composite through a call
+      const uint32_t n = m[fb + 2], first = m[fb + 1];
+      uint32_t k = m[fb + 3];
+      const float ld = as_f(m[fb + 4]);
+      const TexStack ltex = VM_TEX(5);
+      HitG best = m[fb + 7] != 0 ? vm_ld_hit(m, fb + 7) : hit_miss();
+      bool dirty = false, called = false;
+      for (; k < n; k++) {
+        U4 c = ldu4(S.recs, first + k);
+        TexStack t = ltex;
+        const int what = vm_resolve_r(S, c, t);
+        if (what == 1) continue;
+        if (what == 2) {
+          if (dirty) vm_st_hit(m, fb + 7, best);
+          m[fb + 3] = k + 1; rec = c; tex = ltex; d = ld; st = ST_CALL_R; called = true;
+          break;
+        }
+        const HitG h = vm_prim_hit<C>(S, cnt, c, r, ld, t);
+        if (h.hit && (!best.hit || !(best.t < h.t))) { best = h; dirty = true; }
+      }
+      if (!called) { rh = best; VM_POP(); st = ST_RET; }
+    } while (0);
+    if (st == ST_LIST_S) do {
+      const uint32_t n = m[fb + 2], first = m[fb + 1];
+      uint32_t k = m[fb + 3];
+      const float ld = as_f(m[fb + 4]);
+      bool called = false;
+      rb = false;
+      for (; k < n; k++) {
+        U4 c = ldu4(S.recs, first + k);
+        const int what = vm_resolve_s(S, c);
+        if (what == 1) continue;
+        if (what == 2) { m[fb + 3] = k + 1; rec = c; d = ld; st = ST_CALL_S; called = true; break; }
+        if (C) cnt.prim++;
+        if (prim_shadow(S, c.x & RF_KINDMASK, c.y, r, ld)) { rb = true; break; }
+      }
+      if (!called) { VM_POP(); st = ST_RET; }
     } while (0);
     if (st == ST_BIH) do {
       const uint32_t flags = m[fb + 3];
