@@ -48,7 +48,8 @@ class Flattener {
     if (tex_depth_of(root) > kMaxTexDepth)
       throw limit_error("a primitive lies under " + std::to_string(tex_depth_of(root)) + " nested textures; the device's texture stack holds " + std::to_string(kMaxTexDepth));
     const bool warps = bind_warps();  // Warp materials refer to records: the frame's, and the scene's they look into
-    if (F.nesting_depth > kGenericDepth) throw limit_error("scene nests composites deeper than the device interpreter supports (" + std::to_string(F.nesting_depth) + " > " + std::to_string(kGenericDepth) + ")");
+    if (point_depth_of(root) > kGenericDepth)
+      throw limit_error("the solid a Difference carves nests composites deeper than the device's get_metainfo supports (" + std::to_string(point_depth_of(root)) + " > " + std::to_string(kGenericDepth) + ")");
     // flat tier: root program of simple entries
     F.tier = 0;
     if (warps) { F.tier = 1; F.why_generic = "a Warp material traces other roots than the scene's"; }
@@ -111,7 +112,8 @@ class Flattener {
       const uint32_t frame = slot(emit(m.wframe)), scene = m.wscene < 0 ? F.root_rec : slot(emit(m.wscene));
       F.nesting_depth = std::max(F.nesting_depth, std::max(depth_of(m.wframe), m.wscene < 0 ? 0 : depth_of(m.wscene)));
       if (std::max(tex_depth_of(m.wframe), m.wscene < 0 ? 0 : tex_depth_of(m.wscene)) > kMaxTexDepth) throw limit_error("a Warp material's frame / scene has more nested textures than the device's texture stack holds");
-      if (F.nesting_depth > kGenericDepth) throw limit_error("a Warp material's frame / scene nests composites deeper than the device interpreter supports");
+      if (std::max(point_depth_of(m.wframe), m.wscene < 0 ? 0 : point_depth_of(m.wscene)) > kGenericDepth)
+        throw limit_error("a Warp material's frame / scene: the solid a Difference carves nests composites deeper than the device's get_metainfo supports");
       const uint32_t xf = (uint32_t)(F.xfms.size() / 6);
       for (int q = 0; q < 3; q++) F.xfms.push_back(mk4(m.wxf.f.m[4 * q], m.wxf.f.m[4 * q + 1], m.wxf.f.m[4 * q + 2], m.wxf.f.m[4 * q + 3]));
       for (int q = 0; q < 3; q++) F.xfms.push_back(mk4(m.wxf.i.m[4 * q], m.wxf.i.m[4 * q + 1], m.wxf.i.m[4 * q + 2], m.wxf.i.m[4 * q + 3]));
@@ -134,18 +136,43 @@ class Flattener {
   }
   int mat_nest_max() const { int d = 0; for (size_t m = 0; m < G.mats.size(); m++) d = std::max(d, mat_nest((int)m, 0)); return d; }
 
-  // composite nesting depth (Tex / Tag / NoShadow / OnlyShadow wrappers are free: the interpreter loops over them)
+  // composite nesting depth (Tex / Tag / NoShadow / OnlyShadow wrappers are free: the interpreter loops over them).  rayint,
+  // shadow and inside run over explicit frames (rt_generic_vm.hpp) and nest as deep as the frame memory allows; only
+  // `get_metainfo` (rt_generic.hpp) is unrolled to kGenericDepth levels, and only the first operand of a Difference is ever
+  // asked for it (the textures at a carved point, Csg.hs:103-106): point_depth_of is the deepest such operand below `id`.
+  mutable std::unordered_map<int, int> depth_memo, pdepth_memo;
   int depth_of(int id) const {
+    auto it = depth_memo.find(id);
+    if (it != depth_memo.end()) return it->second;
     const Node& n = G.at(id);
+    int d = 0;
     switch (n.kind) {
-      case K_LIST: case K_ISECT: { int d = 0; for (int k : n.kids) d = std::max(d, depth_of(k)); return d + 1; }
-      case K_INSTANCE: return depth_of(n.a) + 1;
-      case K_DIFF: case K_BOUND: case K_INNERBOUND: return std::max(depth_of(n.a), depth_of(n.b)) + 1;
-      case K_BIH: { int d = 0; for (auto& bn : n.bih->nodes) for (int k : bn.items) d = std::max(d, depth_of(k)); return d + 1; }
-      case K_MESH: return 1;
-      case K_TEX: case K_TAG: case K_NOSHADOW: case K_ONLYSHADOW: return depth_of(n.a);
-      default: return 0;
+      case K_LIST: case K_ISECT: { for (int k : n.kids) d = std::max(d, depth_of(k)); d++; break; }
+      case K_INSTANCE: d = depth_of(n.a) + 1; break;
+      case K_DIFF: case K_BOUND: case K_INNERBOUND: d = std::max(depth_of(n.a), depth_of(n.b)) + 1; break;
+      case K_BIH: { for (auto& bn : n.bih->nodes) for (int k : bn.items) d = std::max(d, depth_of(k)); d++; break; }
+      case K_MESH: d = 1; break;
+      case K_TEX: case K_TAG: case K_NOSHADOW: case K_ONLYSHADOW: d = depth_of(n.a); break;
+      default: break;
     }
+    depth_memo[id] = d;
+    return d;
+  }
+  int point_depth_of(int id) const {
+    auto it = pdepth_memo.find(id);
+    if (it != pdepth_memo.end()) return it->second;
+    const Node& n = G.at(id);
+    int d = 0;
+    switch (n.kind) {
+      case K_LIST: case K_ISECT: for (int k : n.kids) d = std::max(d, point_depth_of(k)); break;
+      case K_DIFF: d = std::max(depth_of(n.a), std::max(point_depth_of(n.a), point_depth_of(n.b))); break;
+      case K_BOUND: case K_INNERBOUND: d = std::max(point_depth_of(n.a), point_depth_of(n.b)); break;
+      case K_BIH: for (auto& bn : n.bih->nodes) for (int k : bn.items) d = std::max(d, point_depth_of(k)); break;
+      case K_INSTANCE: case K_TEX: case K_TAG: case K_NOSHADOW: case K_ONLYSHADOW: d = point_depth_of(n.a); break;
+      default: break;
+    }
+    pdepth_memo[id] = d;
+    return d;
   }
 
   // longest texture stack a hit can carry: the Tex wrappers on a path from `id` down to a primitive (a Mesh adds its

@@ -30,6 +30,9 @@
 #include "tiles.hpp"
 #include "rt_device.hpp"
 #include "rt_generic_vm.hpp"
+#ifndef GLOME_GENERIC_LB
+#define GLOME_GENERIC_LB 2  // waves per SIMD the generic-tier kernels are compiled for (256 VGPRs)
+#endif
 #include "bih_build_device.hpp"
 
 using namespace glome;
@@ -241,7 +244,7 @@ __global__ void __launch_bounds__(64, LB) k_render_flat(DRenderArgs A, int stack
   if (A.want_counters) flush_counters(A.counters, T.cnt, T.err);
   else if ((CLS & CLS_CSG) && __builtin_amdgcn_ballot_w64(T.err != 0) && (threadIdx.x & 63) == 0) atomicOr(&A.counters->error, 1u);
 }
-__global__ void __launch_bounds__(64, 2) k_render_generic(DRenderArgs A) {
+__global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_render_generic(DRenderArgs A) {
   GenericTier T{A.S, A.lights, A.nlights, Cnt()};
   render_loop(A, T);
   if (A.want_counters) flush_counters(A.counters, T.cnt, T.err);
@@ -424,7 +427,7 @@ __global__ void __launch_bounds__(64, LB) k_ss_frame_flat(DRenderArgs A, int sta
   if (A.want_counters) flush_counters(A.counters, T.cnt, T.err);
   else if ((CLS & CLS_CSG) && __builtin_amdgcn_ballot_w64(T.err != 0) && (threadIdx.x & 63) == 0) atomicOr(&A.counters->error, 1u);
 }
-__global__ void __launch_bounds__(64, 2) k_ss_frame_generic(DRenderArgs A) {
+__global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_ss_frame_generic(DRenderArgs A) {
   GenericTier T{A.S, A.lights, A.nlights, Cnt()};
   ss_frame_loop(A, T);
   if (A.want_counters) flush_counters(A.counters, T.cnt, T.err);
@@ -474,24 +477,24 @@ __global__ void __launch_bounds__(64) k_shadow_batch_flat(DScene S, size_t n, Ra
     occ[i] = T.occluded(load_ray(R, i), R.tmax[i]) ? 1 : 0;
   if (T.err) atomicOr(&c->error, 1u);
 }
-__global__ void __launch_bounds__(64, 2) k_rayint_batch_generic(DScene S, size_t n, RayStream R, HitStream H, DCounters* c) {
+__global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_rayint_batch_generic(DScene S, size_t n, RayStream R, HitStream H, DCounters* c) {
   GenericTier T{S, nullptr, 0, Cnt()};
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     store_hit(H, i, T.closest(load_ray(R, i), R.tmax[i]));
   if (T.err) atomicOr(&c->error, 1u);
 }
-__global__ void __launch_bounds__(64, 2) k_shadow_batch_generic(DScene S, size_t n, RayStream R, uint8_t* occ, DCounters* c) {
+__global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_shadow_batch_generic(DScene S, size_t n, RayStream R, uint8_t* occ, DCounters* c) {
   GenericTier T{S, nullptr, 0, Cnt()};
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     occ[i] = T.occluded(load_ray(R, i), R.tmax[i]) ? 1 : 0;
   if (T.err) atomicOr(&c->error, 1u);
 }
-__global__ void __launch_bounds__(64, 2) k_inside_batch(DScene S, size_t n, const float* px, const float* py, const float* pz, uint8_t* in, DCounters* c) {
-  Cnt cnt; unsigned int err = 0;
-  GCtx<true> g{S, cnt, err};
+__global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_inside_batch(DScene S, size_t n, const float* px, const float* py, const float* pz, uint8_t* in, DCounters* c) {
+  unsigned int err = 0;
+  uint32_t vm[kVmWords];
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    in[i] = inside_g<kGenericDepth>(g, ldu4(S.recs, S.root_rec), v3(px[i], py[i], pz[i])) ? 1 : 0;
-  if (g.err) atomicOr(&c->error, 1u);
+    in[i] = vm_inside(S, err, vm, 0, ldu4(S.recs, S.root_rec), v3(px[i], py[i], pz[i])) ? 1 : 0;
+  if (err) atomicOr(&c->error, 1u);
 }
 
 // ------------------------------------------------------------------------------------------------ tile transport

@@ -105,6 +105,129 @@ template <bool C> GD HitG vm_prim_hit(const DScene& S, Cnt& cnt, const U4& rec, 
   return h;
 }
 
+// `inside s p` (Solid.hs:138-254) over the same word stack, from word `base` up: a run-to-completion loop (the callers are
+// the CSG nodes and Bound, in the middle of a rayint step).  A composite is an OR (List, InnerBound, the leaves of a BIH), an
+// AND (Intersection, Bound, Difference = a && not b) or an Instance (the point moves into its frame).
+//   frames: word 0 = tag | previous frame << 8
+//     IN_OR / IN_AND   1 next record, 2 records left          IN_NOT   -          IN_INST  1-3 the outer point
+//     IN_THEN (a && b, a || b after a)  1 record b, 2 = 1 for ||                    IN_BIH   1 entries, then node references
+enum : uint32_t { IN_DONE = 0, IN_OR, IN_AND, IN_NOT, IN_INST, IN_THEN, IN_BIH };
+GD bool vm_inside(const DScene& S, unsigned int& err, uint32_t* m, int base, U4 rec, V3 p) {
+  if (base + 1 > kVmWords) { err = 1; return false; }
+  int sp = base + 1, fb = base;
+  m[base] = IN_DONE;
+  bool val = false, ret = false;
+#define IN_PUSH(tag, n) { if (sp + (n) > kVmWords) { err = 1; return false; } m[sp] = (uint32_t)(tag) | ((uint32_t)fb << 8); fb = sp; sp += (n); }
+#define IN_POP() { sp = fb; fb = (int)(m[fb] >> 8); }
+  for (;;) {
+    if (!ret) {  // evaluate `inside rec p`
+      rec = skip_tex(S, rec);
+      const uint32_t kind = rec.x & RF_KINDMASK;
+      ret = true;
+      if (kind >= R_SPHERE && kind <= R_CONE) { val = prim_inside(S, kind, rec.y, p); continue; }
+      switch (kind) {
+        case R_LIST:  // foldl' (||) False
+          val = false;
+          if (rec.z != 0) { IN_PUSH(IN_OR, 3); m[fb + 1] = rec.y; m[fb + 2] = rec.z; }
+          break;
+        case R_ISECT:  // foldl' (&&) True, Csg.hs:96-101
+          val = true;
+          if (rec.z != 0) { IN_PUSH(IN_AND, 3); m[fb + 1] = rec.y; m[fb + 2] = rec.z; }
+          break;
+        case R_INSTANCE: {  // Solid.hs:473-475
+          Xf6 x = load_xf(S, rec.z);
+          IN_PUSH(IN_INST, 4);
+          m[fb + 1] = as_u(p.x); m[fb + 2] = as_u(p.y); m[fb + 3] = as_u(p.z);
+          p = mat_point(x.i0, x.i1, x.i2, p);
+          rec = ldu4(S.recs, rec.y); ret = false;
+          break;
+        }
+        case R_DIFF: case R_BOUND: case R_INNERBOUND: {  // a && not b (Csg.hs:92-94), a && b (Bound.hs:51-52), a || b
+          IN_PUSH(IN_THEN, 3);
+          m[fb + 1] = rec.z; m[fb + 2] = kind;
+          rec = ldu4(S.recs, rec.y); ret = false;
+          break;
+        }
+        case R_BIH: {  // inside_bih, Bih.hs:550-565: strict box test, then both sides may be descended
+          F4 h0 = ld4(S.bihhdr, 3 * rec.y), h1 = ld4(S.bihhdr, 3 * rec.y + 1);
+          val = false;
+          if (!(p.x > h0.x && p.x < h1.x && p.y > h0.y && p.y < h1.y && p.z > h0.z && p.z < h1.z)) break;
+          IN_PUSH(IN_BIH, 3);
+          m[fb + 1] = as_u(h0.w); m[fb + 2] = 0;  // (word 1: the reference to look at next; 0xffffffff = take an entry)
+          break;
+        }
+        default: val = false; break;  // Mesh (Mesh.hs:211), Void
+      }
+      continue;
+    }
+    // a value has come back to the frame on top
+    const uint32_t tag = m[fb] & 0xffu;
+    if (tag == IN_DONE) return val;
+    if (tag == IN_OR || tag == IN_AND) {
+      const bool is_or = tag == IN_OR;
+      uint32_t left = m[fb + 2], cur = m[fb + 1];
+      bool called = false;
+      while (val != is_or && left != 0) {  // (an OR goes on while false, an AND while true)
+        const U4 c = skip_tex(S, ldu4(S.recs, cur)); cur++; left--;
+        const uint32_t ck = c.x & RF_KINDMASK;
+        if (ck >= R_SPHERE && ck <= R_CONE) { val = prim_inside(S, ck, c.y, p); continue; }
+        m[fb + 1] = cur; m[fb + 2] = left; rec = c; ret = false; called = true;
+        break;
+      }
+      if (!called) IN_POP();
+      continue;
+    }
+    if (tag == IN_NOT) { val = !val; IN_POP(); continue; }
+    if (tag == IN_INST) { p = v3(as_f(m[fb + 1]), as_f(m[fb + 2]), as_f(m[fb + 3])); IN_POP(); continue; }
+    if (tag == IN_THEN) {
+      const uint32_t kind = m[fb + 2], b = m[fb + 1];
+      const bool go_on = kind == R_INNERBOUND ? !val : val;
+      if (go_on) {
+        rec = ldu4(S.recs, b); ret = false;
+        if (kind == R_DIFF) m[fb] = (m[fb] & ~0xffu) | IN_NOT; else IN_POP();
+      } else IN_POP();
+      continue;
+    }
+    {  // IN_BIH: a leaf's items came back (OR frame above has been popped) or the walk goes on
+      if (val) { IN_POP(); continue; }
+      uint32_t ref = m[fb + 1];
+      bool called = false;
+      for (;;) {
+        if (ref == 0xffffffffu) {
+          const uint32_t ne = m[fb + 2];
+          if (ne == 0) break;
+          ref = m[fb + 3 + ne - 1]; m[fb + 2] = ne - 1; sp = fb + 3 + (int)ne - 1;
+        }
+        if (ref & BREF_LEAF) {
+          uint32_t count = (ref >> 26) & 7u, first = ref & BREF_FIRST;
+          if (count == 7u) { F4 n = ld4(S.bihnodes, first); count = as_u(n.z); first = as_u(n.w); }
+          ref = 0xffffffffu;
+          if (count != 0) {
+            m[fb + 1] = ref;
+            IN_PUSH(IN_OR, 3); m[fb + 1] = first; m[fb + 2] = count;
+            val = false; called = true;
+            break;
+          }
+        } else {
+          F4 n = ld4(S.bihnodes, ref);
+          uint32_t w0 = as_u(n.z), w1 = as_u(n.w), axis = w0 & 3u;
+          float o = vcomp(p, axis);
+          bool gl = o < n.x, gr = o > n.y;
+          if (gl) {
+            if (gr) { if (sp + 1 > kVmWords) { err = 1; return false; } m[sp++] = w1; m[fb + 2]++; }
+            ref = w0 >> 2;
+          } else if (gr) ref = w1;
+          else ref = 0xffffffffu;
+        }
+      }
+      if (!called) { val = false; IN_POP(); }
+      continue;
+    }
+  }
+#undef IN_PUSH
+#undef IN_POP
+}
+
 // Frame layouts (word offsets from the frame base fb; word 0 = tag | previous fb << 8):
 //   LIST_R   1 first record, 2 n, 3 k, 4 d, 5-6 tex, 7.. best hit            LIST_S  1 first, 2 n, 3 k, 4 d
 //   INST_R   1-6 outer ray, 7 1/lenscale, 8 exact, 9 transform               INST_S  1-6 outer ray
@@ -189,7 +312,7 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, int st
     if (st == ST_DIFF) do {  // one round of the advance loop (the self-recursion through rayint_advance, Solid.hs:85-91)
       const U4 rbrec = ldu4(S.recs, m[fb + 2]);
       tex = VM_TEX(3); d = as_f(m[fb + 8]);
-      if (inside_g<kGenericDepth>(g, rbrec, r.o)) { VM_TAG(VT_DIFF_B); rec = rbrec; }
+      if (vm_inside(S, err, m, sp, rbrec, r.o)) { VM_TAG(VT_DIFF_B); rec = rbrec; }
       else { VM_TAG(VT_DIFF_A); rec = ldu4(S.recs, m[fb + 1]); }
       st = ST_CALL_R;
     } while (0);
@@ -248,7 +371,7 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, int st
         case R_DIFF: case R_ISECT: st = ST_ENTER_CSG; break;
         case R_BOUND: {  // rayint_bound, Bound.hs:30-35
           U4 sa = ldu4(S.recs, rec.y);
-          if (inside_g<kGenericDepth>(g, sa, r.o)) { rec = ldu4(S.recs, rec.z); st = ST_CALL_R; break; }
+          if (vm_inside(S, err, m, sp, sa, r.o)) { rec = ldu4(S.recs, rec.z); st = ST_CALL_R; break; }
           VM_PUSH(VT_BOUND_R, 5);
           m[fb + 1] = rec.z; m[fb + 2] = as_u(d); VM_SET_TEX(3, tex);
           rec = sa; st = ST_CALL_S;
@@ -318,7 +441,7 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, int st
         }
         case R_BOUND: {  // shadow_bound, Bound.hs:44-49
           U4 sa = ldu4(S.recs, rec.y);
-          if (inside_g<kGenericDepth>(g, sa, r.o)) { rec = ldu4(S.recs, rec.z); st = ST_CALL_S; break; }
+          if (vm_inside(S, err, m, sp, sa, r.o)) { rec = ldu4(S.recs, rec.z); st = ST_CALL_S; break; }
           VM_PUSH(VT_BOUND_S, 3);
           m[fb + 1] = rec.z; m[fb + 2] = as_u(d);
           rec = sa; st = ST_CALL_S;
@@ -408,7 +531,7 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, int st
           if (tag == VT_DIFF_B) {
             if (rh.hit) {
               const U4 ra = ldu4(S.recs, m[fb + 1]), rbrec = ldu4(S.recs, m[fb + 2]);
-              if (inside_g<kGenericDepth>(g, ra, rh.p) && !inside_g<kGenericDepth>(g, rbrec, vscaleadd(rh.p, r.d, kDel))) {
+              if (vm_inside(S, err, m, sp, ra, rh.p) && !vm_inside(S, err, m, sp, rbrec, vscaleadd(rh.p, r.d, kDel))) {
                 res = rh;
                 res.n = vneg(rh.n);
                 res.tex = meta_g<kGenericDepth>(g, ra, rh.p);  // `difference` = Difference a b True: textures of A at the carved point
@@ -453,14 +576,14 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, int st
           if (from + 1 == n) { VM_POP(); break; }  // [] -> rayint s r d t tags
           const U4 s = ldu4(S.recs, m[fb + 1] + from);
           uint32_t nfrom; V3 no; float nd;
-          if (inside_g<kGenericDepth>(g, s, o)) {
+          if (vm_inside(S, err, m, sp, s, o)) {
             if (!rh.hit) { m[fb + 3] = from + 1; st = ST_ISECT; break; }  // RayMiss -> rayint (Intersection ss) r d: a tail call
             m[fb + 10] = as_u(rh.t); VM_TAG(VT_ISECT_S1);  // rest = rayint (Intersection ss) r sd
             nfrom = from + 1; no = o; nd = rh.t;
           } else {
             if (!rh.hit) { rh = hit_miss(); VM_POP(); break; }
             bool rest = true;  // inside (Intersection ss) sp: foldl' (&&) True
-            for (uint32_t k = from + 1; k < n; k++) rest = rest && inside_g<kGenericDepth>(g, ldu4(S.recs, m[fb + 1] + k), rh.p);
+            for (uint32_t k = from + 1; k < n; k++) rest = rest && vm_inside(S, err, m, sp, ldu4(S.recs, m[fb + 1] + k), rh.p);
             if (rest) { VM_POP(); break; }  // RayHit sd sp sn r vzero st stags
             const float a = rh.t + kDel;  // rayint_advance (Intersection slds) r d t tags sd
             m[fb + 10] = as_u(a); VM_TAG(VT_ISECT_S2);

@@ -137,10 +137,10 @@ int hostsim_shadow(void* sv, int tier, size_t n, const float* ox, const float* o
 }
 int hostsim_inside(void* sv, size_t n, const float* px, const float* py, const float* pz, unsigned char* in) {
   SimScene* s = (SimScene*)sv;
-  Cnt cnt; unsigned int err = 0;
-  GCtx<true> g{s->D, cnt, err};
-  for (size_t i = 0; i < n; i++) in[i] = inside_g<kGenericDepth>(g, s->D.recs[s->D.root_rec], v3(px[i], py[i], pz[i]));
-  return g.err ? -2 : 0;
+  unsigned int err = 0;
+  uint32_t vm[kVmWords];
+  for (size_t i = 0; i < n; i++) in[i] = vm_inside(s->D, err, vm, 0, s->D.recs[s->D.root_rec], v3(px[i], py[i], pz[i]));
+  return err ? -2 : 0;
 }
 // whole-frame, 1 ray per pixel (renderTile); cam = 12 floats, lights = nl x 8 floats (pos3 col3 rad shadow)
 int hostsim_render(void* sv, int tier, const float* cam, const float* lights, int nl, int width, int height, int maxdepth, float* out5, unsigned long long* counters) {

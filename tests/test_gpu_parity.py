@@ -365,7 +365,8 @@ def test_edge_cases(gpu_ctx):
         n = b.sphere((0, 0, 0), 1)
         for _ in range(8):
             n = b.group([b.transform(n, [api.translate((0.1, 0, 0))]), b.sphere((9, 9, 9), 0.1)])
-        gpu_ctx.commit(b, n)
+        gpu_ctx.commit(b, n).release()  # sixteen composite levels: fine (zoo.deep_nest is rendered by the parity tests)
+        gpu_ctx.commit(b, b.difference(n, b.sphere((0.5, 0, 0), 0.7)))  # get_metainfo of the carved solid is unrolled 6 deep
 
 
 def test_device_pointer_seams_match_host_seams(gpu_ctx):

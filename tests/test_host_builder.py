@@ -115,13 +115,15 @@ def test_flatten_tiers_and_limits(built):
         sd = zoo.ALL[name]()
         b = api.Builder(); nm, _ = sd.replay(b)
         assert HostSim(b, nm[sd.root]).info()["tier"] == 0, name
-    # nesting deeper than the interpreter is instantiated for is refused at commit, not mis-rendered
+    # composites nest as deep as the scene goes (zoo.deep_nest renders in the parity tests); the one unrolled method left is
+    # get_metainfo, asked of the solid a Difference carves: that solid nesting deeper than kGenericDepth is refused at commit
     b = api.Builder()
     n = b.sphere((0, 0, 0), 1)
     for _ in range(8):
         n = b.group([b.transform(n, [api.translate((0.1, 0, 0))]), b.sphere((9, 9, 9), 0.1)])
+    assert HostSim(b, n).info()["nesting"] == 16
     with pytest.raises(RuntimeError, match="nests composites deeper"):
-        HostSim(b, n)
+        HostSim(b, b.difference(n, b.sphere((0.5, 0, 0), 0.7)))
 
 
 def test_c_abi_exports_every_declared_symbol(built):

@@ -252,6 +252,28 @@ testscene = scenes.testscene  # GlomeView's default scene (TestScene.hs:183-197)
 ALL["testscene"] = lambda: testscene(4)  # (a 9x9x9 lattice keeps the CPU oracle's frames in seconds; the GPU tests also run the 21x21x21 one)
 
 
+def deep_nest(levels=14):
+    """Composites nested `levels` deep -- group [instance (bih [...]), sphere] over and over, each level moved, turned and
+    scaled a little, and a Difference whose operands are shallow at the very top: the reference recurses as deep as the scene
+    goes; the device's rayint / shadow loop keeps its frames in memory and does the same (rt_generic_vm.hpp)."""
+    sd = SceneDesc()
+    m = scenes.materials(sd)
+    teal, pink = scenes.matte(sd, (0.1, 0.7, 0.7)), scenes.matte(sd, (1, 0.4, 0.7))
+    n = sd.tex(sd.sphere((0, 0, 0), 0.5), m["shiny_red"])
+    for k in range(levels // 2):
+        side = sd.tex(sd.sphere((1.1, 0.0, 0.0), 0.35) if k % 2 else sd.box((0.7, -0.3, -0.3), (1.3, 0.3, 0.3)), teal if k % 2 else pink)
+        inner = sd.bih([n, side]) if k % 3 == 1 else sd.group([n, side])
+        n = sd.group([sd.transform(inner, [api.rotate((0, 0, 1), api.deg(17 + k)), api.scale((0.93, 0.9, 0.95)), api.translate((0.35, 0.25, 0.1))]),
+                      sd.tex(sd.sphere((-0.9, 0.2 * k, 0.3), 0.25), m["shiny_white"])])
+    carved = sd.group([sd.transform(n, [api.scale((1.6, 1.6, 1.6)), api.translate((0, 1.6, 0))]),
+                       sd.tex(sd.difference(sd.sphere((-3.5, 1, 0), 1.0), sd.box((-4.6, 1.0, -1.2), (-2.4, 2.2, 1.2))), teal)])
+    pl = sd.tex(sd.plane((0, 0, 0), (0, 1, 0)), scenes.matte(sd, (0, 0.8, 0.3)))
+    return _finish(sd, sd.group([pl, carved]))
+
+
+ALL["deep_nest"] = deep_nest
+
+
 def random_composites(seed, n_items=9, max_depth=3):
     """A random scene in TestScene.hs vocabulary: primitives of every family under random Tex stacks, grouped, instanced with
     random (rotate, non-uniform scale, translate) transforms, carved (Difference) and intersected, nested up to `max_depth`
