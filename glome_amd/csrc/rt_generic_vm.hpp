@@ -18,6 +18,10 @@ namespace glome {
 
 constexpr int kVmWords = 768;  // frame words per ray (scratch); running out raises the context's error flag
 constexpr int kHitWords = 17;
+#ifndef GLOME_VM_BIH_STEPS
+#define GLOME_VM_BIH_STEPS 8
+#endif
+constexpr int kBihStepsPerPass = GLOME_VM_BIH_STEPS;  // BIH steps a lane may take in one pass of the loop
 
 enum : uint32_t {
   VT_DONE = 0, VT_LIST_R, VT_LIST_S, VT_INST_R, VT_INST_S, VT_BOUND_R, VT_BOUND_S, VT_IB_R, VT_IB_S,
@@ -668,63 +672,68 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, int st
       }
       if (!called) { VM_POP(); st = ST_RET; }
     } while (0);
-    if (st == ST_BIH) do {
+    if (st == ST_BIH) do {  // up to kBihStepsPerPass steps of the walk (most of a ray's passes are spent here)
       const uint32_t flags = m[fb + 3];
       const bool root_leaf = flags & 1u, exactm = flags & 2u, shadowm = flags & 4u, ordered = !exactm && !shadowm;
       const int fixed = shadowm ? kBihFixedS : kBihFixedR;
-      if (ref == 0xffffffffu) {  // take the next entry, or finish
-        int ne = (int)m[fb + 11];
-        if (ne == 0) {
-          if (!shadowm) rh = vm_ld_hit(m, fb + 12); else rb = false;
-          VM_POP(); st = ST_RET;
-          break;
-        }
-        ne--;
-        const int e = fb + fixed + 3 * ne;
-        ref = m[e]; nearv = as_f(m[e + 1]); farv = as_f(m[e + 2]);
-        m[fb + 11] = (uint32_t)ne; sp = e;
-      }
-      bool popit = true;
-      const float geo_far = farv;  // the node's interval as the planes cut it (what its items are tested with)
-      if (ordered) farv = gminf(farv, bt);
-      if (ref & BREF_LEAF) {
-        uint32_t count = (ref >> 26) & 7u, first = ref & BREF_FIRST;
-        if (count == 7u) { F4 nn = ld4(S.bihnodes, first); count = as_u(nn.z); first = as_u(nn.w); }
-        if (count != 0 && (exactm || root_leaf || !(nearv > farv))) {
-          m[fb + 8] = first; m[fb + 9] = count; m[fb + 10] = as_u(ordered ? geo_far : farv);
-          st = ST_BIH_ITEM;
-          break;
-        }
-      } else {
-        if (C) cnt.bih++;
-        if (!(nearv > farv)) {
-          F4 nn = ld4(S.bihnodes, ref);
-          uint32_t w0 = as_u(nn.z), w1 = as_u(nn.w);
-          uint32_t axis = w0 & 3u;
-          float dirr = as_f(m[fb + 5 + axis]), o = vcomp(r.o, axis);
-          float dl = (nn.x - o) * dirr, dr = (nn.y - o) * dirr;
-          uint32_t left = w0 >> 2, right = w1;
-          uint32_t c1, c2; float c1far, c2near; bool go1, go2;
-          if (dirr > 0) { c1 = left; go1 = nearv < dl; c1far = gminf(dl, farv); c2 = right; go2 = dr < farv; c2near = gmaxf(dr, nearv); }
-          else { c1 = right; go1 = nearv < dr; c1far = gminf(dr, farv); c2 = left; go2 = dl < farv; c2near = gmaxf(dl, nearv); }
-          go1 = go1 && c1 != BREF_LEAF;
-          go2 = go2 && c2 != BREF_LEAF;
-          if (ordered) {  // the children keep the interval the planes give them; `best` only decided go1 / go2
-            c1far = gminf(dirr > 0 ? dl : dr, geo_far);
-            farv = geo_far;
+      const V3 rcp = v3(as_f(m[fb + 5]), as_f(m[fb + 6]), as_f(m[fb + 7]));
+      int ne = (int)m[fb + 11];
+      const int bfb = fb;
+      for (int rep = 0; rep < kBihStepsPerPass; rep++) {
+        if (ref == 0xffffffffu) {  // take the next entry, or finish
+          if (ne == 0) {
+            if (!shadowm) rh = vm_ld_hit(m, fb + 12); else rb = false;
+            VM_POP(); st = ST_RET;
+            break;
           }
-          if (go1) {
-            if (go2) {
-              VM_NEED(3);
-              m[sp] = c2; m[sp + 1] = as_u(c2near); m[sp + 2] = as_u(farv); sp += 3; m[fb + 11]++;
+          ne--;
+          const int e = fb + fixed + 3 * ne;
+          ref = m[e]; nearv = as_f(m[e + 1]); farv = as_f(m[e + 2]);
+          sp = e;
+        }
+        bool popit = true;
+        const float geo_far = farv;  // the node's interval as the planes cut it (what its items are tested with)
+        if (ordered) farv = gminf(farv, bt);
+        if (ref & BREF_LEAF) {
+          uint32_t count = (ref >> 26) & 7u, first = ref & BREF_FIRST;
+          if (count == 7u) { F4 nn = ld4(S.bihnodes, first); count = as_u(nn.z); first = as_u(nn.w); }
+          if (count != 0 && (exactm || root_leaf || !(nearv > farv))) {
+            m[fb + 8] = first; m[fb + 9] = count; m[fb + 10] = as_u(ordered ? geo_far : farv);
+            st = ST_BIH_ITEM;
+            break;
+          }
+        } else {
+          if (C) cnt.bih++;
+          if (!(nearv > farv)) {
+            F4 nn = ld4(S.bihnodes, ref);
+            uint32_t w0 = as_u(nn.z), w1 = as_u(nn.w);
+            uint32_t axis = w0 & 3u;
+            float dirr = vcomp(rcp, axis), o = vcomp(r.o, axis);
+            float dl = (nn.x - o) * dirr, dr = (nn.y - o) * dirr;
+            uint32_t left = w0 >> 2, right = w1;
+            uint32_t c1, c2; float c1far, c2near; bool go1, go2;
+            if (dirr > 0) { c1 = left; go1 = nearv < dl; c1far = gminf(dl, farv); c2 = right; go2 = dr < farv; c2near = gmaxf(dr, nearv); }
+            else { c1 = right; go1 = nearv < dr; c1far = gminf(dr, farv); c2 = left; go2 = dl < farv; c2near = gmaxf(dl, nearv); }
+            go1 = go1 && c1 != BREF_LEAF;
+            go2 = go2 && c2 != BREF_LEAF;
+            if (ordered) {  // the children keep the interval the planes give them; `best` only decided go1 / go2
+              c1far = gminf(dirr > 0 ? dl : dr, geo_far);
+              farv = geo_far;
             }
-            ref = c1; farv = c1far; popit = false;
-          } else if (go2) {
-            ref = c2; nearv = c2near; popit = false;
+            if (go1) {
+              if (go2) {
+                VM_NEED(3);
+                m[sp] = c2; m[sp + 1] = as_u(c2near); m[sp + 2] = as_u(farv); sp += 3; ne++;
+              }
+              ref = c1; farv = c1far; popit = false;
+            } else if (go2) {
+              ref = c2; nearv = c2near; popit = false;
+            }
           }
         }
+        if (popit) ref = 0xffffffffu;
       }
-      if (popit) ref = 0xffffffffu;
+      if (st != ST_RET) m[bfb + 11] = (uint32_t)ne;
     } while (0);
   }
 #undef VM_NEED
