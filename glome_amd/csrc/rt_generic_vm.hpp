@@ -117,6 +117,8 @@ template <bool C> GD HitG vm_prim_hit(const DScene& S, Cnt& cnt, const U4& rec, 
 //     IN_THEN (a && b, a || b after a)  1 record b, 2 = 1 for ||                    IN_BIH   1 entries, then node references
 enum : uint32_t { IN_DONE = 0, IN_OR, IN_AND, IN_NOT, IN_INST, IN_THEN, IN_BIH };
 GD bool vm_inside(const DScene& S, unsigned int& err, uint32_t* m, int base, U4 rec, V3 p) {
+  rec = skip_tex(S, rec);
+  if ((rec.x & RF_KINDMASK) >= R_SPHERE && (rec.x & RF_KINDMASK) <= R_CONE) return prim_inside(S, rec.x & RF_KINDMASK, rec.y, p);  // (most operands)
   if (base + 1 > kVmWords) { err = 1; return false; }
   int sp = base + 1, fb = base;
   m[base] = IN_DONE;
@@ -256,6 +258,9 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, int st
 #define VM_POP() { sp = fb; fb = (int)(m[fb] >> 8); }
 #define VM_TAG(tag) m[fb] = (m[fb] & ~0xffu) | (uint32_t)(tag)
 #define VM_TEX(i) ((TexStack)m[fb + (i)] | ((TexStack)m[fb + (i) + 1] << 32))
+// a rayint call issued before ST_RET in the pass: a primitive callee answers at once and the caller's frame goes on in this pass
+#define VM_CALL_R_INLINE() { const int what_ = vm_resolve_r(S, rec, tex); \
+    if (what_ == 2) st = ST_CALL_R; else { rh = what_ == 0 ? vm_prim_hit<C>(S, cnt, rec, r, d, tex) : hit_miss(); st = ST_RET; } }
 #define VM_SET_TEX(i, t) { m[fb + (i)] = (uint32_t)(t); m[fb + (i) + 1] = (uint32_t)((t) >> 32); }
   for (;;) {
     // One pass runs the states in an order that lets the common chains finish inside it: leaf item -> call of a primitive ->
@@ -318,7 +323,7 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, int st
       tex = VM_TEX(3); d = as_f(m[fb + 8]);
       if (vm_inside(S, err, m, sp, rbrec, r.o)) { VM_TAG(VT_DIFF_B); rec = rbrec; }
       else { VM_TAG(VT_DIFF_A); rec = ldu4(S.recs, m[fb + 1]); }
-      st = ST_CALL_R;
+      VM_CALL_R_INLINE();
     } while (0);
     if (st == ST_ISECT) do {  // a fresh frame: `rayint (Intersection slds) r d` at list position `from`
       const uint32_t from = m[fb + 3], n = m[fb + 2];
@@ -327,7 +332,7 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, int st
       if (from >= n || fd < 0) { rh = hit_miss(); VM_POP(); st = ST_RET; break; }  // null slds || d < 0
       rec = ldu4(S.recs, m[fb + 1] + from); tex = VM_TEX(4); d = fd;
       VM_TAG(VT_ISECT_HS);
-      st = ST_CALL_R;
+      VM_CALL_R_INLINE();
     } while (0);
     if (st == ST_CALL_R) do {
       bool novis = false;
@@ -541,18 +546,22 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, int st
                 res.tex = meta_g<kGenericDepth>(g, ra, rh.p);  // `difference` = Difference a b True: textures of A at the carved point
               } else { finish = false; adv = rh.t; }
             }
-          } else if (tag == VT_DIFF_A) {
-            if (rh.hit) {
-              vm_st_hit(m, fb + 10, rh);
-              VM_TAG(VT_DIFF_AB);
-              rec = ldu4(S.recs, m[fb + 2]); tex = VM_TEX(3); d = as_f(m[fb + 8]);
-              st = ST_CALL_R;
-              break;
-            }
           } else {
-            const HitG ha = vm_ld_hit(m, fb + 10);
-            if (!rh.hit || ha.t < rh.t) res = ha;
-            else { finish = false; adv = rh.t; }
+            HitG ha;
+            bool have_b = tag == VT_DIFF_AB;
+            if (have_b) ha = vm_ld_hit(m, fb + 10);
+            else if (rh.hit) {  // the hit of a is in; now b, with the same ray
+              ha = rh;
+              rec = ldu4(S.recs, m[fb + 2]); tex = VM_TEX(3); d = as_f(m[fb + 8]);
+              const int what = vm_resolve_r(S, rec, tex);
+              if (what == 2) { vm_st_hit(m, fb + 10, ha); VM_TAG(VT_DIFF_AB); st = ST_CALL_R; break; }
+              rh = what == 0 ? vm_prim_hit<C>(S, cnt, rec, r, d, tex) : hit_miss();  // (a primitive b answers in place)
+              have_b = true;
+            }
+            if (have_b) {
+              if (!rh.hit || ha.t < rh.t) res = ha;
+              else { finish = false; adv = rh.t; }
+            }
           }
           uint32_t na = m[fb + 9];
           if (!finish) {
@@ -742,6 +751,7 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, int st
 #undef VM_TAG
 #undef VM_TEX
 #undef VM_SET_TEX
+#undef VM_CALL_R_INLINE
 }
 
 template <bool C> GD HitG vm_closest(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, const Ray& r, float tmax, uint32_t root) {
