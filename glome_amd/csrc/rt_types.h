@@ -50,9 +50,9 @@ constexpr int kMaxTexDepth = 4;
 constexpr int kMaxLights = 8;
 constexpr int kFlatStack = 32;     // LDS traversal-stack entries per lane in the flat-tier kernels
 constexpr int kGenericStack = 32;  // scratch traversal-stack entries per BIH/Mesh level in the generic tier
-constexpr int kGenericDepth = 6;   // composite nesting levels the generic interpreter is instantiated for
+constexpr int kGenericDepth = 6;   // composite nesting levels get_metainfo is unrolled for (rt_generic.hpp; rayint / shadow / inside are loops)
 constexpr int kCsgMaxAdvance = 32; // ray-advance steps per CSG node before giving up (reference: unbounded)
-constexpr int kIsectFrames = 40;   // explicit frames for rayint_intersection's list recursion
+constexpr int kIsectFrames = 40;   // explicit frames for rayint_intersection's list recursion (flat tier's CSG items)
 constexpr int kMaxTraceDepth = 4;  // maxdepth values the render kernels are instantiated for
 constexpr int kMaxMatNest = 2;
 constexpr int kMaxBatchFrames = 8;  // frames one render launch can carry     // Blend / AdditiveLayers nesting the shader is instantiated for

@@ -40,7 +40,7 @@ enum glome_status {
   GLOME_E_SCENE = -2,     /* scene validation failed (infinite bound in bih, corrupt matrix, ...) */
   GLOME_E_NO_DEVICE = -3, /* no usable gfx950 device */
   GLOME_E_HIP = -4,       /* HIP runtime error */
-  GLOME_E_LIMIT = -5      /* scene exceeds a device-side limit (nesting depth, texture stack, ...) */
+  GLOME_E_LIMIT = -5      /* scene exceeds a device-side limit (texture stack, frame memory, ...) */
 };
 
 /* ---- context ---- */
