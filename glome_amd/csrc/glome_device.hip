@@ -1034,6 +1034,10 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
     for (int pass = 1; pass <= 5; pass++) {
       int rw, rh;
       ss_region_shape(pass, nframes >= 8 ? 2 : (nframes >= 3 ? 1 : 0), rw, rh);
+      // The generic tier's rays cost fifty times a flat-tier ray and its kernel runs eight waves per CU: parallelism is worth
+      // more than shared compaction.  One block per region for a frame alone (GlomeView's default scene: 68.5 -> 37.0 ms), two
+      // blocks in passes 3-5 of a batch (12.1 -> 9.1 ms per frame; tools/probe/ts_variants.sh with GLOME_DEBUG_SS_REGIONS)
+      if (s->dev.tier != 0) { rw = (nframes >= 3 && pass >= 3) ? 2 : 1; rh = 1; }
       A.ss_rw[pass] = (int8_t)rw; A.ss_rh[pass] = (int8_t)rh;
     }
     if (const char* e = getenv("GLOME_DEBUG_SS_REGIONS")) {  // "1x5,3x5,5x5,5x5,5x5"
