@@ -116,9 +116,8 @@ template <bool C> GD HitG vm_prim_hit(const DScene& S, Cnt& cnt, const U4& rec, 
 //     IN_OR / IN_AND   1 next record, 2 records left          IN_NOT   -          IN_INST  1-3 the outer point
 //     IN_THEN (a && b, a || b after a)  1 record b, 2 = 1 for ||                    IN_BIH   1 entries, then node references
 enum : uint32_t { IN_DONE = 0, IN_OR, IN_AND, IN_NOT, IN_INST, IN_THEN, IN_BIH };
-GD bool vm_inside(const DScene& S, unsigned int& err, uint32_t* m, int base, U4 rec, V3 p) {
-  rec = skip_tex(S, rec);
-  if ((rec.x & RF_KINDMASK) >= R_SPHERE && (rec.x & RF_KINDMASK) <= R_CONE) return prim_inside(S, rec.x & RF_KINDMASK, rec.y, p);  // (most operands)
+// (out of line: six call sites in vm_run, nine calls in ten are answered by the primitive test in front of it, vm_inside)
+GDN bool vm_inside_composite(const DScene& S, unsigned int& err, uint32_t* m, int base, U4 rec, V3 p) {
   if (base + 1 > kVmWords) { err = 1; return false; }
   int sp = base + 1, fb = base;
   m[base] = IN_DONE;
@@ -232,6 +231,11 @@ GD bool vm_inside(const DScene& S, unsigned int& err, uint32_t* m, int base, U4 
   }
 #undef IN_PUSH
 #undef IN_POP
+}
+GD bool vm_inside(const DScene& S, unsigned int& err, uint32_t* m, int base, U4 rec, V3 p) {
+  rec = skip_tex(S, rec);
+  if ((rec.x & RF_KINDMASK) >= R_SPHERE && (rec.x & RF_KINDMASK) <= R_CONE) return prim_inside(S, rec.x & RF_KINDMASK, rec.y, p);  // (most operands)
+  return vm_inside_composite(S, err, m, base, rec, p);
 }
 
 // Frame layouts (word offsets from the frame base fb; word 0 = tag | previous fb << 8):
