@@ -48,6 +48,8 @@ class Flattener {
     if (tex_depth_of(root) > kMaxTexDepth)
       throw limit_error("a primitive lies under " + std::to_string(tex_depth_of(root)) + " nested textures; the device's texture stack holds " + std::to_string(kMaxTexDepth));
     const bool warps = bind_warps();  // Warp materials refer to records: the frame's, and the scene's they look into
+    if (vm_words_of(root) + 2 > kVmWords)
+      throw limit_error("scene nests deeper than the device interpreter's frame memory holds (" + std::to_string(vm_words_of(root) + 2) + " of " + std::to_string(kVmWords) + " words)");
     if (point_depth_of(root) > kGenericDepth)
       throw limit_error("the solid a Difference carves nests composites deeper than the device's get_metainfo supports (" + std::to_string(point_depth_of(root)) + " > " + std::to_string(kGenericDepth) + ")");
     // flat tier: root program of simple entries
@@ -58,8 +60,8 @@ class Flattener {
     if (F.tier == 0 && F.max_mesh_depth > kFlatStack) { F.tier = 1; F.why_generic = "Mesh BVH deeper than the LDS stack"; }
     if (F.tier != 0) F.entries.clear();
     // the generic tier walks BIHs / Mesh BVHs with a fixed scratch stack per level: a deeper tree is refused, not truncated
-    if (F.tier != 0 && std::max(F.max_bih_depth, F.max_mesh_depth) > kGenericStack)
-      throw limit_error("BIH / Mesh tree deeper than the device traversal stack (" + std::to_string(std::max(F.max_bih_depth, F.max_mesh_depth)) + " > " + std::to_string(kGenericStack) + ")");
+    if (F.tier != 0 && F.max_mesh_depth > kGenericStack)
+      throw limit_error("Mesh tree deeper than the device traversal stack (" + std::to_string(F.max_mesh_depth) + " > " + std::to_string(kGenericStack) + ")");
     pad();
   }
 
@@ -112,6 +114,8 @@ class Flattener {
       const uint32_t frame = slot(emit(m.wframe)), scene = m.wscene < 0 ? F.root_rec : slot(emit(m.wscene));
       F.nesting_depth = std::max(F.nesting_depth, std::max(depth_of(m.wframe), m.wscene < 0 ? 0 : depth_of(m.wscene)));
       if (std::max(tex_depth_of(m.wframe), m.wscene < 0 ? 0 : tex_depth_of(m.wscene)) > kMaxTexDepth) throw limit_error("a Warp material's frame / scene has more nested textures than the device's texture stack holds");
+      if (std::max(vm_words_of(m.wframe), m.wscene < 0 ? 0 : vm_words_of(m.wscene)) + 2 > kVmWords)
+        throw limit_error("a Warp material's frame / scene nests deeper than the device interpreter's frame memory holds");
       if (std::max(point_depth_of(m.wframe), m.wscene < 0 ? 0 : point_depth_of(m.wscene)) > kGenericDepth)
         throw limit_error("a Warp material's frame / scene: the solid a Difference carves nests composites deeper than the device's get_metainfo supports");
       const uint32_t xf = (uint32_t)(F.xfms.size() / 6);
@@ -172,6 +176,52 @@ class Flattener {
       default: break;
     }
     pdepth_memo[id] = d;
+    return d;
+  }
+
+  // Frame words a rayint / shadow / inside call on `id` can have live at once in the generic tier's loop (rt_generic_vm.hpp's
+  // frame layouts): what the interpreter's nesting limit is now -- memory, checked here so that a scene is refused at commit
+  // rather than stopped in the middle of a frame.  An Intersection's chain of advance frames depends on the geometry; the
+  // estimate allows kVmIsectChain of them and the run-time check (GLOME_E_LIMIT) remains behind it.
+  mutable std::unordered_map<int, int> words_memo, iwords_memo;
+  int bih_items_max(const Node& n, bool inside) const {
+    int d = 0;
+    for (auto& bn : n.bih->nodes) for (int k : bn.items) d = std::max(d, inside ? inside_words_of(k) : vm_words_of(k));
+    return d;
+  }
+  int inside_words_of(int id) const {
+    auto it = iwords_memo.find(id);
+    if (it != iwords_memo.end()) return it->second;
+    const Node& n = G.at(id);
+    int d = 0;
+    switch (n.kind) {
+      case K_LIST: case K_ISECT: { for (int k : n.kids) d = std::max(d, inside_words_of(k)); d += 3; break; }
+      case K_INSTANCE: d = 4 + inside_words_of(n.a); break;
+      case K_DIFF: case K_BOUND: case K_INNERBOUND: d = 3 + std::max(inside_words_of(n.a), inside_words_of(n.b)); break;
+      case K_BIH: d = 3 + n.bih->depth + 3 + bih_items_max(n, true); break;
+      case K_TEX: case K_TAG: case K_NOSHADOW: case K_ONLYSHADOW: d = inside_words_of(n.a); break;
+      default: break;
+    }
+    iwords_memo[id] = d;
+    return d;
+  }
+  int vm_words_of(int id) const {
+    auto it = words_memo.find(id);
+    if (it != words_memo.end()) return it->second;
+    const Node& n = G.at(id);
+    int d = 0;
+    switch (n.kind) {
+      case K_LIST: { for (int k : n.kids) d = std::max(d, vm_words_of(k)); d += kVmListR; break; }
+      case K_ISECT: { for (int k : n.kids) d = std::max(d, std::max(vm_words_of(k), 1 + inside_words_of(k))); d += 1 + kVmIsectChain * kVmIsectWords; break; }
+      case K_INSTANCE: d = kVmInstR + vm_words_of(n.a); break;
+      case K_DIFF: d = 1 + kVmDiffFixed + kCsgMaxAdvance + std::max(std::max(vm_words_of(n.a), vm_words_of(n.b)), 1 + std::max(inside_words_of(n.a), inside_words_of(n.b))); break;
+      case K_BOUND: d = kVmBoundR + std::max(std::max(vm_words_of(n.a), vm_words_of(n.b)), 1 + inside_words_of(n.a)); break;
+      case K_INNERBOUND: d = kVmIbR + std::max(vm_words_of(n.a), vm_words_of(n.b)); break;
+      case K_BIH: d = kVmBihFixedR + 3 * n.bih->depth + bih_items_max(n, false); break;
+      case K_TEX: case K_TAG: case K_NOSHADOW: case K_ONLYSHADOW: d = vm_words_of(n.a); break;
+      default: break;  // primitives and a Mesh (its walk has a stack of its own) need no frame
+    }
+    words_memo[id] = d;
     return d;
   }
 

@@ -16,8 +16,7 @@
 
 namespace glome {
 
-constexpr int kVmWords = 768;  // frame words per ray (scratch); running out raises the context's error flag
-constexpr int kHitWords = 17;
+constexpr int kHitWords = kVmHitWords;  // (kVmWords frame words per ray, scratch: rt_types.h; running out raises the context's error flag)
 #ifndef GLOME_VM_BIH_STEPS
 #define GLOME_VM_BIH_STEPS 8
 #endif
@@ -247,7 +246,7 @@ GD bool vm_inside(const DScene& S, unsigned int& err, uint32_t* m, int base, U4 
 //   ISECT    1 first record, 2 n, 3 from, 4-5 tex, 6-8 origin, 9 d, 10 aux    (one frame per IFrame of the recursive form)
 //   BIH      1-2 tex, 3 flags (1 root is a leaf, 2 exact walk, 4 shadow), 4 d, 5-7 1/direction, 8 leaf cursor, 9 items left,
 //            10 the leaf's tmax, 11 traversal entries, [12.. best hit (rayint only)], then the entries (node, near, far)
-constexpr int kBihFixedS = 12, kBihFixedR = 12 + kHitWords, kDiffFixed = 10 + kHitWords, kIsectWords = 11;
+constexpr int kBihFixedS = kVmBihFixedS, kBihFixedR = kVmBihFixedR, kDiffFixed = kVmDiffFixed, kIsectWords = kVmIsectWords;
 
 template <bool C>
 GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, int st, U4 rec, Ray r, float d, bool exact, HitG& rh, bool& rb) {
@@ -363,7 +362,7 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, int st
         case R_LIST: {  // foldl' nearest RayMiss, every item with the same d (Solid.hs:327, Q9)
           rh = hit_miss();
           if (rec.z == 0) break;
-          VM_PUSH(VT_LIST_R, 7 + kHitWords);
+          VM_PUSH(VT_LIST_R, kVmListR);
           m[fb + 1] = rec.y; m[fb + 2] = rec.z; m[fb + 3] = 0; m[fb + 4] = as_u(d); VM_SET_TEX(5, tex); m[fb + 7] = 0;
           st = ST_LIST_R;
           break;
@@ -372,7 +371,7 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, int st
           Xf6 x = load_xf(S, rec.z);
           V3 newdir = mat_vec(x.i0, x.i1, x.i2, r.d), neworig = mat_point(x.i0, x.i1, x.i2, r.o);
           float lenscale = sqrtf(vdot(newdir, newdir)), invlenscale = 1.0f / lenscale;
-          VM_PUSH(VT_INST_R, 10);
+          VM_PUSH(VT_INST_R, kVmInstR);
           m[fb + 1] = as_u(r.o.x); m[fb + 2] = as_u(r.o.y); m[fb + 3] = as_u(r.o.z);
           m[fb + 4] = as_u(r.d.x); m[fb + 5] = as_u(r.d.y); m[fb + 6] = as_u(r.d.z);
           m[fb + 7] = as_u(invlenscale); m[fb + 8] = exact ? 1u : 0u; m[fb + 9] = rec.z;
@@ -385,13 +384,13 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, int st
         case R_BOUND: {  // rayint_bound, Bound.hs:30-35
           U4 sa = ldu4(S.recs, rec.y);
           if (vm_inside(S, err, m, sp, sa, r.o)) { rec = ldu4(S.recs, rec.z); st = ST_CALL_R; break; }
-          VM_PUSH(VT_BOUND_R, 5);
+          VM_PUSH(VT_BOUND_R, kVmBoundR);
           m[fb + 1] = rec.z; m[fb + 2] = as_u(d); VM_SET_TEX(3, tex);
           rec = sa; st = ST_CALL_S;
           break;
         }
         case R_INNERBOUND: {  // rayint_innerbound, Bound.hs:97-99
-          VM_PUSH(VT_IB_R, 4);
+          VM_PUSH(VT_IB_R, kVmIbR);
           m[fb + 1] = rec.z; VM_SET_TEX(2, tex);
           rec = ldu4(S.recs, rec.y); tex = 0; st = ST_CALL_R;
           break;

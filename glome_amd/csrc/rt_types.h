@@ -51,6 +51,10 @@ constexpr int kMaxLights = 8;
 constexpr int kFlatStack = 32;     // LDS traversal-stack entries per lane in the flat-tier kernels
 constexpr int kGenericStack = 32;  // scratch traversal-stack entries per BIH/Mesh level in the generic tier
 constexpr int kGenericDepth = 6;   // composite nesting levels get_metainfo is unrolled for (rt_generic.hpp; rayint / shadow / inside are loops)
+// the generic tier's frame stack (rt_generic_vm.hpp): words per ray, and the frame sizes the host's commit-time estimate shares
+constexpr int kVmWords = 768, kVmHitWords = 17, kVmListR = 7 + kVmHitWords, kVmInstR = 10, kVmBoundR = 5, kVmIbR = 4, kVmDiffFixed = 10 + kVmHitWords,
+              kVmIsectWords = 11, kVmBihFixedR = 12 + kVmHitWords, kVmBihFixedS = 12;
+constexpr int kVmIsectChain = 8;   // Intersection frames the commit-time estimate allows for (a chain longer than the memory is caught at run time)
 constexpr int kCsgMaxAdvance = 32; // ray-advance steps per CSG node before giving up (reference: unbounded)
 constexpr int kIsectFrames = 40;   // explicit frames for rayint_intersection's list recursion (flat tier's CSG items)
 constexpr int kMaxTraceDepth = 4;  // maxdepth values the render kernels are instantiated for

@@ -124,6 +124,11 @@ def test_flatten_tiers_and_limits(built):
     assert HostSim(b, n).info()["nesting"] == 16
     with pytest.raises(RuntimeError, match="nests composites deeper"):
         HostSim(b, b.difference(n, b.sphere((0.5, 0, 0), 0.7)))
+    # what bounds the nesting now is the interpreter's frame memory, estimated at commit from the frames each node needs
+    for _ in range(20):
+        n = b.group([b.transform(n, [api.translate((0.1, 0, 0))]), b.sphere((9, 9, 9), 0.1)])
+    with pytest.raises(RuntimeError, match="frame memory"):
+        HostSim(b, n)
 
 
 def test_c_abi_exports_every_declared_symbol(built):
