@@ -141,7 +141,7 @@ int32_t glome_sb_material_blend_fn(glome_sb* sb, int32_t a, int32_t b, int32_t w
 
 int32_t glome_sb_material_warp(glome_sb* sb, int32_t frame, int32_t scene, const glome_light* lights, int nlights, const double xfm[24]) {
   return guard(sb, [&] {
-    if (nlights < 0 || nlights > 8 || (nlights > 0 && !lights) || !xfm) throw std::invalid_argument("bad Warp lights / transform");
+    if (nlights < 0 || nlights > kMaxLights || (nlights > 0 && !lights) || !xfm) throw std::invalid_argument("bad Warp lights / transform");
     sb->graph.at(frame);
     if (scene >= 0) sb->graph.at(scene);
     Mat m; m.kind = MAT_WARP; m.wframe = frame; m.wscene = scene < 0 ? -1 : scene; m.wxf = xf_from(xfm);

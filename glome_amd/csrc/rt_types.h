@@ -47,7 +47,7 @@ enum DMatKind : uint32_t { DM_SURFACE = 0, DM_REFLECT = 1, DM_REFRACT = 2, DM_LA
 // A texture stack is at most 4 material ids, innermost first, 16 bits each, stored as id+1 (0 = end).
 typedef uint64_t TexStack;
 constexpr int kMaxTexDepth = 4;
-constexpr int kMaxLights = 8;
+constexpr int kMaxLights = 16;
 constexpr int kFlatStack = 32;     // LDS traversal-stack entries per lane in the flat-tier kernels
 constexpr int kGenericStack = 32;  // scratch traversal-stack entries per BIH/Mesh level in the generic tier
 constexpr int kGenericDepth = 6;   // composite nesting levels get_metainfo is unrolled for (rt_generic.hpp; rayint / shadow / inside are loops)

@@ -40,6 +40,23 @@ def test_rayint_shadow_inside_vs_oracle(gpu_ctx, name):
     sc.release()
 
 
+@pytest.mark.parametrize("name", ["flat_mixed", "nested"])
+def test_sixteen_lights(gpu_ctx, name):
+    # the light list's capacity (kMaxLights): a flat-tier and a generic-tier scene under 16 lights of every kind
+    sd = SCENES[name]()
+    rng = np.random.default_rng(16)
+    sd.lights = []
+    for k in range(16):
+        sd.add_light((float(rng.uniform(-20, 20)), float(rng.uniform(6, 40)), float(rng.uniform(-5, 40))), tuple(float(x) for x in rng.uniform(5, 60, 3)),
+                     rad=float(rng.uniform(25, 60)) if k % 5 == 4 else 1000000.0, shadow=k % 4 != 3)
+    b, nm, sc = commit(gpu_ctx, sd)
+    cam, lights = product_camera_lights(sd)
+    assert len(lights) == 16
+    img, _, st = sc.render(cam, lights, api.render_params(width=200, height=120, maxdepth=2), want_packed=False)
+    parity.check_image(img, (st["rays_primary"], st["rays_shadow"], st["rays_secondary"]), sd, 200, 120, 2)
+    sc.release()
+
+
 @pytest.mark.parametrize("name", sorted(SCENES))
 def test_render_vs_oracle(gpu_ctx, name):
     sd = SCENES[name]()
@@ -354,7 +371,7 @@ def test_edge_cases(gpu_ctx):
     with pytest.raises(api.GlomeError):
         sc.render(cam, [], api.render_params(width=16, height=16, maxdepth=0))
     with pytest.raises(api.GlomeError):
-        sc.render(cam, [api.light((0, 1, 0), (1, 1, 1))] * 9, api.render_params(width=16, height=16))
+        sc.render(cam, [api.light((0, 1, 0), (1, 1, 1))] * 17, api.render_params(width=16, height=16))
     with pytest.raises(api.GlomeError):
         sc.render(cam, [], api.render_params(width=16, height=16, mode=7))
     for (w, h) in [(1, 1), (7, 5), (65, 65), (66, 131)]:  # adaptive mode on tiny / ragged frames
@@ -848,8 +865,8 @@ def test_refused_parameters_fail_with_a_status_not_a_frame(gpu_ctx):
     cams = (L.Camera * 9)(*[cam] * 9)
     assert sc.lib.glome_render_packed_batch_dev(sc.h, cams, 9, la, len(lights), C.byref(P), C.c_void_p(buf.data_ptr()), 64 * 64, None) == L.E_LIMIT  # 1..8 frames
     assert sc.lib.glome_render_packed_batch_dev(sc.h, cams, 2, la, len(lights), C.byref(P), C.c_void_p(buf.data_ptr()), 0, None) == L.E_INVALID   # frame stride
-    too_many = (L.Light * 9)(*[lights[0]] * 9)
-    assert sc.lib.glome_render_dev(sc.h, C.byref(cam), too_many, 9, C.byref(P), None, C.c_void_p(buf.data_ptr()), None) in (L.E_INVALID, L.E_LIMIT)
+    too_many = (L.Light * 17)(*[lights[0]] * 17)  # (the light list holds 16)
+    assert sc.lib.glome_render_dev(sc.h, C.byref(cam), too_many, 17, C.byref(P), None, C.c_void_p(buf.data_ptr()), None) in (L.E_INVALID, L.E_LIMIT)
     gpu_ctx.synchronize()
     assert int(buf.abs().sum()) == 0
     sc.release()
