@@ -50,8 +50,6 @@ class Flattener {
     const bool warps = bind_warps();  // Warp materials refer to records: the frame's, and the scene's they look into
     if (vm_words_of(root) + 2 > kVmWords)
       throw limit_error("scene nests deeper than the device interpreter's frame memory holds (" + std::to_string(vm_words_of(root) + 2) + " of " + std::to_string(kVmWords) + " words)");
-    if (point_depth_of(root) > kGenericDepth)
-      throw limit_error("the solid a Difference carves nests composites deeper than the device's get_metainfo supports (" + std::to_string(point_depth_of(root)) + " > " + std::to_string(kGenericDepth) + ")");
     // flat tier: root program of simple entries
     F.tier = 0;
     if (warps) { F.tier = 1; F.why_generic = "a Warp material traces other roots than the scene's"; }
@@ -116,8 +114,6 @@ class Flattener {
       if (std::max(tex_depth_of(m.wframe), m.wscene < 0 ? 0 : tex_depth_of(m.wscene)) > kMaxTexDepth) throw limit_error("a Warp material's frame / scene has more nested textures than the device's texture stack holds");
       if (std::max(vm_words_of(m.wframe), m.wscene < 0 ? 0 : vm_words_of(m.wscene)) + 2 > kVmWords)
         throw limit_error("a Warp material's frame / scene nests deeper than the device interpreter's frame memory holds");
-      if (std::max(point_depth_of(m.wframe), m.wscene < 0 ? 0 : point_depth_of(m.wscene)) > kGenericDepth)
-        throw limit_error("a Warp material's frame / scene: the solid a Difference carves nests composites deeper than the device's get_metainfo supports");
       const uint32_t xf = (uint32_t)(F.xfms.size() / 6);
       for (int q = 0; q < 3; q++) F.xfms.push_back(mk4(m.wxf.f.m[4 * q], m.wxf.f.m[4 * q + 1], m.wxf.f.m[4 * q + 2], m.wxf.f.m[4 * q + 3]));
       for (int q = 0; q < 3; q++) F.xfms.push_back(mk4(m.wxf.i.m[4 * q], m.wxf.i.m[4 * q + 1], m.wxf.i.m[4 * q + 2], m.wxf.i.m[4 * q + 3]));
@@ -140,11 +136,10 @@ class Flattener {
   }
   int mat_nest_max() const { int d = 0; for (size_t m = 0; m < G.mats.size(); m++) d = std::max(d, mat_nest((int)m, 0)); return d; }
 
-  // composite nesting depth (Tex / Tag / NoShadow / OnlyShadow wrappers are free: the interpreter loops over them).  rayint,
-  // shadow and inside run over explicit frames (rt_generic_vm.hpp) and nest as deep as the frame memory allows; only
-  // `get_metainfo` (rt_generic.hpp) is unrolled to kGenericDepth levels, and only the first operand of a Difference is ever
-  // asked for it (the textures at a carved point, Csg.hs:103-106): point_depth_of is the deepest such operand below `id`.
-  mutable std::unordered_map<int, int> depth_memo, pdepth_memo;
+  // composite nesting depth (Tex / Tag / NoShadow / OnlyShadow wrappers are free: the interpreter loops over them); reported
+  // in glome_scene_info.  Nothing on the device is unrolled by it any more: all four class methods run over explicit frames
+  // (rt_generic.hpp), and what bounds the nesting is the frame memory (vm_words_of below).
+  mutable std::unordered_map<int, int> depth_memo;
   int depth_of(int id) const {
     auto it = depth_memo.find(id);
     if (it != depth_memo.end()) return it->second;
@@ -162,28 +157,11 @@ class Flattener {
     depth_memo[id] = d;
     return d;
   }
-  int point_depth_of(int id) const {
-    auto it = pdepth_memo.find(id);
-    if (it != pdepth_memo.end()) return it->second;
-    const Node& n = G.at(id);
-    int d = 0;
-    switch (n.kind) {
-      case K_LIST: case K_ISECT: for (int k : n.kids) d = std::max(d, point_depth_of(k)); break;
-      case K_DIFF: d = std::max(depth_of(n.a), std::max(point_depth_of(n.a), point_depth_of(n.b))); break;
-      case K_BOUND: case K_INNERBOUND: d = std::max(point_depth_of(n.a), point_depth_of(n.b)); break;
-      case K_BIH: for (auto& bn : n.bih->nodes) for (int k : bn.items) d = std::max(d, point_depth_of(k)); break;
-      case K_INSTANCE: case K_TEX: case K_TAG: case K_NOSHADOW: case K_ONLYSHADOW: d = point_depth_of(n.a); break;
-      default: break;
-    }
-    pdepth_memo[id] = d;
-    return d;
-  }
-
-  // Frame words a rayint / shadow / inside call on `id` can have live at once in the generic tier's loop (rt_generic_vm.hpp's
+  // Frame words a rayint / shadow / inside call on `id` can have live at once in the generic tier's loop (rt_generic.hpp's
   // frame layouts): what the interpreter's nesting limit is now -- memory, checked here so that a scene is refused at commit
   // rather than stopped in the middle of a frame.  An Intersection's chain of advance frames depends on the geometry; the
   // estimate allows kVmIsectChain of them and the run-time check (GLOME_E_LIMIT) remains behind it.
-  mutable std::unordered_map<int, int> words_memo, iwords_memo;
+  mutable std::unordered_map<int, int> words_memo, iwords_memo, mwords_memo;
   int bih_items_max(const Node& n, bool inside) const {
     int d = 0;
     for (auto& bn : n.bih->nodes) for (int k : bn.items) d = std::max(d, inside ? inside_words_of(k) : vm_words_of(k));
@@ -205,6 +183,22 @@ class Flattener {
     iwords_memo[id] = d;
     return d;
   }
+  int meta_words_of(int id) const {  // get_metainfo's frames (vm_meta), with the inside calls it makes above them
+    auto it = mwords_memo.find(id);
+    if (it != mwords_memo.end()) return it->second;
+    const Node& n = G.at(id);
+    int d = 0;
+    switch (n.kind) {
+      case K_LIST: case K_ISECT: { for (int k : n.kids) d = std::max(d, std::max(meta_words_of(k), 1 + inside_words_of(k))); d = std::max(d, 1 + inside_words_of(id)) + 7; break; }
+      case K_INSTANCE: d = 8 + meta_words_of(n.a); break;
+      case K_DIFF: case K_BOUND: case K_INNERBOUND: d = 3 + std::max(std::max(meta_words_of(n.a), meta_words_of(n.b)), 1 + std::max(inside_words_of(n.a), inside_words_of(n.b))); break;
+      case K_BIH: { for (auto& bn : n.bih->nodes) for (int k : bn.items) d = std::max(d, std::max(meta_words_of(k), 1 + inside_words_of(k))); d += 11 + n.bih->depth; break; }
+      case K_TEX: case K_TAG: case K_NOSHADOW: case K_ONLYSHADOW: d = meta_words_of(n.a); break;
+      default: break;
+    }
+    mwords_memo[id] = d;
+    return d;
+  }
   int vm_words_of(int id) const {
     auto it = words_memo.find(id);
     if (it != words_memo.end()) return it->second;
@@ -214,7 +208,7 @@ class Flattener {
       case K_LIST: { for (int k : n.kids) d = std::max(d, vm_words_of(k)); d += kVmListR; break; }
       case K_ISECT: { for (int k : n.kids) d = std::max(d, std::max(vm_words_of(k), 1 + inside_words_of(k))); d += 1 + kVmIsectChain * kVmIsectWords; break; }
       case K_INSTANCE: d = kVmInstR + vm_words_of(n.a); break;
-      case K_DIFF: d = 1 + kVmDiffFixed + kCsgMaxAdvance + std::max(std::max(vm_words_of(n.a), vm_words_of(n.b)), 1 + std::max(inside_words_of(n.a), inside_words_of(n.b))); break;
+      case K_DIFF: d = 1 + kVmDiffFixed + kCsgMaxAdvance + std::max(std::max(vm_words_of(n.a), vm_words_of(n.b)), 1 + std::max(std::max(inside_words_of(n.a), inside_words_of(n.b)), meta_words_of(n.a))); break;
       case K_BOUND: d = kVmBoundR + std::max(std::max(vm_words_of(n.a), vm_words_of(n.b)), 1 + inside_words_of(n.a)); break;
       case K_INNERBOUND: d = kVmIbR + std::max(vm_words_of(n.a), vm_words_of(n.b)); break;
       case K_BIH: d = kVmBihFixedR + 3 * n.bih->depth + bih_items_max(n, false); break;

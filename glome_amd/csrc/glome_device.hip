@@ -9,7 +9,7 @@
 //                                       (packet: rt_device.hpp bih_tri_wave; for triangles the hand-written walk of
 //                                       bih_packet_asm.hpp) -> shadow rays -> shade; secondary rays re-enter the same walk
 //                                       through the shading state machine (shade_vm).  No ray streams in HBM at all.
-//   k_render_generic                    same loop over the generic interpreter (rt_generic_vm.hpp: rayint / shadow / inside of any
+//   k_render_generic                    same loop over the generic interpreter (rt_generic.hpp: rayint / shadow / inside / get_metainfo of any
 //                                       nesting of composites as one loop over explicit frames)
 //   k_ss_frame_flat / k_ss_frame_generic  the adaptive sampler (renderTileSubsample, Glome.hs:226-323): five passes per
 //                                       tile, one launch per frame or batch of frames
@@ -30,7 +30,7 @@
 #include "flatten.hpp"
 #include "tiles.hpp"
 #include "rt_device.hpp"
-#include "rt_generic_vm.hpp"
+#include "rt_generic.hpp"
 #ifndef GLOME_GENERIC_LB
 #define GLOME_GENERIC_LB 2  // waves per SIMD the generic-tier kernels are compiled for (256 VGPRs)
 #endif
@@ -942,7 +942,7 @@ static void launch_render(glome_scene* s, const DRenderArgs& A, const glome_rend
   // A scene with a Refract material, traced deeper than the primary ray: the transmitted rays are not unit length
   // (Shader.hs:141), and for those rayint_sphere (Sphere.hs:20-41) reports hits outside the sphere's box -- the ordered
   // early-out's pruning is exact only for unit rays, so such a frame is traversed as the reference traverses (the flat
-  // tier's faithful instance; the generic tier switches per ray, rt_generic_vm.hpp).
+  // tier's faithful instance; the generic tier switches per ray, rt_generic.hpp).
   if (s->dev.tier == 0 && s->has_refract && P->maxdepth > 1) faithful = count = true;
   if (s->dev.tier == 0) {
     // lean kernel: legal when no secondary trace can do work and no material nests (Blend / AdditiveLayers)

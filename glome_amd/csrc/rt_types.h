@@ -50,8 +50,7 @@ constexpr int kMaxTexDepth = 4;
 constexpr int kMaxLights = 16;
 constexpr int kFlatStack = 32;     // LDS traversal-stack entries per lane in the flat-tier kernels
 constexpr int kGenericStack = 32;  // scratch traversal-stack entries per BIH/Mesh level in the generic tier
-constexpr int kGenericDepth = 6;   // composite nesting levels get_metainfo is unrolled for (rt_generic.hpp; rayint / shadow / inside are loops)
-// the generic tier's frame stack (rt_generic_vm.hpp): words per ray, and the frame sizes the host's commit-time estimate shares
+// the generic tier's frame stack (rt_generic.hpp): words per ray, and the frame sizes the host's commit-time estimate shares
 constexpr int kVmWords = 768, kVmHitWords = 17, kVmListR = 7 + kVmHitWords, kVmInstR = 10, kVmBoundR = 5, kVmIbR = 4, kVmDiffFixed = 10 + kVmHitWords,
               kVmIsectWords = 11, kVmBihFixedR = 12 + kVmHitWords, kVmBihFixedS = 12;
 constexpr int kVmIsectChain = 8;   // Intersection frames the commit-time estimate allows for (a chain longer than the memory is caught at run time)

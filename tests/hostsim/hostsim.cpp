@@ -8,7 +8,7 @@
 #include "../../glome_amd/csrc/capi_shared.hpp"
 #include "../../glome_amd/csrc/flatten.hpp"
 #include "../../glome_amd/csrc/rt_device.hpp"
-#include "../../glome_amd/csrc/rt_generic_vm.hpp"
+#include "../../glome_amd/csrc/rt_generic.hpp"
 
 using namespace glome;
 

@@ -255,7 +255,7 @@ ALL["testscene"] = lambda: testscene(4)  # (a 9x9x9 lattice keeps the CPU oracle
 def deep_nest(levels=14):
     """Composites nested `levels` deep -- group [instance (bih [...]), sphere] over and over, each level moved, turned and
     scaled a little, and a Difference whose operands are shallow at the very top: the reference recurses as deep as the scene
-    goes; the device's rayint / shadow loop keeps its frames in memory and does the same (rt_generic_vm.hpp)."""
+    goes; the device's rayint / shadow loop keeps its frames in memory and does the same (rt_generic.hpp)."""
     sd = SceneDesc()
     m = scenes.materials(sd)
     teal, pink = scenes.matte(sd, (0.1, 0.7, 0.7)), scenes.matte(sd, (1, 0.4, 0.7))

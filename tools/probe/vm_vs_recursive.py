@@ -1,4 +1,4 @@
-"""CPU regression check of the generic tier's explicit-frame loop (rt_generic_vm.hpp) against the recursive interpreter it
+"""CPU regression check of the generic tier's explicit-frame loop (rt_generic.hpp) against the recursive interpreter it
 replaced: both compiled for the host (tests/hostsim), random composite scenes with random cameras and light rigs; frames,
 work counters, rayint / shadow / inside batches must be bit-identical.  The recursive build comes from the history:
     rm -rf /tmp/legacy && mkdir -p /tmp/legacy && git archive 58d9928 glome_amd/csrc tests/hostsim include | tar -x -C /tmp/legacy && make -C /tmp/legacy/tests/hostsim
