@@ -109,11 +109,23 @@ struct Cnt {  // per-lane work counters (only live when COUNT)
   uint32_t bih = 0, mesh = 0, prim = 0, shadow = 0, secondary = 0, primary = 0;
 };
 
+// 1 / (a ray direction component), the ONE way everywhere a slab or a split plane is clipped: a box that ends on a BIH split
+// plane (or on its tree's bounds) must leave at bit-identical distances on both paths -- box_shadow's `far > d` (Box.hs:56-62)
+// and every `near > far` depend on it.  Written as `1.0f / x` the compiler lowers most sites to v_rcp_f32 (the build allows
+// 2.5 ulp) but loses that licence on some after hoisting them, and those come out correctly rounded: a last-bit disagreement
+// between a leaf's interval and its item's slab that the generic tier's loop showed on 1 shadow ray in 10,000 (found by the
+// GPU fuzz soak; the host build divides exactly everywhere and never saw it).
+#ifdef __HIP_DEVICE_COMPILE__
+GD float dir_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#else
+GD float dir_rcp(float x) { return 1.0f / x; }
+#endif
+
 // ------------------------------------------------------------------ slab tests (Vec.hs:725-762)
 // bbclip_ub: divides by the direction itself and branches on d > 0 (not on 1/d) -- Q1: d = +0 gives
 // (in, out) = (+inf, -inf) or NaN where the origin coordinate lies inside the slab.
 GD void bbclip_ub(const Ray& r, V3 lo, V3 hi, float& nearv, float& farv) {
-  float dxr = 1.0f / r.d.x, dyr = 1.0f / r.d.y, dzr = 1.0f / r.d.z;
+  float dxr = dir_rcp(r.d.x), dyr = dir_rcp(r.d.y), dzr = dir_rcp(r.d.z);
   float inx, outx, iny, outy, inz, outz;
   if (r.d.x > 0) { inx = (lo.x - r.o.x) * dxr; outx = (hi.x - r.o.x) * dxr; } else { inx = (hi.x - r.o.x) * dxr; outx = (lo.x - r.o.x) * dxr; }
   if (r.d.y > 0) { iny = (lo.y - r.o.y) * dyr; outy = (hi.y - r.o.y) * dyr; } else { iny = (hi.y - r.o.y) * dyr; outy = (lo.y - r.o.y) * dyr; }
@@ -476,7 +488,7 @@ GD void bih_traverse(const DScene& S, uint32_t hdr, const Ray& r, float d, STK& 
   float nearv, farv;
   bbclip_ub(r, v3(h0), v3(h1), nearv, farv);
   farv = gminf(d, farv);  // `traverse root near (fmin d far)`, Bih.hs:368
-  V3 rcp = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+  V3 rcp = v3(dir_rcp(r.d.x), dir_rcp(r.d.y), dir_rcp(r.d.z));
   uint32_t ref = as_u(h0.w);
   // A tree that is one leaf: the reference tests it whatever the root interval (`traverse (BihLeaf s) near far = rayint s r
   // far`, Bih.hs:339) -- and something CAN be hit when the ray misses the box: Refract's transmitted direction is not unit
@@ -555,7 +567,7 @@ GD bool bih_tri(const DScene& S, uint32_t hdr, const Ray& r, float d, STK& stk, 
   float nearv, farv;
   bbclip_ub(r, v3(h0), v3(h1), nearv, farv);
   farv = gminf(d, farv);  // `traverse root near (fmin d far)`, Bih.hs:368
-  const V3 rcp = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+  const V3 rcp = v3(dir_rcp(r.d.x), dir_rcp(r.d.y), dir_rcp(r.d.z));
   uint32_t ref = as_u(h0.w);
   const int cap = stk.total_cap();
   int sp = 0;
@@ -806,7 +818,7 @@ GD bool bih_tri_wave(const DScene& S, uint32_t hdr, const Ray& r, float d, bool 
   F4 h0 = ld4u(S.bihhdr, 3 * hdr), h1 = ld4u(S.bihhdr, 3 * hdr + 1);
   const uint32_t delta = uni(as_u(ld4u(S.bihhdr, 3 * hdr + 2).x));
   const uint32_t ref = uni(as_u(h0.w));
-  const V3 rcp = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+  const V3 rcp = v3(dir_rcp(r.d.x), dir_rcp(r.d.y), dir_rcp(r.d.z));
   float nearv, farv;
   bbclip_ub(r, v3(h0), v3(h1), nearv, farv);
   farv = gminf(d, farv);  // `traverse root near (fmin d far)`, Bih.hs:368
@@ -872,7 +884,7 @@ constexpr uint32_t MREF_LEAF = 0x80000000u;
 template <bool COUNT, class STK>
 GD void mesh_closest(const DScene& S, uint32_t mh, const Ray& ray, float depth, STK& stk, int stack_cap, Cnt& cnt, float& best_t, uint32_t& best_tri) {
   F4 h0 = ld4(S.meshhdr, 2 * mh), h1 = ld4(S.meshhdr, 2 * mh + 1);
-  V3 rcp = v3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+  V3 rcp = v3(dir_rcp(ray.d.x), dir_rcp(ray.d.y), dir_rcp(ray.d.z));
   float nearv, farv;
   bbclip_ub_rcp(ray.o, rcp, v3(h0), v3(h1), nearv, farv);
   best_t = kInf; best_tri = 0xffffffffu;  // ridepth RayMiss = infinity

@@ -547,7 +547,7 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, int st
           VM_PUSH(VT_BIH_R, kBihFixedR);
           VM_SET_TEX(1, tex);
           m[fb + 3] = ((ref & BREF_LEAF) ? 1u : 0u) | (exact ? 2u : 0u); m[fb + 4] = as_u(d);
-          m[fb + 5] = as_u(1.0f / r.d.x); m[fb + 6] = as_u(1.0f / r.d.y); m[fb + 7] = as_u(1.0f / r.d.z);
+          m[fb + 5] = as_u(dir_rcp(r.d.x)); m[fb + 6] = as_u(dir_rcp(r.d.y)); m[fb + 7] = as_u(dir_rcp(r.d.z));
           m[fb + 9] = 0; m[fb + 11] = 0; m[fb + 12] = 0;
           bt = kInf * 4.0f;
           st = ST_BIH;
@@ -616,7 +616,7 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, int st
           ref = as_u(h0.w);
           VM_PUSH(VT_BIH_S, kBihFixedS);
           m[fb + 3] = ((ref & BREF_LEAF) ? 1u : 0u) | 4u; m[fb + 4] = as_u(d);
-          m[fb + 5] = as_u(1.0f / r.d.x); m[fb + 6] = as_u(1.0f / r.d.y); m[fb + 7] = as_u(1.0f / r.d.z);
+          m[fb + 5] = as_u(dir_rcp(r.d.x)); m[fb + 6] = as_u(dir_rcp(r.d.y)); m[fb + 7] = as_u(dir_rcp(r.d.z));
           m[fb + 9] = 0; m[fb + 11] = 0;
           bt = 0;
           st = ST_BIH;
@@ -832,7 +832,7 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, int st
       const uint32_t flags = m[fb + 3];
       const bool root_leaf = flags & 1u, exactm = flags & 2u, shadowm = flags & 4u, ordered = !exactm && !shadowm;
       const int fixed = shadowm ? kBihFixedS : kBihFixedR;
-      const V3 rcp = v3(as_f(m[fb + 5]), as_f(m[fb + 6]), as_f(m[fb + 7]));
+      const V3 rcp = v3(as_f(m[fb + 5]), as_f(m[fb + 6]), as_f(m[fb + 7]));  // (dir_rcp of the ray at entry: rt_device.hpp)
       int ne = (int)m[fb + 11];
       const int bfb = fb;
       for (int rep = 0; rep < kBihStepsPerPass; rep++) {
