@@ -405,3 +405,18 @@ def random_flat(seed, n_items=14):
     if extra == 2:
         parts.append(sd.bih([sd.tex(sd.sphere((float(x), 0.4, float(z)), 0.35), mats[(x + z) % 2]) for x in range(-4, 4) for z in range(5, 8)]))
     return _finish(sd, sd.group(parts))
+
+
+def random_rig(sd, seed):
+    """a random view and light rig for a fuzz scene (tools/probe/fuzz_gpu.py's): axis-aligned and inside-the-scene cameras, 1-4
+    lights, some without shadows, some of finite reach"""
+    rng = np.random.default_rng(7000 + seed)
+    k = int(rng.integers(0, 4))
+    if k == 0: sd.set_camera((0.0, 2.0, 12.0), (0.0, 2.0, 0.0), (0, 1, 0), 45.0)
+    elif k == 1: sd.set_camera((float(rng.uniform(-3, 3)), float(rng.uniform(0.5, 3)), float(rng.uniform(-3, 3))), (0.0, 1.0, 0.0), (0, 1, 0), 70.0)
+    elif k == 2: sd.set_camera((float(rng.uniform(-9, 9)), float(rng.uniform(3, 9)), float(rng.uniform(8, 14))), (0.0, 1.0, 0.0), (0, 1, 0), float(rng.uniform(30, 60)))
+    sd.lights = []
+    for _ in range(int(rng.integers(1, 5))):
+        sd.add_light((float(rng.uniform(-30, 30)), float(rng.uniform(5, 60)), float(rng.uniform(-10, 60))), tuple(float(x) for x in rng.uniform(20, 900, 3)),
+                     rad=float(rng.uniform(15, 60)) if rng.uniform() < 0.3 else 1000000.0, shadow=bool(rng.uniform() < 0.8))
+    return sd
