@@ -712,16 +712,15 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, int st
           }
           uint32_t na = m[fb + 9];
           if (!finish) {
-            if (na >= (uint32_t)kCsgMaxAdvance) { err = 1; finish = true; }
-            else {
-              VM_NEED(1);
-              const float a = adv + kDel;
-              m[sp++] = as_u(a); m[fb + 9] = na + 1;
-              r.o = vscaleadd(r.o, r.d, a);  // ray_move
-              m[fb + 8] = as_u(as_f(m[fb + 8]) - a);
-              st = ST_DIFF;
-              break;
-            }
+            // (the reference advances as often as it takes; here as long as the frame memory lasts -- the commit-time estimate
+            // allows kCsgMaxAdvance per Difference, the flat tier's fixed cap)
+            VM_NEED(1);
+            const float a = adv + kDel;
+            m[sp++] = as_u(a); m[fb + 9] = na + 1;
+            r.o = vscaleadd(r.o, r.d, a);  // ray_move
+            m[fb + 8] = as_u(as_f(m[fb + 8]) - a);
+            st = ST_DIFF;
+            break;
           }
           if (res.hit) for (int k = (int)na - 1; k >= 0; k--) res.t = res.t + as_f(m[fb + kDiffFixed + k]);  // RayHit (depth+a) ..., innermost first
           r.o = v3(as_f(m[fb + 5]), as_f(m[fb + 6]), as_f(m[fb + 7]));
