@@ -34,7 +34,16 @@
 #ifndef GLOME_GENERIC_LB
 #define GLOME_GENERIC_LB 2  // waves per SIMD the generic-tier kernels are compiled for (256 VGPRs)
 #endif
+// This file is compiled several times (glome_amd/build.py, in parallel): -DGLOME_PART=k keeps the kernel instances listed for
+// part k further down (and their launchers); part 0 is the host runtime, the light kernels and the tree builders.  Without the
+// define the whole file is one translation unit, as it used to be (4.5 minutes of hipcc).
+#ifndef GLOME_PART
+#define GLOME_PART -1
+#endif
+#define GLOME_IN_PART(k) (GLOME_PART == -1 || GLOME_PART == (k))
+#if GLOME_IN_PART(0)
 #include "bih_build_device.hpp"
+#endif
 
 using namespace glome;
 
@@ -245,12 +254,14 @@ __global__ void __launch_bounds__(64, LB) k_render_flat(DRenderArgs A, int stack
   if (A.want_counters) flush_counters(A.counters, T.cnt, T.err);
   else if ((CLS & CLS_CSG) && __builtin_amdgcn_ballot_w64(T.err != 0) && (threadIdx.x & 63) == 0) atomicOr(&A.counters->error, 1u);
 }
+#if GLOME_IN_PART(6)
 __global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_render_generic(DRenderArgs A) {
   GenericTier T{A.S, A.lights, A.nlights, Cnt()};
   render_loop(A, T);
   if (A.want_counters) flush_counters(A.counters, T.cnt, T.err);
   else if (__builtin_amdgcn_ballot_w64(T.err != 0) && (threadIdx.x & 63) == 0) atomicOr(&A.counters->error, 1u);
 }
+#endif
 
 
 // ------------------------------------------------------------------------------------------------ adaptive sampler
@@ -428,12 +439,14 @@ __global__ void __launch_bounds__(64, LB) k_ss_frame_flat(DRenderArgs A, int sta
   if (A.want_counters) flush_counters(A.counters, T.cnt, T.err);
   else if ((CLS & CLS_CSG) && __builtin_amdgcn_ballot_w64(T.err != 0) && (threadIdx.x & 63) == 0) atomicOr(&A.counters->error, 1u);
 }
+#if GLOME_IN_PART(7)
 __global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_ss_frame_generic(DRenderArgs A) {
   GenericTier T{A.S, A.lights, A.nlights, Cnt()};
   ss_frame_loop(A, T);
   if (A.want_counters) flush_counters(A.counters, T.cnt, T.err);
   else if (__builtin_amdgcn_ballot_w64(T.err != 0) && (threadIdx.x & 63) == 0) atomicOr(&A.counters->error, 1u);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------ batch seams
 struct RayStream { const float *ox, *oy, *oz, *dx, *dy, *dz, *tmax; };
@@ -471,6 +484,7 @@ __global__ void __launch_bounds__(64) k_rayint_batch_flat(DScene S, size_t n, Ra
   }
   if (T.err) atomicOr(&c->error, 1u);
 }
+template <int DUMMY = 0>
 __global__ void __launch_bounds__(64) k_shadow_batch_flat(DScene S, size_t n, RayStream R, uint8_t* occ, int stack_cap, uint32_t* ovf, int ovf_cap, DCounters* c) {
   extern __shared__ uint32_t lds[];
   FlatTier<false, false, false, CLS_EVERY> T{S, nullptr, 0, lane_stack(lds, stack_cap, ovf, ovf_cap), Cnt()};
@@ -478,6 +492,7 @@ __global__ void __launch_bounds__(64) k_shadow_batch_flat(DScene S, size_t n, Ra
     occ[i] = T.occluded(load_ray(R, i), R.tmax[i]) ? 1 : 0;
   if (T.err) atomicOr(&c->error, 1u);
 }
+#if GLOME_IN_PART(8)
 __global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_rayint_batch_generic(DScene S, size_t n, RayStream R, HitStream H, DCounters* c) {
   GenericTier T{S, nullptr, 0, Cnt()};
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -497,8 +512,10 @@ __global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_inside_batch(DScene S,
     in[i] = vm_inside(S, err, vm, 0, ldu4(S.recs, S.root_rec), v3(px[i], py[i], pz[i])) ? 1 : 0;
   if (err) atomicOr(&c->error, 1u);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------ tile transport
+#if GLOME_IN_PART(0)
 __global__ void k_tiles_pack(const DTile* tiles, int ntiles, int width, const float* frame, float* payload) {
   for (int t = blockIdx.y; t < ntiles; t += gridDim.y) {
     DTile T = tiles[t];
@@ -537,7 +554,96 @@ __global__ void k_tiles_blit_packed(const DTile* tiles, int ntiles, int width, c
   }
 }
 
+#endif
+
+// ------------------------------------------------------------------------------------------------ kernel instances by part
+// Every instance the host runtime can ask for, listed once; the part that holds an instance defines the launcher that knows it.
+struct FlatLaunch { int grid; size_t lds; hipStream_t st; int stack_cap; uint32_t* ovf; int ovf_cap; };
+constexpr int render_flat_key(bool F, bool C, bool U, int CLS, int LB, bool TWO) { return (F ? 1 : 0) | (C ? 2 : 0) | (U ? 4 : 0) | (TWO ? 8 : 0) | (LB << 4) | (CLS << 8); }
+constexpr int ss_flat_key(bool U, int CLS, int LB, bool TWO, bool F) { return (F ? 1 : 0) | (U ? 4 : 0) | (TWO ? 8 : 0) | (LB << 4) | (CLS << 8); }
+// k_render_flat<FAITHFUL, COUNT, FULL, CLS, LB, TWO_ROWS>
+#define GLOME_RENDER_FLAT_P1(X) /* production, lean */                                                                      \
+  X(false, false, false, CLS_BIH_TRI, 1, false) X(false, false, false, (CLS_BIH_SPHERE | CLS_PRIMS), 1, false) X(false, false, false, CLS_MESH, 1, false) \
+  X(false, false, false, CLS_ALL, 1, false) X(false, false, false, CLS_BIH_TRI, 6, true)
+#define GLOME_RENDER_FLAT_P2(X) /* production, full (secondary rays, nested materials) */                                   \
+  X(false, false, true, CLS_BIH_TRI, 1, false) X(false, false, true, (CLS_BIH_SPHERE | CLS_PRIMS), 1, false) X(false, false, true, CLS_MESH, 1, false) \
+  X(false, false, true, CLS_ALL, 1, false)
+#define GLOME_RENDER_FLAT_P3(X) /* the CSG class (two waves per SIMD: S4 0.72 -> 0.52 ms; three spill) */                    \
+  X(false, false, false, CLS_EVERY, 2, false) X(false, false, true, CLS_EVERY, 2, false)
+#define GLOME_RENDER_FLAT_P4(X) /* faithful / counting */                                                                   \
+  X(true, true, true, CLS_EVERY, 1, false) X(true, true, false, CLS_EVERY, 1, false) X(false, true, true, CLS_EVERY, 1, false) X(false, true, false, CLS_EVERY, 1, false)
+// k_ss_frame_flat<FULL, CLS, LB, TWO_ROWS, FAITHFUL>
+#define GLOME_SS_FLAT_P5(X) X(false, CLS_BIH_TRI, 5, true, false) X(false, CLS_BIH_TRI, 4, true, false) X(false, CLS_BIH_TRI, 1, false, false) X(true, CLS_BIH_TRI, 1, false, false)
+#define GLOME_SS_FLAT_P9(X) X(true, CLS_EVERY, 1, false, true) X(false, CLS_EVERY, 2, false, false) X(true, CLS_EVERY, 2, false, false)
+constexpr int kParts = 10;
+
+#define GLOME_TRY_RENDER_FLAT(F, C, U, K, B, T)                                                                                                   \
+  if (key == render_flat_key(F, C, U, K, B, T)) {                                                                                                 \
+    hipLaunchKernelGGL((k_render_flat<F, C, U, K, B, T>), dim3(L.grid), dim3(64), L.lds, L.st, A, L.stack_cap, L.ovf, L.ovf_cap);                 \
+    return true;                                                                                                                                  \
+  }
+#define GLOME_TRY_SS_FLAT(U, K, B, T, F)                                                                                                          \
+  if (key == ss_flat_key(U, K, B, T, F)) {                                                                                                        \
+    hipLaunchKernelGGL((k_ss_frame_flat<U, K, B, T, F>), dim3(L.grid), dim3(64), L.lds, L.st, A, L.stack_cap, L.ovf, L.ovf_cap);                  \
+    return true;                                                                                                                                  \
+  }
+bool launch_flat_p1(int key, const FlatLaunch& L, const DRenderArgs& A);
+bool launch_flat_p2(int key, const FlatLaunch& L, const DRenderArgs& A);
+bool launch_flat_p3(int key, const FlatLaunch& L, const DRenderArgs& A);
+bool launch_flat_p4(int key, const FlatLaunch& L, const DRenderArgs& A);
+bool launch_ss_flat_p5(int key, const FlatLaunch& L, const DRenderArgs& A);
+bool launch_ss_flat_p9(int key, const FlatLaunch& L, const DRenderArgs& A);
+void launch_render_generic(int grid, hipStream_t st, const DRenderArgs& A);
+void launch_ss_generic(int grid, hipStream_t st, const DRenderArgs& A);
+void launch_rayint_batch_flat(const FlatLaunch& L, DScene S, size_t n, RayStream R, HitStream H, DCounters* c);
+void launch_shadow_batch_flat(const FlatLaunch& L, DScene S, size_t n, RayStream R, uint8_t* occ, DCounters* c);
+void launch_rayint_batch_generic(int grid, hipStream_t st, DScene S, size_t n, RayStream R, HitStream H, DCounters* c);
+void launch_shadow_batch_generic(int grid, hipStream_t st, DScene S, size_t n, RayStream R, uint8_t* occ, DCounters* c);
+void launch_inside_batch(int grid, hipStream_t st, DScene S, size_t n, const float* px, const float* py, const float* pz, uint8_t* in, DCounters* c);
+#if GLOME_IN_PART(1)
+bool launch_flat_p1(int key, const FlatLaunch& L, const DRenderArgs& A) { GLOME_RENDER_FLAT_P1(GLOME_TRY_RENDER_FLAT) return false; }
+#endif
+#if GLOME_IN_PART(2)
+bool launch_flat_p2(int key, const FlatLaunch& L, const DRenderArgs& A) { GLOME_RENDER_FLAT_P2(GLOME_TRY_RENDER_FLAT) return false; }
+#endif
+#if GLOME_IN_PART(3)
+bool launch_flat_p3(int key, const FlatLaunch& L, const DRenderArgs& A) { GLOME_RENDER_FLAT_P3(GLOME_TRY_RENDER_FLAT) return false; }
+#endif
+#if GLOME_IN_PART(4)
+bool launch_flat_p4(int key, const FlatLaunch& L, const DRenderArgs& A) { GLOME_RENDER_FLAT_P4(GLOME_TRY_RENDER_FLAT) return false; }
+#endif
+#if GLOME_IN_PART(5)
+bool launch_ss_flat_p5(int key, const FlatLaunch& L, const DRenderArgs& A) { GLOME_SS_FLAT_P5(GLOME_TRY_SS_FLAT) return false; }
+void launch_rayint_batch_flat(const FlatLaunch& L, DScene S, size_t n, RayStream R, HitStream H, DCounters* c) {
+  hipLaunchKernelGGL((k_rayint_batch_flat<false>), dim3(L.grid), dim3(64), L.lds, L.st, S, n, R, H, L.stack_cap, L.ovf, L.ovf_cap, c);
+}
+void launch_shadow_batch_flat(const FlatLaunch& L, DScene S, size_t n, RayStream R, uint8_t* occ, DCounters* c) {
+  hipLaunchKernelGGL((k_shadow_batch_flat<0>), dim3(L.grid), dim3(64), L.lds, L.st, S, n, R, occ, L.stack_cap, L.ovf, L.ovf_cap, c);
+}
+#endif
+#if GLOME_IN_PART(9)
+bool launch_ss_flat_p9(int key, const FlatLaunch& L, const DRenderArgs& A) { GLOME_SS_FLAT_P9(GLOME_TRY_SS_FLAT) return false; }
+#endif
+#if GLOME_IN_PART(6)
+void launch_render_generic(int grid, hipStream_t st, const DRenderArgs& A) { hipLaunchKernelGGL(k_render_generic, dim3(grid), dim3(64), 0, st, A); }
+#endif
+#if GLOME_IN_PART(7)
+void launch_ss_generic(int grid, hipStream_t st, const DRenderArgs& A) { hipLaunchKernelGGL(k_ss_frame_generic, dim3(grid), dim3(64), 0, st, A); }
+#endif
+#if GLOME_IN_PART(8)
+void launch_rayint_batch_generic(int grid, hipStream_t st, DScene S, size_t n, RayStream R, HitStream H, DCounters* c) { hipLaunchKernelGGL(k_rayint_batch_generic, dim3(grid), dim3(64), 0, st, S, n, R, H, c); }
+void launch_shadow_batch_generic(int grid, hipStream_t st, DScene S, size_t n, RayStream R, uint8_t* occ, DCounters* c) { hipLaunchKernelGGL(k_shadow_batch_generic, dim3(grid), dim3(64), 0, st, S, n, R, occ, c); }
+void launch_inside_batch(int grid, hipStream_t st, DScene S, size_t n, const float* px, const float* py, const float* pz, uint8_t* in, DCounters* c) {
+  hipLaunchKernelGGL(k_inside_batch, dim3(grid), dim3(64), 0, st, S, n, px, py, pz, in, c);
+}
+#endif
+
+#if GLOME_IN_PART(0)
 // ================================================================================================ host runtime
+static bool launch_render_flat(int key, const FlatLaunch& L, const DRenderArgs& A) {
+  return launch_flat_p1(key, L, A) || launch_flat_p2(key, L, A) || launch_flat_p3(key, L, A) || launch_flat_p4(key, L, A);
+}
+static bool launch_ss_flat(int key, const FlatLaunch& L, const DRenderArgs& A) { return launch_ss_flat_p5(key, L, A) || launch_ss_flat_p9(key, L, A); }
 struct glome_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -936,7 +1042,7 @@ static bool use_two_rows(const glome_scene* s, const glome_render_params* P, uin
   return scene_class(s) == CLS_BIH_TRI;  // (what bih_walk_asm walks: a two-row kernel has no row for bih_tri_packet's references)
 }
 
-static void launch_render(glome_scene* s, const DRenderArgs& A, const glome_render_params* P, int grid, size_t lds) {
+static bool launch_render(glome_scene* s, const DRenderArgs& A, const glome_render_params* P, int grid, size_t lds) {
   hipStream_t st = s->ctx->stream;
   bool faithful = P->faithful != 0, count = P->count_work != 0 || faithful;
   // A scene with a Refract material, traced deeper than the primary ray: the transmitted rays are not unit length
@@ -944,34 +1050,19 @@ static void launch_render(glome_scene* s, const DRenderArgs& A, const glome_rend
   // early-out's pruning is exact only for unit rays, so such a frame is traversed as the reference traverses (the flat
   // tier's faithful instance; the generic tier switches per ray, rt_generic.hpp).
   if (s->dev.tier == 0 && s->has_refract && P->maxdepth > 1) faithful = count = true;
-  if (s->dev.tier == 0) {
-    // lean kernel: legal when no secondary trace can do work and no material nests (Blend / AdditiveLayers)
-    bool full = s->has_nested_mats || (s->has_secondary_mats && P->maxdepth > 1);
-    dim3 g(grid), blk(64);
-    int cls = scene_class(s);
-#define GLOME_LAUNCH(F, C, U, K, B) hipLaunchKernelGGL((k_render_flat<F, C, U, K, B>), g, blk, lds, st, A, s->stack_cap, s->ctx->slot().d_ovf, s->ovf_cap)
-#define GLOME_BY_CLS(F, C, U)                                                   \
-    do {                                                                          \
-      if (cls == CLS_BIH_TRI) GLOME_LAUNCH(F, C, U, CLS_BIH_TRI, 1);              \
-      else if (cls == (CLS_BIH_SPHERE | CLS_PRIMS)) GLOME_LAUNCH(F, C, U, (CLS_BIH_SPHERE | CLS_PRIMS), 1); \
-      else if (cls == CLS_MESH) GLOME_LAUNCH(F, C, U, CLS_MESH, 1);               \
-      else if (cls == CLS_EVERY) GLOME_LAUNCH(F, C, U, CLS_EVERY, 2);  /* two waves per SIMD: S4 0.72 -> 0.52 ms; three spill */ \
-      else GLOME_LAUNCH(F, C, U, CLS_ALL, 1);                                     \
-    } while (0)
-    if (use_two_rows(s, P, A.total_waves * (uint32_t)A.nframes)) {
-      size_t lds2 = lds;  // sized by the caller for two rows
-      uint32_t* ov = s->ctx->slot().d_ovf;
-      hipLaunchKernelGGL((k_render_flat<false, false, false, CLS_BIH_TRI, 6, true>), g, blk, lds2, st, A, s->stack_cap, ov, s->ovf_cap);
-    } else
-    if (faithful) { if (full) GLOME_LAUNCH(true, true, true, CLS_EVERY, 1); else GLOME_LAUNCH(true, true, false, CLS_EVERY, 1); }
-    else if (count) { if (full) GLOME_LAUNCH(false, true, true, CLS_EVERY, 1); else GLOME_LAUNCH(false, true, false, CLS_EVERY, 1); }
-    else if (full) GLOME_BY_CLS(false, false, true);
-    else GLOME_BY_CLS(false, false, false);
-#undef GLOME_BY_CLS
-#undef GLOME_LAUNCH
-  } else {
-    hipLaunchKernelGGL(k_render_generic, dim3(grid), dim3(64), 0, st, A);
+  if (s->dev.tier != 0) { launch_render_generic(grid, st, A); return true; }
+  // lean kernel: legal when no secondary trace can do work and no material nests (Blend / AdditiveLayers)
+  const bool full = s->has_nested_mats || (s->has_secondary_mats && P->maxdepth > 1);
+  const FlatLaunch L{grid, lds, st, s->stack_cap, s->ctx->slot().d_ovf, s->ovf_cap};
+  int key;
+  if (use_two_rows(s, P, A.total_waves * (uint32_t)A.nframes)) key = render_flat_key(false, false, false, CLS_BIH_TRI, 6, true);  // (lds sized by the caller for two rows)
+  else if (faithful) key = render_flat_key(true, true, full, CLS_EVERY, 1, false);
+  else if (count) key = render_flat_key(false, true, full, CLS_EVERY, 1, false);
+  else {
+    const int cls = scene_class(s);
+    key = render_flat_key(false, false, full, cls, cls == CLS_EVERY ? 2 : 1, false);
   }
+  return launch_render_flat(key, L, A);
 }
 
 static int render_impl(glome_scene* s, const glome_camera* cam, const glome_light* lights, int nlights, const glome_render_params* P,
@@ -1063,19 +1154,20 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
     tgrid = (int)std::min<uint32_t>((uint32_t)tgrid, items);
     if (s->dev.tier == 0 && (rc = ensure_overflow(ctx, tgrid, 1, s->ovf_cap))) return rc;
     uint32_t* ov = ctx->slot().d_ovf;
-    dim3 g(tgrid), blk(64);
-    if (s->dev.tier != 0) hipLaunchKernelGGL(k_ss_frame_generic, g, blk, 0, ctx->stream, A);
+    const FlatLaunch L{tgrid, lds, ctx->stream, s->stack_cap, ov, s->ovf_cap};
+    const bool refr = s->has_refract && P->maxdepth > 1;
+    int key;
     // (four waves per SIMD: with 80 registers the sampler's own state spills, and every reload waits for the loads in flight;
     // a tree of a million nodes misses the caches often enough that a fifth wave pays for the spills of 96 registers:
     // S5 2.28 -> 2.12 ms per frame, S3 0.294 -> 0.310)
-    else if (two_rows && big_tree) hipLaunchKernelGGL((k_ss_frame_flat<false, CLS_BIH_TRI, 5, true>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
-    else if (two_rows) hipLaunchKernelGGL((k_ss_frame_flat<false, CLS_BIH_TRI, 4, true>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
-    else if (tri && !full) hipLaunchKernelGGL((k_ss_frame_flat<false, CLS_BIH_TRI>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
-    else if (tri && !(s->has_refract && P->maxdepth > 1)) hipLaunchKernelGGL((k_ss_frame_flat<true, CLS_BIH_TRI>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
+    if (two_rows) key = ss_flat_key(false, CLS_BIH_TRI, big_tree ? 5 : 4, true, false);
+    else if (tri && !full) key = ss_flat_key(false, CLS_BIH_TRI, 1, false, false);
+    else if (tri && !refr) key = ss_flat_key(true, CLS_BIH_TRI, 1, false, false);
     // (a Refract material traced deeper than the primary ray: the reference's own traversal, see launch_render)
-    else if (full && s->has_refract && P->maxdepth > 1) hipLaunchKernelGGL((k_ss_frame_flat<true, CLS_EVERY, 1, false, true>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
-    else if (!full) hipLaunchKernelGGL((k_ss_frame_flat<false, CLS_EVERY, 2>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
-    else hipLaunchKernelGGL((k_ss_frame_flat<true, CLS_EVERY, 2>), g, blk, lds, ctx->stream, A, s->stack_cap, ov, s->ovf_cap);
+    else if (full && refr) key = ss_flat_key(true, CLS_EVERY, 1, false, true);
+    else key = ss_flat_key(full, CLS_EVERY, 2, false, false);
+    if (s->dev.tier != 0) launch_ss_generic(tgrid, ctx->stream, A);
+    else if (!launch_ss_flat(key, L, A)) { ctx->err = "no sampler kernel instance for this scene class (build error)"; return GLOME_E_INVALID; }
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
   } else if (A.ntiles > 0) {
@@ -1089,7 +1181,7 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
     ev_start = e0; ev_stop = e1;
     const bool timed = stats || pooled;
     if (timed) HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
-    launch_render(s, A, P, grid, lds);
+    if (!launch_render(s, A, P, grid, lds)) { ctx->err = "no kernel instance for this scene class (build error)"; return GLOME_E_INVALID; }
     HIPCHK(ctx, hipGetLastError());
     if (timed) HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
   }
@@ -1178,10 +1270,10 @@ int glome_rayint_batch_dev(glome_scene* s, size_t n, const float* ox, const floa
     size_t lds = flat_lds_bytes(s->stack_cap);
     int grid = batch_grid(ctx, n, lds), rc;
     if ((rc = ensure_overflow(ctx, grid, 1, s->ovf_cap))) return rc;
-    hipLaunchKernelGGL((k_rayint_batch_flat<false>), dim3(grid), dim3(64), lds, ctx->stream, s->dev, n, R, H, s->stack_cap, ctx->slot().d_ovf, s->ovf_cap, ctx->slot().d_counters);
+    launch_rayint_batch_flat(FlatLaunch{grid, lds, ctx->stream, s->stack_cap, ctx->slot().d_ovf, s->ovf_cap}, s->dev, n, R, H, ctx->slot().d_counters);
   } else {
     if (int rcc = reset_counters(ctx)) return rcc;
-    hipLaunchKernelGGL(k_rayint_batch_generic, dim3(batch_grid(ctx, n, 0)), dim3(64), 0, ctx->stream, s->dev, n, R, H, ctx->slot().d_counters);
+    launch_rayint_batch_generic(batch_grid(ctx, n, 0), ctx->stream, s->dev, n, R, H, ctx->slot().d_counters);
   }
   HIPCHK(ctx, hipGetLastError());
   return 0;
@@ -1198,10 +1290,10 @@ int glome_shadow_batch_dev(glome_scene* s, size_t n, const float* ox, const floa
     size_t lds = flat_lds_bytes(s->stack_cap);
     int grid = batch_grid(ctx, n, lds), rc;
     if ((rc = ensure_overflow(ctx, grid, 1, s->ovf_cap))) return rc;
-    hipLaunchKernelGGL(k_shadow_batch_flat, dim3(grid), dim3(64), lds, ctx->stream, s->dev, n, R, occluded, s->stack_cap, ctx->slot().d_ovf, s->ovf_cap, ctx->slot().d_counters);
+    launch_shadow_batch_flat(FlatLaunch{grid, lds, ctx->stream, s->stack_cap, ctx->slot().d_ovf, s->ovf_cap}, s->dev, n, R, occluded, ctx->slot().d_counters);
   } else {
     if (int rcc = reset_counters(ctx)) return rcc;
-    hipLaunchKernelGGL(k_shadow_batch_generic, dim3(batch_grid(ctx, n, 0)), dim3(64), 0, ctx->stream, s->dev, n, R, occluded, ctx->slot().d_counters);
+    launch_shadow_batch_generic(batch_grid(ctx, n, 0), ctx->stream, s->dev, n, R, occluded, ctx->slot().d_counters);
   }
   HIPCHK(ctx, hipGetLastError());
   return 0;
@@ -1279,7 +1371,7 @@ int glome_inside_batch(glome_scene* s, size_t n, const float* px, const float* p
   uint8_t* din = st.in<uint8_t>(nullptr, n);
   if (!dx || !dy || !dz || !din) { ctx->err = "staging allocation failed"; return GLOME_E_HIP; }
   if (int rcc = reset_counters(ctx)) return rcc;
-  hipLaunchKernelGGL(k_inside_batch, dim3(batch_grid(ctx, n, 0)), dim3(64), 0, ctx->stream, s->dev, n, dx, dy, dz, din, ctx->slot().d_counters);
+  launch_inside_batch(batch_grid(ctx, n, 0), ctx->stream, s->dev, n, dx, dy, dz, din, ctx->slot().d_counters);
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   int rc = check_device_error(ctx);
@@ -1582,3 +1674,4 @@ int glome_render_multi(glome_scene* const* scenes, int n, const glome_camera* ca
   glome_multi_destroy(m);
   return rc;
 }
+#endif  // GLOME_IN_PART(0)

@@ -14,6 +14,6 @@ trap 'cp /tmp/libhostsim_keep.so tests/hostsim/libhostsim.so; cp /tmp/liboracle_
 (cd oracle && g++ $san -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -pthread -shared -o liboracle.so oracle_capi.cpp)
 mkdir -p build_old
 g++ $san -std=c++17 -fPIC -Wall -Iinclude -c glome_amd/csrc/capi_host.cpp -o /tmp/capi_host_san.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build_old/libglome_san.so /tmp/capi_host_san.o glome_amd/csrc/glome_device.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build_old/libglome_san.so /tmp/capi_host_san.o glome_amd/csrc/obj/glome_device_p*.o
 GLOME_DEBUG_LIB=build_old/libglome_san.so LD_PRELOAD=$pre ASAN_OPTIONS=detect_leaks=0 python -m pytest tests/test_host_builder.py tests/test_show_format.py tests/test_nff.py -x -q
 LD_PRELOAD=$pre ASAN_OPTIONS=detect_leaks=0 python -m pytest tests/test_hostsim_parity.py tests/test_golden.py tests/test_oracle_kat.py tests/test_np_crosscheck.py tests/test_nff.py tests/test_show_format.py -x -q
