@@ -558,13 +558,16 @@ __global__ void k_tiles_blit_packed(const DTile* tiles, int ntiles, int width, c
 
 // ------------------------------------------------------------------------------------------------ kernel instances by part
 // Every instance the host runtime can ask for, listed once; the part that holds an instance defines the launcher that knows it.
+#ifndef GLOME_FLAG_LB
+#define GLOME_FLAG_LB 6  // waves per SIMD of the flagship instance (two stack rows, every ray a packet)
+#endif
 struct FlatLaunch { int grid; size_t lds; hipStream_t st; int stack_cap; uint32_t* ovf; int ovf_cap; };
 constexpr int render_flat_key(bool F, bool C, bool U, int CLS, int LB, bool TWO) { return (F ? 1 : 0) | (C ? 2 : 0) | (U ? 4 : 0) | (TWO ? 8 : 0) | (LB << 4) | (CLS << 8); }
 constexpr int ss_flat_key(bool U, int CLS, int LB, bool TWO, bool F) { return (F ? 1 : 0) | (U ? 4 : 0) | (TWO ? 8 : 0) | (LB << 4) | (CLS << 8); }
 // k_render_flat<FAITHFUL, COUNT, FULL, CLS, LB, TWO_ROWS>
 #define GLOME_RENDER_FLAT_P1(X) /* production, lean */                                                                      \
   X(false, false, false, CLS_BIH_TRI, 1, false) X(false, false, false, (CLS_BIH_SPHERE | CLS_PRIMS), 1, false) X(false, false, false, CLS_MESH, 1, false) \
-  X(false, false, false, CLS_ALL, 1, false) X(false, false, false, CLS_BIH_TRI, 6, true)
+  X(false, false, false, CLS_ALL, 1, false) X(false, false, false, CLS_BIH_TRI, GLOME_FLAG_LB, true)
 #define GLOME_RENDER_FLAT_P2(X) /* production, full (secondary rays, nested materials) */                                   \
   X(false, false, true, CLS_BIH_TRI, 1, false) X(false, false, true, (CLS_BIH_SPHERE | CLS_PRIMS), 1, false) X(false, false, true, CLS_MESH, 1, false) \
   X(false, false, true, CLS_ALL, 1, false)
@@ -947,7 +950,7 @@ glome_scene* glome_scene_commit(glome_ctx* ctx, glome_sb* sb, int32_t root) {
   int need = std::max(F.max_bih_depth, F.max_mesh_depth);
   // LDS holds up to kLdsStack entries per lane (LDS per wave bounds occupancy); a deeper tree keeps its correctness
   // through the global overflow columns.
-  constexpr int kLdsStack = 12;
+  constexpr int kLdsStack = kAsmLdsCap;
   int lds_cap = getenv("GLOME_DEBUG_STACK_CAP") ? atoi(getenv("GLOME_DEBUG_STACK_CAP")) : kLdsStack;
   int total = std::min(kFlatStack, std::max(4, need));
   s->stack_cap = std::max(4, std::min(lds_cap, total));
@@ -1055,7 +1058,7 @@ static bool launch_render(glome_scene* s, const DRenderArgs& A, const glome_rend
   const bool full = s->has_nested_mats || (s->has_secondary_mats && P->maxdepth > 1);
   const FlatLaunch L{grid, lds, st, s->stack_cap, s->ctx->slot().d_ovf, s->ovf_cap};
   int key;
-  if (use_two_rows(s, P, A.total_waves * (uint32_t)A.nframes)) key = render_flat_key(false, false, false, CLS_BIH_TRI, 6, true);  // (lds sized by the caller for two rows)
+  if (use_two_rows(s, P, A.total_waves * (uint32_t)A.nframes)) key = render_flat_key(false, false, false, CLS_BIH_TRI, GLOME_FLAG_LB, true);  // (lds sized by the caller for two rows)
   else if (faithful) key = render_flat_key(true, true, full, CLS_EVERY, 1, false);
   else if (count) key = render_flat_key(false, true, full, CLS_EVERY, 1, false);
   else {
@@ -1173,7 +1176,7 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
   } else if (A.ntiles > 0) {
     const bool two_rows = use_two_rows(s, P, A.total_waves * (uint32_t)nframes);
     size_t lds = s->dev.tier == 0 ? flat_lds_bytes(s->stack_cap, two_rows) : 0;
-    int grid = persistent_grid(ctx, lds, A.total_waves * (uint32_t)nframes, two_rows ? 24 : 32, grid_floor(s));
+    int grid = persistent_grid(ctx, lds, A.total_waves * (uint32_t)nframes, two_rows ? 4 * GLOME_FLAG_LB : 32, grid_floor(s));
     if (s->dev.tier == 0 && (rc = ensure_overflow(ctx, grid, 1, s->ovf_cap))) return rc;
     bool pooled = ctx->timing && (ctx->timing_seen++ % ctx->timing_stride) == 0 && ctx->pool_used + 2 <= (int)ctx->pool.size();
     hipEvent_t e0 = pooled ? ctx->pool[ctx->pool_used] : ctx->ev0, e1 = pooled ? ctx->pool[ctx->pool_used + 1] : ctx->ev1;

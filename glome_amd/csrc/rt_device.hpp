@@ -647,7 +647,10 @@ GD bool bih_tri(const DScene& S, uint32_t hdr, const Ray& r, float d, STK& stk, 
 // `valid`: the lane holds a ray.  All lanes of the wave must make this call together.
 // The packet loop proper.  Every branch in it is wave-uniform (the per-lane decisions are selects), and it takes and
 // returns everything by value, so it can be compiled as a function of its own with plain scalar control flow.
-constexpr int kAsmLdsCap = 12;  // entries of the LDS part of the flat tier's stack: the hand-written walk is instantiated for it
+#ifndef GLOME_LDS_STACK
+#define GLOME_LDS_STACK 12
+#endif
+constexpr int kAsmLdsCap = GLOME_LDS_STACK;  // entries of the LDS part of the flat tier's stack: the hand-written walk is instantiated for it
 struct PacketResult { float best_t; uint32_t best_rec; uint32_t occ_lo, occ_hi, n_bih, n_prim; };
 template <int MODE, bool COUNT, int LEAFK, class STK>
 GD PacketResult bih_tri_packet(const F4* nodes, const F4* tris, uint32_t ref, uint32_t delta, uint32_t fwdbits, uint32_t am_lo, uint32_t am_hi,

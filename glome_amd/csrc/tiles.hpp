@@ -25,14 +25,17 @@ inline uint32_t tile_waves(int w, int h) {
   return nbx * nby + (rest + 63) / 64;
 }
 // Who owns tile k of a frame shared by `world` ranks.  Plain round robin (share_pct 0 or 100): rank k mod world.  With
-// rank0_share_pct in 1..99 rank 0 -- the rank that also receives and blits every frame -- owns that percentage of a fair
-// share and the others split the rest evenly: a repeating pattern of s0 + (world - 1) * 10 slots, s0 = pct / 10 rounded,
-// each rank's slots spread evenly over the period (largest remaining deficit first), so neighbouring tiles still go to
-// different ranks.  Every rank computes the same pattern from (world, pct).
+// rank0_share_pct in 1..99 rank 0 -- the rank that also receives and blits every frame -- gets that WEIGHT, in percent of
+// ONE other rank's: rank 0 owns pct / (pct + 100 * (world - 1)) of the tiles, every other rank 100 / (pct + 100 * (world - 1)).
+// The pattern repeats with period (pct + 100 * (world - 1)) / gcd(pct, 100) slots (pct 80, two ranks: 4 + 5 = 9), each rank's
+// slots spread evenly over the period (largest remaining deficit first), so neighbouring tiles still go to different ranks.
+// Every rank computes the same pattern from (world, pct); every percent is a different layout.
 inline std::vector<int> shard_pattern(int world, int share_pct) {
   std::vector<int> pat;
   if (world <= 1 || share_pct <= 0 || share_pct >= 100) { for (int r = 0; r < std::max(world, 1); r++) pat.push_back(r); return pat; }
-  const int s = 10, s0 = std::max(1, (s * share_pct + 50) / 100), period = s0 + (world - 1) * s;
+  int g = share_pct, h = 100;
+  while (h) { const int t = g % h; g = h; h = t; }
+  const int s = 100 / g, s0 = share_pct / g, period = s0 + (world - 1) * s;
   std::vector<long> given((size_t)world, 0);
   for (int j = 0; j < period; j++) {
     int best = 0; long bestd = -(1L << 60);

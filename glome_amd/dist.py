@@ -53,8 +53,11 @@ def _clone_params(p, **kw):
     return q
 
 
-# rank 0's share of a fair share of the tiles, by ranks (renderTile mode; measured, profiles/r02_g_shard_share.log)
-RANK0_SHARE_PCT = {1: 0, 2: 85, 3: 78, 4: 70, 5: 68, 6: 67, 7: 66, 8: 65}  # (2, 4, 8 measured; the others in between)
+# rank 0's weight in percent of one other rank's (glome_render_params.rank0_share_pct), by ranks.  renderTile mode; where rank
+# 0's and another rank's sustained frame periods met in the one-GPU rehearsal (tools/shard_share.py,
+# profiles/r02_g_shard_share.log: until round 3 the pattern was quantised to tens, so 2 ranks ran at 90 where 80 is the meeting
+# point, and 8 ranks at 70)
+RANK0_SHARE_PCT = {1: 0, 2: 80, 3: 75, 4: 70, 5: 70, 6: 70, 7: 70, 8: 70}  # (2, 4, 8 measured; the others in between)
 
 
 class ShardPlan:
@@ -169,7 +172,7 @@ class ShardedFrame:
         # rank 0 also receives and blits every frame: it owns less than a fair share of the tiles (glome_render_params.rank0_share_pct;
         # the defaults are where rank 0's and another rank's sustained frame periods met on one GPU, tools/shard_share.py)
         if rank0_share_pct is None:
-            rank0_share_pct = RANK0_SHARE_PCT.get(world, 65) if params.mode == 0 else 0
+            rank0_share_pct = RANK0_SHARE_PCT.get(world, 70) if params.mode == 0 else 0
         params = _clone_params(params, rank0_share_pct=int(rank0_share_pct))
         self.rank0_share_pct = int(rank0_share_pct)
         # renderTile's pixels do not depend on the tile map (the adaptive sampler's do, Q21): the shard unit is then a 64x64

@@ -225,11 +225,12 @@ typedef struct glome_render_params {
   int32_t faithful;      /* 1: BIH traversal without ordered early-out, exactly as Bih.hs:332-368 visits nodes */
   int32_t count_work;    /* 1: count node visits / primitive tests (slower; implied by faithful).  The generic
                             tier always counts and always traverses with early-out. */
-  int32_t rank0_share_pct; /* shards of tile_stride ranks: 0 (or 100) = tile k belongs to rank k mod tile_stride; 1..99 = rank
-                            0, which also receives and blits every frame, owns this percentage of a fair share and the other
-                            ranks split the rest evenly (an evenly interleaved repeating pattern every rank derives from
-                            (tile_stride, percentage); parMap over tiles, Glome.hs:385, has no such notion -- a tile is a
-                            tile whoever renders it) */
+  int32_t rank0_share_pct; /* shards of tile_stride ranks: 0 (or 100) = tile k belongs to rank k mod tile_stride; 1..99 = the
+                            weight of rank 0, which also receives and blits every frame, in percent of one other rank's: rank
+                            0 owns pct / (pct + 100 (tile_stride - 1)) of the tiles, the others split the rest evenly (an
+                            evenly interleaved repeating pattern every rank derives from (tile_stride, percentage), every
+                            percent a different one; parMap over tiles, Glome.hs:385, has no such notion -- a tile is a tile
+                            whoever renders it) */
 } glome_render_params;
 void glome_render_params_default(glome_render_params*);
 typedef struct glome_stats {

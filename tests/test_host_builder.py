@@ -160,9 +160,9 @@ def test_no_gpu_means_loud_failure_not_fallback(built):
 
 @pytest.mark.parametrize("world,pct", [(2, 90), (3, 70), (4, 75), (8, 60), (8, 35), (5, 0), (8, 100)])
 def test_weighted_shards_partition_the_frame(built, world, pct):
-    """glome_render_params.rank0_share_pct: every tile of the frame belongs to exactly one rank, rank 0 owns about the stated
-    percentage of a fair share, the other ranks' shares differ by a few tiles at most, and no rank owns long runs of
-    neighbouring tiles (the pattern interleaves)."""
+    """glome_render_params.rank0_share_pct: every tile of the frame belongs to exactly one rank, rank 0's share is its stated
+    weight (percent of one other rank's), the other ranks' shares differ by a few tiles at most, and no rank owns long runs
+    of neighbouring tiles (the pattern interleaves)."""
     from glome_amd import dist
     P = api.render_params(width=1920, height=1080, blocksize=64, rank0_share_pct=pct)
     whole = dist.owned_layout(api.render_params(width=1920, height=1080, blocksize=64), 0, 1)
@@ -182,8 +182,20 @@ def test_weighted_shards_partition_the_frame(built, world, pct):
         assert order == [k % world for k in range(len(whole))]  # plain round robin, as before
     else:
         want0 = len(whole) * (pct / 100.0) / (pct / 100.0 + world - 1)
-        assert abs(counts[0] - want0) <= 0.08 * fair + 2, (counts, want0)
+        assert abs(counts[0] - want0) <= 2, (counts, want0)
         assert max(counts[1:]) - min(counts[1:]) <= 2, counts
         order = [seen[(int(x), int(y))] for x, y, _, _, _ in whole]
         runs = max(len(list(g)) for _, g in __import__("itertools").groupby(order))
         assert runs <= 2, runs
+
+
+def test_every_share_percent_is_its_own_layout(built):
+    """the weight is honoured at percent granularity (until round 3 it was quantised to tens: 65..70 were one layout)"""
+    from glome_amd import dist
+    n0 = []
+    for pct in (64, 65, 66, 67, 68, 70, 85, 90, 95):
+        P = api.render_params(width=3840, height=2160, blocksize=64, rank0_share_pct=pct)
+        n0.append(len(dist.owned_layout(P, 0, 8)))
+    assert n0 == sorted(n0) and len(set(n0)) == len(n0), n0
+    lay = [dist.owned_layout(api.render_params(width=1920, height=1080, blocksize=64, rank0_share_pct=pct), 0, 2).tolist() for pct in (85, 90)]
+    assert lay[0] != lay[1]
