@@ -17,11 +17,14 @@ struct FlatScene {
   std::vector<F4> spheres, tris, trinorms, boxes, planes, discs, quadrics, xfms, bihhdr, bihnodes, meshhdr, meshnodes, mtris, mats, wlights;
   std::vector<U4> mtrimeta, entries;
   std::vector<uint32_t> matkids;
+  std::vector<float> tripairs;  // pair record k = triangles k and k + 1 interleaved (bih_packet_asm.hpp); flat tier only
+  std::vector<F4> pknodes;      // the packet walk's copy of the triangle BIHs' branch nodes: same slots as bihnodes, child references in its own form
   uint32_t root_rec = 0;
   uint32_t tier = 1;
   int nesting_depth = 0, max_bih_depth = 0, max_mesh_depth = 0;
   int64_t n_other_prims = 0;
   std::string why_generic;  // why the flat tier was not chosen
+  bool pk_all = true;       // every triangle BIH has the packet walk's node form (emit_bih)
 };
 
 inline float f32(double d) { return (float)d; }
@@ -57,6 +60,7 @@ class Flattener {
     if (F.tier == 0 && F.max_bih_depth > kFlatStack) { F.tier = 1; F.why_generic = "BIH deeper than the LDS stack"; }
     if (F.tier == 0 && F.max_mesh_depth > kFlatStack) { F.tier = 1; F.why_generic = "Mesh BVH deeper than the LDS stack"; }
     if (F.tier != 0) F.entries.clear();
+    if (F.tier == 0) emit_pairs();
     // the generic tier walks BIHs / Mesh BVHs with a fixed scratch stack per level: a deeper tree is refused, not truncated
     if (F.tier != 0 && F.max_mesh_depth > kGenericStack)
       throw limit_error("Mesh tree deeper than the device traversal stack (" + std::to_string(F.max_mesh_depth) + " > " + std::to_string(kGenericStack) + ")");
@@ -70,6 +74,26 @@ class Flattener {
 
   static bool is_prim(int k) { return k >= K_SPHERE && k <= K_CONE; }
 
+  // The packet walk tests a leaf's triangles two at a time: record k holds triangles k and k + 1 (leaf order), every component
+  // of p1, e1, e2 as an (A, B) pair -- p1x p1y p1z e1x e1y e1z e2x e2y e2z, 18 floats -- then the number of triangles of k's leaf
+  // from k on (emit_bih fills it in; what the walk's loop counts down) and a pad word: kPairWords words.  A leaf's odd last
+  // triangle is read as a pair whose B half belongs to whatever comes next and is ignored (the last record of the pool repeats
+  // its own triangle).
+  void emit_pairs() {
+    const size_t n = F.tris.size() / 3;
+    F.tripairs.resize(n * kPairWords, 0.0f);
+    for (size_t k = 0; k < n; k++) {
+      const size_t b = k + 1 < n ? k + 1 : k;
+      float* r = &F.tripairs[k * kPairWords];
+      for (int w = 0; w < 3; w++) {  // word w of a triangle record: (p1, .) (e1, .) (e2, .)
+        const F4 &A = F.tris[3 * k + w], &B = F.tris[3 * b + w];
+        r[6 * w + 0] = A.x; r[6 * w + 1] = B.x; r[6 * w + 2] = A.y; r[6 * w + 3] = B.y; r[6 * w + 4] = A.z; r[6 * w + 5] = B.z;
+      }
+      r[18] = as_float_bits(k < pair_left.size() ? pair_left[k] : 1u);
+    }
+  }
+  std::vector<uint32_t> pair_left;  // per triangle of `tris`: triangles of its BIH leaf from it on (1 outside a triangle BIH)
+
   void pad() {  // never hand a null pool to a kernel
     auto p4 = [](std::vector<F4>& v) { if (v.empty()) v.push_back(F4{0, 0, 0, 0}); };
     p4(F.spheres); p4(F.tris); p4(F.trinorms); p4(F.boxes); p4(F.planes); p4(F.discs); p4(F.quadrics); p4(F.xfms);
@@ -77,6 +101,8 @@ class Flattener {
     if (F.mtrimeta.empty()) F.mtrimeta.push_back(U4{0, 0, 0, 0});
     if (F.entries.empty()) F.entries.push_back(U4{0, 0, 0, 0});
     if (F.matkids.empty()) F.matkids.push_back(0);
+    if (F.tripairs.empty()) F.tripairs.assign(18, 0.0f);
+    if (F.pknodes.size() < F.bihnodes.size()) F.pknodes.resize(F.bihnodes.size(), F4{0, 0, 0, 0});
   }
 
   void emit_materials() {
@@ -422,9 +448,12 @@ class Flattener {
     }
     F.bihnodes.resize(base + std::max<uint32_t>(nslots, 1u));
     if (base + nslots >= BREF_FIRST_LIMIT) throw limit_error("too many BIH nodes");
+    bool pk = cls == BC_TRI && base + nslots < (1u << 27);  // (a node's byte offset is a reference: 31 bits)
+    F.pknodes.resize(F.bihnodes.size(), F4{0, 0, 0, 0});
     // pass 1: leaves -- emit the items fresh (no memo) so records and pool entries are consecutive, and build the
     // child reference that describes each leaf (rt_device.hpp: BREF_*)
     std::vector<uint32_t> ref(T.nodes.size(), 0);
+    std::vector<uint32_t> pkleaf(T.nodes.size(), 3u);  // a leaf as the packet walk refers to it: byte offset of its first pair record | 3
     uint32_t delta = 0;
     bool have_delta = false;
     for (size_t k = 0; k < T.nodes.size(); k++) {
@@ -453,9 +482,17 @@ class Flattener {
         if (have_delta && dl != delta) throw scene_error("internal: BIH leaf pools are not contiguous");
         delta = dl; have_delta = true;
       }
+      if (cls == BC_TRI && count) {
+        if ((uint64_t)(first_prim + count) * kPairWords * 4 >= (1ull << 31)) pk = false;  // (a pair record's byte offset is a reference)
+        pkleaf[k] = first_prim * (uint32_t)(kPairWords * 4) | 3u;
+        if (pair_left.size() < (size_t)first_prim + count) pair_left.resize((size_t)first_prim + count, 1u);
+        for (uint32_t q = 0; q < count; q++) pair_left[first_prim + q] = count - q;
+      }
       if (count == 0) ref[k] = BREF_LEAF_BIT;
       else if (count <= 6) ref[k] = BREF_LEAF_BIT | (count << 26) | first_rec;
-      else { F.bihnodes[base + slot[k]] = F4{0.0f, 0.0f, as_float_bits(count), as_float_bits(first_rec)}; ref[k] = BREF_LEAF_BIT | (7u << 26) | (base + slot[k]); }
+      else {
+        F.bihnodes[base + slot[k]] = F4{0.0f, 0.0f, as_float_bits(count), as_float_bits(first_rec)}; ref[k] = BREF_LEAF_BIT | (7u << 26) | (base + slot[k]);
+      }
     }
     // pass 2: branches
     for (size_t k = 0; k < T.nodes.size(); k++) {
@@ -467,10 +504,21 @@ class Flattener {
       const float inf = std::numeric_limits<float>::infinity();
       float ls = ref[bn.left] == BREF_LEAF_BIT ? -inf : round_up(bn.lsplit), rs = ref[bn.right] == BREF_LEAF_BIT ? inf : round_down(bn.rsplit);
       F.bihnodes[base + slot[k]] = F4{ls, rs, as_float_bits((uint32_t)bn.axis | (ref[bn.left] << 2)), as_float_bits(ref[bn.right])};
+      // The hand-written packet walk (bih_packet_asm.hpp) reads its own copy: a branch child is referred to by its BYTE OFFSET
+      // in this pool with the child's axis in the two low bits (scalar loads ignore them), a leaf child by the byte offset of
+      // its first pair record (tripairs) with both low bits set -- the step's code is picked, the near child's node asked for
+      // and a leaf's triangles fetched without a shift, a mask or a multiplication.  (An empty leaf is 3: never entered.)
+      if (pk) {
+        auto pkref = [&](int c) { return T.nodes[c].leaf ? pkleaf[c] : (((base + slot[c]) << 4) | (uint32_t)T.nodes[c].axis); };
+        F.pknodes[base + slot[k]] = F4{ls, rs, as_float_bits(pkref(bn.left)), as_float_bits(pkref(bn.right))};
+      }
     }
     F.bihhdr[3 * hdr] = mk4u(round_down(T.bb.lo.x), round_down(T.bb.lo.y), round_down(T.bb.lo.z), ref[0]);
     F.bihhdr[3 * hdr + 1] = mk4u(round_up(T.bb.hi.x), round_up(T.bb.hi.y), round_up(T.bb.hi.z), cls);
-    F.bihhdr[3 * hdr + 2] = F4{as_float_bits(delta), 0, 0, 0};
+    if (cls == BC_TRI) F.pk_all = F.pk_all && pk;
+    // (y: the root in the packet walk's form, z: 1 when this tree has that form -- triangle leaves, byte offsets that fit a reference)
+    const uint32_t pkroot = (pk && !T.nodes.empty() && !T.nodes[0].leaf) ? (((base + slot[0]) << 4) | (uint32_t)T.nodes[0].axis) : 0u;
+    F.bihhdr[3 * hdr + 2] = F4{as_float_bits(delta), as_float_bits(pkroot), as_float_bits(pk ? 1u : 0u), 0};
     return U4{R_BIH, hdr, 0, (uint32_t)n.uid};
   }
 

@@ -250,6 +250,7 @@ template <bool FAITHFUL, bool COUNT, bool FULL, int CLS, int LB = 1, bool TWO_RO
 __global__ void __launch_bounds__(64, LB) k_render_flat(DRenderArgs A, int stack_cap, uint32_t* ovf, int ovf_cap) {
   extern __shared__ uint32_t lds[];
   FlatTier<FAITHFUL, COUNT, FULL, CLS> T{A.S, A.lights, A.nlights, lane_stack<TWO_ROWS>(lds, stack_cap, ovf, ovf_cap), Cnt()};
+  T.stk.dbg = A.counters->dbg;
   render_loop(A, T);
   if (A.want_counters) flush_counters(A.counters, T.cnt, T.err);
   else if ((CLS & CLS_CSG) && __builtin_amdgcn_ballot_w64(T.err != 0) && (threadIdx.x & 63) == 0) atomicOr(&A.counters->error, 1u);
@@ -689,6 +690,7 @@ struct glome_scene {
   bool has_secondary_mats = false, has_nested_mats = false;
   bool has_refract = false;  // a Refract material: its transmitted rays are not unit length (Shader.hs:141) -- see launch_render
   int cls_mask = CLS_ALL;  // which entry classes the flat root program contains
+  bool pk_all = false;     // every triangle BIH of the scene has the hand-written walk's node form (flatten.hpp emit_bih)
 };
 
 static std::string g_global_error;
@@ -843,6 +845,13 @@ int glome_ctx_synchronize(glome_ctx* c) {
     if (sl.launched) { sl.launched = false; int r = poll_device_error(c, sl); if (r) rc = r; }
   return rc;
 }
+int glome_ctx_debug_words(glome_ctx* c, uint64_t* out16) {  // DCounters::dbg of the current slot (measurement builds write them)
+  if (!c || !out16) return GLOME_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(out16, c->slot().d_counters->dbg, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return 0;
+}
 int glome_ctx_device_info(glome_ctx* c, char* name, int cap, int* cu_count, int* warp_size) {
   if (!c) return GLOME_E_INVALID;
   if (name && cap > 0) snprintf(name, cap, "%s (%s)", c->prop.name, c->prop.gcnArchName);
@@ -914,10 +923,10 @@ glome_scene* glome_scene_commit(glome_ctx* ctx, glome_sb* sb, int32_t root) {
   int rc = 0;
   DScene& D = s->dev;
   rc |= upload(s, F.recs, &D.recs);
-  rc |= upload(s, F.spheres, &D.spheres); rc |= upload(s, F.tris, &D.tris); rc |= upload(s, F.trinorms, &D.trinorms);
+  rc |= upload(s, F.spheres, &D.spheres); rc |= upload(s, F.tris, &D.tris); rc |= upload(s, F.tripairs, &D.tripairs); rc |= upload(s, F.trinorms, &D.trinorms);
   rc |= upload(s, F.boxes, &D.boxes); rc |= upload(s, F.planes, &D.planes); rc |= upload(s, F.discs, &D.discs);
   rc |= upload(s, F.quadrics, &D.quadrics); rc |= upload(s, F.xfms, &D.xfms);
-  rc |= upload(s, F.bihhdr, &D.bihhdr); rc |= upload(s, F.bihnodes, &D.bihnodes);
+  rc |= upload(s, F.bihhdr, &D.bihhdr); rc |= upload(s, F.bihnodes, &D.bihnodes); rc |= upload(s, F.pknodes, &D.pknodes); D.pknodes_bytes = (uint32_t)(F.pknodes.size() * sizeof(F4));
   rc |= upload(s, F.meshhdr, &D.meshhdr); rc |= upload(s, F.meshnodes, &D.meshnodes); rc |= upload(s, F.mtris, &D.mtris);
   rc |= upload(s, F.mtrimeta, &D.mtrimeta); rc |= upload(s, F.mats, &D.mats); rc |= upload(s, F.wlights, &D.wlights); rc |= upload(s, F.matkids, &D.matkids);
   rc |= upload(s, F.entries, &D.entries);
@@ -947,6 +956,7 @@ glome_scene* glome_scene_commit(glome_ctx* ctx, glome_sb* sb, int32_t root) {
     }
     s->cls_mask = m;
   }
+  s->pk_all = F.pk_all;
   int need = std::max(F.max_bih_depth, F.max_mesh_depth);
   // LDS holds up to kLdsStack entries per lane (LDS per wave bounds occupancy); a deeper tree keeps its correctness
   // through the global overflow columns.
@@ -1041,7 +1051,7 @@ static bool use_two_rows(const glome_scene* s, const glome_render_params* P, uin
   // 16-wave instance (measured at 8 ranks: 0.040 against 0.047 ms per frame); from ~48k work items on the 24-wave one wins
   if (P->tile_stride != 1 && items < 48000u) return false;
   if (s->dev.tier != 0 || P->faithful || P->count_work) return false;
-  if (s->has_secondary_mats || s->has_nested_mats || s->stack_cap != kAsmLdsCap) return false;
+  if (s->has_secondary_mats || s->has_nested_mats || s->stack_cap != kAsmLdsCap || !s->pk_all) return false;
   return scene_class(s) == CLS_BIH_TRI;  // (what bih_walk_asm walks: a two-row kernel has no row for bih_tri_packet's references)
 }
 
@@ -1499,7 +1509,9 @@ struct Rccl {  // the five entry points the gather needs, resolved from librccl.
     static std::once_flag once;
     std::call_once(once, [] {
       void* h = nullptr;
-      for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+      // GLOME_DEBUG_RCCL_LIB: another library with the same entry points (tests/rcclstub: the RCCL branch exercised on one GPU)
+      if (const char* dbg = getenv("GLOME_DEBUG_RCCL_LIB")) h = dlopen(dbg, RTLD_NOW | RTLD_GLOBAL);
+      else for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
       if (!h) return;
       r.CommInitAll = (decltype(r.CommInitAll))dlsym(h, "ncclCommInitAll");
       r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
@@ -1574,7 +1586,9 @@ glome_multi* glome_multi_create(glome_scene* const* scenes, int n, const glome_r
   // transport
   bool distinct = true;
   for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) distinct &= scenes[i]->ctx->device != scenes[j]->ctx->device;
-  if (use_rccl && n > 1 && distinct && Rccl::get().ok) {
+  // (GLOME_DEBUG_RCCL_SAME_DEVICE lifts the distinct-device condition -- real RCCL refuses two ranks on one device -- for the
+  // stubbed transport of the one-GPU test)
+  if (use_rccl && n > 1 && (distinct || getenv("GLOME_DEBUG_RCCL_SAME_DEVICE")) && Rccl::get().ok) {
     std::vector<int> devs;
     for (int i = 0; i < n; i++) devs.push_back(scenes[i]->ctx->device);
     m->comms.assign(n, nullptr);
@@ -1629,8 +1643,13 @@ int glome_multi_render(glome_multi* m, const glome_camera* cams, int nframes, co
   if (n > 1 && m->rccl) {
     Rccl& R = Rccl::get();
     int rc = R.GroupStart();
+    // rank i's Send is ordered on ITS stream behind its render and in front of its next one, so a payload is never rewritten
+    // before it has left; rank 0's Recvs are ordered on its stream in front of the blit.  (The device of a call's communicator
+    // is made current first: RCCL releases before 2.18 want that.)
     for (int i = 1; i < n && rc == 0; i++) {
+      MHIP(m, hipSetDevice(m->scenes[i]->ctx->device));
       rc = R.Send(m->payload[i], words, kNcclUint32, 0, m->comms[i], m->scenes[i]->ctx->stream);
+      MHIP(m, hipSetDevice(c0->device));
       if (rc == 0) rc = R.Recv(m->gathered + (size_t)i * slab, words, kNcclUint32, i, m->comms[0], c0->stream);
     }
     int rc2 = R.GroupEnd();

@@ -403,6 +403,7 @@ struct LaneStack {
   //   reads them back on re-entry, so no C++ variable ever carries them.  push_dump / pop_dump are the C++ steps' view.
   bool has_ref_row;  // false in kernels with two LDS rows per entry (lane_stack<true>): only bih_walk_asm runs there
   uint32_t* dump;    // this lane's column of the dump block: [3][64] words per wave
+  unsigned long long* dbg = nullptr;  // DCounters::dbg in the render kernels (read by the GLOME_PKW_STAMPS measurement build only)
   GD void push2(int sp, float a, float b) {
     if (__builtin_expect(sp < cap, 1)) { nearv[sp * STRIDE] = a; farv[sp * STRIDE] = b; }
     else { uint32_t* o = ovf + (size_t)(sp - cap) * 3 * STRIDE; __builtin_nontemporal_store(as_u(a), o + STRIDE); __builtin_nontemporal_store(as_u(b), o + 2 * STRIDE); }
@@ -736,11 +737,12 @@ GD PacketResult bih_tri_packet(const F4* nodes, const F4* tris, uint32_t ref, ui
 #include "bih_packet_asm.hpp"
 namespace glome {
 // The production packet walk: bih_walk_asm (hand-written, one instance per octant) with the C++ steps of bih_tri_packet for
-// what it declines -- a push or pop beyond the LDS part of the stack, a leaf of more than six triangles.  Same visits, same
-// results, same tie order as bih_tri_packet<MODE, false, 0>.
+// what it declines -- a push or pop beyond the LDS part of the stack.  Same visits, same results, same tie order as
+// bih_tri_packet<MODE, false, 0>.  `nodes` is the walk's own pool (DScene::pknodes) and `ref`, like every stack entry of this
+// walk, in its form: a branch = byte offset | axis, a leaf = byte offset of its first pair record | 3 (flatten.hpp emit_bih).
 template <int MODE>
-GD PacketResult bih_tri_packet_hw(const F4* nodes, const F4* tris, uint32_t ref, uint32_t delta, uint32_t fwdbits, LaneMask am, float nearv, float farv, V3 ro, V3 rd,
-                                  V3 rcp, float best_t, LaneStack& stk) {
+GD PacketResult bih_tri_packet_hw(const F4* nodes, uint32_t nbytes, const float* pairs, uint32_t ref, uint32_t delta, uint32_t fwdbits, LaneMask am, float nearv, float farv,
+                                  V3 ro, V3 rd, V3 rcp, float best_t, LaneStack& stk) {
   constexpr int CAP = kAsmLdsCap;
   ref = uni(ref); delta = uni(delta); fwdbits = uni(fwdbits); am = uni(am);
   Ray r; r.o = ro; r.d = rd;
@@ -750,7 +752,7 @@ GD PacketResult bih_tri_packet_hw(const F4* nodes, const F4* tris, uint32_t ref,
   const uint32_t lds_row = (uint32_t)(uintptr_t)stk.nearv;
   for (;;) {
     int st;
-#define GLOME_WALK(XF, YF, ZF) st = bih_walk_asm<MODE, XF, YF, ZF, CAP>(nodes, tris, delta, phase, ref, am, sp, nearv, farv, R.best_t, R.best_rec, occm, r.o, rcp, r.d, lds_row, stk.dump)
+#define GLOME_WALK(XF, YF, ZF) st = bih_walk_asm<MODE, XF, YF, ZF, CAP>(nodes, nbytes, pairs, phase, ref, am, sp, nearv, farv, R.best_t, R.best_rec, occm, r.o, rcp, r.d, lds_row, stk.dump)
     switch (fwdbits) {  // wave-uniform: one scalar jump per walk
       case 7: GLOME_WALK(true, true, true); break;
       case 6: GLOME_WALK(false, true, true); break;
@@ -766,9 +768,9 @@ GD PacketResult bih_tri_packet_hw(const F4* nodes, const F4* tris, uint32_t ref,
     if (st == PKW_DONE) break;
     ref = uni(ref); am = uni(am); sp = (int)uni((uint32_t)sp);
     if (st == PKW_PUSH_OVERFLOW) {  // one branch step of bih_tri_packet; its push goes to the overflow columns
-      F4 n = ld4u(nodes, ref);
-      const uint32_t w0 = uni(as_u(n.z)), right = uni(as_u(n.w));
-      const uint32_t axis = w0 & 3u, left = w0 >> 2;
+      F4 n = ld4u(nodes, ref >> 4);
+      const uint32_t left = uni(as_u(n.z)), right = uni(as_u(n.w));
+      const uint32_t axis = ref & 3u;
       float dl, dr;
       if (axis == 0) { dl = (n.x - r.o.x) * rcp.x; dr = (n.y - r.o.x) * rcp.x; }
       else if (axis == 1) { dl = (n.x - r.o.y) * rcp.y; dr = (n.y - r.o.y) * rcp.y; }
@@ -782,26 +784,9 @@ GD PacketResult bih_tri_packet_hw(const F4* nodes, const F4* tris, uint32_t ref,
       const bool g1 = m1 != 0;
       ref = g1 ? c1 : c2;
       am = g1 ? m1 : m2;
-      farv = g1 ? f1 : farv;
+      farv = g1 ? f1 : farv;  // (the walk only ever reads the lanes of its current mask)
       nearv = g1 ? nearv : n2;
       phase = am != 0 ? 0 : 1;
-    } else if (st == PKW_BIG_LEAF) {  // the leaf's extent is in its node
-      const F4 ln = ld4u(nodes, ref & BREF_FIRST);
-      const uint32_t count = uni(as_u(ln.z)), first = uni(as_u(ln.w));
-      for (uint32_t k = 0; k < count && am != 0; k++) {
-        F4 p0, p1, p2;
-        float t, b1, b2;
-        ld_tri_u(tris, first + delta + k, p0, p1, p2);
-        const bool hit = tri_test(p0, p1, p2, r, farv, t, b1, b2) && lane_of(am);
-        if (MODE == 2) { const LaneMask hm = wave_ballot(hit); occm |= hm; am &= ~hm; }
-        else {
-          const bool acc = hit && !(R.best_t < t);
-          R.best_t = acc ? t : R.best_t;
-          R.best_rec = acc ? first + k : R.best_rec;
-          farv = acc ? gminf(farv, t) : farv;
-        }
-      }
-      phase = 1;
     } else {  // PKW_POP_OVERFLOW: the top entry sits in the overflow columns
       sp--;
       stk.pop_dump(sp, ref, am, nearv, farv);
@@ -810,6 +795,8 @@ GD PacketResult bih_tri_packet_hw(const F4* nodes, const F4* tris, uint32_t ref,
       phase = am != 0 ? 0 : 1;
     }
   }
+  // the walk records a hit as the byte offset of the triangle's pair record: back to the record index the callers expect
+  if (R.best_rec != kNoRec) R.best_rec = pkw_triangle_of(R.best_rec) - delta;
   R.occ_lo = (uint32_t)occm; R.occ_hi = (uint32_t)(occm >> 32);
   return R;
 }
@@ -819,7 +806,10 @@ template <int MODE, bool COUNT, int LEAFK = 0, class STK>
 GD bool bih_tri_wave(const DScene& S, uint32_t hdr, const Ray& r, float d, bool valid, STK& stk, Cnt& cnt, float& best_t, uint32_t& best_rec) {
   hdr = uni(hdr);
   F4 h0 = ld4u(S.bihhdr, 3 * hdr), h1 = ld4u(S.bihhdr, 3 * hdr + 1);
-  const uint32_t delta = uni(as_u(ld4u(S.bihhdr, 3 * hdr + 2).x));
+  const F4 h2 = ld4u(S.bihhdr, 3 * hdr + 2);
+  const uint32_t delta = uni(as_u(h2.x));
+  const uint32_t pkroot = uni(as_u(h2.y)), has_pk = uni(as_u(h2.z));  // the root as the hand-written walk refers to it (flatten.hpp emit_bih)
+  (void)pkroot; (void)has_pk;  // (the host build has no hand-written walk)
   const uint32_t ref = uni(as_u(h0.w));
   const V3 rcp = v3(dir_rcp(r.d.x), dir_rcp(r.d.y), dir_rcp(r.d.z));
   float nearv, farv;
@@ -860,7 +850,7 @@ GD bool bih_tri_wave(const DScene& S, uint32_t hdr, const Ray& r, float d, bool 
     bool walked = false;
 #if defined(__HIPCC__)
     if constexpr (MODE != 0 && !COUNT && LEAFK == 0 && std::is_same<STK, LaneStack>::value) {
-      if (stk.cap == kAsmLdsCap) { R = bih_tri_packet_hw<MODE>(S.bihnodes, S.tris, ref, delta, fwdbits, am, nearv, farv, r.o, r.d, rcp, best_t, stk); walked = true; }
+      if (stk.cap == kAsmLdsCap && has_pk) { R = bih_tri_packet_hw<MODE>(S.pknodes, S.pknodes_bytes, S.tripairs, pkroot, delta, fwdbits, am, nearv, farv, r.o, r.d, rcp, best_t, stk); walked = true; }
     }
 #endif
     if (!walked) {

@@ -60,6 +60,8 @@ constexpr int kMaxTraceDepth = 4;  // maxdepth values the render kernels are ins
 constexpr int kMaxMatNest = 2;
 constexpr int kMaxBatchFrames = 8;  // frames one render launch can carry     // Blend / AdditiveLayers nesting the shader is instantiated for
 
+constexpr int kPairWords = 20;  // a pair record: 18 floats, the leaf's remaining count, one pad word (80 bytes)
+
 struct F4 { float x, y, z, w; };
 struct U4 { uint32_t x, y, z, w; };
 
@@ -67,6 +69,8 @@ struct DScene {
   const U4* recs;
   const F4* spheres;
   const F4* tris;
+  const float* tripairs;  // record k (kPairWords words) = triangles k and k + 1 of `tris`, every component of p1, e1, e2 as (A, B), then the
+                          // number of triangles of k's leaf from k on: the packet walk's pair tests (bih_packet_asm.hpp)
   const F4* trinorms;
   const F4* boxes;
   const F4* planes;
@@ -75,6 +79,9 @@ struct DScene {
   const F4* xfms;
   const F4* bihhdr;
   const F4* bihnodes;
+  const F4* pknodes;  // the hand-written packet walk's copy of the triangle BIHs' nodes (flatten.hpp emit_bih): a branch child = byte
+                      // offset | axis, a leaf child = byte offset of its first pair record | 3
+  uint32_t pknodes_bytes;
   const F4* meshhdr;
   const F4* meshnodes;
   const F4* mtris;
@@ -105,6 +112,8 @@ struct DCounters {  // device-side atomics, one block per launch slot
   unsigned int done_pad[31];
   unsigned int done;       // waves of the running launch that have left the queue (the last one resets the heads)
   unsigned int error;      // sticky: set when a device-side limit was hit (stack overflow guard, CSG cap); reset_counters stops short of it
+  unsigned int dbg_pad;
+  unsigned long long dbg[16];  // measurement builds only (GLOME_PKW_STAMPS: the packet walk's wait cycles by kind); glome_ctx_debug_words reads them
 };
 
 struct DRenderArgs {

@@ -71,6 +71,9 @@ int glome_ctx_timing_end(glome_ctx*, float* ms_out, int cap);
  * that runs ALONE wants (24 for the packet instances).  The reference has no such knob (GHC's +RTS -N is the nearest). */
 int glome_ctx_set_grid_per_cu(glome_ctx*, int waves_per_cu);
 int glome_ctx_device_info(glome_ctx*, char* name, int cap, int* cu_count, int* warp_size);
+/* debugging aid, no reference counterpart: 16 words a measurement build of the library accumulates on the device (the stock
+   build leaves them zero); synchronises the context's stream */
+int glome_ctx_debug_words(glome_ctx*, uint64_t* out16);
 
 /* ---- transforms: Xfm = forward 3x4 (12 doubles, row major) + inverse 3x4 (12 doubles) ---- */
 int glome_xfm_translate(const double v[3], double out[24]);                          /* Vec.hs:564-567 */

@@ -141,8 +141,17 @@ def compare_hits(got_t, ref_t, rtol=1e-4):
     return mism, (float(err.max()) if err.size else 0.0), err
 
 
+REL_FLOOR = 1e-3  # the floor of the true relative error below: a colour channel darker than this is compared absolutely (at 1e-7)
+
+
 def compare_images(got, ref, tol=1e-4):
-    """Per-pixel relative RGBA error vs the fp64 oracle: |got-ref| / max(1, |ref|)."""
+    """Per-pixel RGBA error vs the fp64 oracle, two ways:
+      max / p999 / frac_over / mean -- |got-ref| / max(1, |ref|): colours live in [0, 1], so this is an ABSOLUTE error;
+      rel_*                         -- |got-ref| / max(|ref|, REL_FLOOR): the north star's "1e-4 relative", true for every
+                                       channel brighter than 0.001 (1e-4 of a 0.01-bright pixel is 1e-6, near fp32's ulp there)."""
     g = got[..., :4].astype(np.float64); r = ref[..., :4]
-    e = (np.abs(g - r) / np.maximum(1.0, np.abs(r))).max(axis=-1)
-    return {"max": float(e.max()), "p999": float(np.quantile(e, 0.999)), "frac_over": float(np.mean(e > tol)), "mean": float(e.mean())}
+    d = np.abs(g - r)
+    e = (d / np.maximum(1.0, np.abs(r))).max(axis=-1)
+    rel = (d / np.maximum(REL_FLOOR, np.abs(r))).max(axis=-1)
+    return {"max": float(e.max()), "p999": float(np.quantile(e, 0.999)), "frac_over": float(np.mean(e > tol)), "mean": float(e.mean()),
+            "rel_max": float(rel.max()), "rel_p999": float(np.quantile(rel, 0.999)), "rel_frac_over": float(np.mean(rel > tol)), "rel_mean": float(rel.mean())}

@@ -78,9 +78,9 @@ void* hostsim_commit(glome_sb* sb, int root, char* errbuf, int cap) {
   } catch (std::exception& e) { snprintf(errbuf, cap, "%s", e.what()); delete s; return nullptr; }
   FlatScene& F = s->F;
   DScene& D = s->D;
-  D.recs = F.recs.data(); D.spheres = F.spheres.data(); D.tris = F.tris.data(); D.trinorms = F.trinorms.data(); D.boxes = F.boxes.data();
+  D.recs = F.recs.data(); D.spheres = F.spheres.data(); D.tris = F.tris.data(); D.tripairs = F.tripairs.data(); D.trinorms = F.trinorms.data(); D.boxes = F.boxes.data();
   D.planes = F.planes.data(); D.discs = F.discs.data(); D.quadrics = F.quadrics.data(); D.xfms = F.xfms.data(); D.bihhdr = F.bihhdr.data();
-  D.bihnodes = F.bihnodes.data(); D.meshhdr = F.meshhdr.data(); D.meshnodes = F.meshnodes.data(); D.mtris = F.mtris.data();
+  D.bihnodes = F.bihnodes.data(); D.pknodes = F.pknodes.data(); D.pknodes_bytes = (uint32_t)(F.pknodes.size() * sizeof(F4)); D.meshhdr = F.meshhdr.data(); D.meshnodes = F.meshnodes.data(); D.mtris = F.mtris.data();
   D.mtrimeta = F.mtrimeta.data(); D.mats = F.mats.data(); D.wlights = F.wlights.data(); D.matkids = F.matkids.data(); D.entries = F.entries.data();
   D.n_entries = F.tier == 0 ? (uint32_t)F.entries.size() : 0; D.root_rec = F.root_rec; D.tier = F.tier; D.n_mats = (uint32_t)sb_graph(sb).mats.size();
   return s;

@@ -833,6 +833,18 @@ def test_multi_gpu_c_abi_frames_equal_the_single_gpu_frames(gpu_ctx, n):
         c.close()
 
 
+@pytest.mark.gpu
+def test_rccl_branch_of_the_multi_gpu_entry_with_a_stub_transport():
+    """glome_multi_render's RCCL branch (one group of ncclSend / ncclRecv per call, on the ranks' own streams) needs distinct
+    devices and so never ran on a one-GPU box.  Here it runs against tests/rcclstub (send / recv pairs = stream-ordered device
+    copies; GLOME_DEBUG_RCCL_LIB, GLOME_DEBUG_RCCL_SAME_DEVICE): 2, 3 and 8 ranks, batches of four views and adaptive mode,
+    payload buffers reused over three calls -- every frame equals the single-context render bit for bit."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_stub_multi.py")], capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0 and "rccl stub transport ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
 # ------------------------------------------------------------------ edge cases: empty, tiny and ragged inputs, refused parameters
 def test_empty_and_tiny_inputs_through_the_c_abi(gpu_ctx):
     """An empty ray batch; a scene that is an empty group (every ray misses: transparent pixels at depth = infinity, Shader.hs:
