@@ -28,16 +28,16 @@
 //                it, so no per-lane address register can drift under a partial EXEC).
 //                At most one prefetch is ever in flight, and a fetch that was not prefetched (a far child entered alone, a
 //                popped entry, the root) is only issued behind an s_waitcnt, so two loads never race for one register set.
-//   triangles    TWO per test, any number per leaf: the leaf's triangles k and k + 1 come as one 80-byte pair record
-//                (DScene::tripairs: every component of p1, e1, e2 as (A, B) in an aligned scalar pair, then the number of
-//                triangles left in the leaf from k on; five of six leaves of the flagship tree hold exactly two triangles)
+//   triangles    TWO per test, any number per leaf: a leaf's triangles come as 80-byte pair records (DScene::tripairs,
+//                flatten.hpp emit_pairs: every component of p1, e1, e2 of two triangles as (A, B) in an aligned scalar pair,
+//                then the number of triangles left in the leaf; five of six leaves of the flagship tree hold exactly two)
 //                and the Moeller-Trumbore arithmetic runs on (A, B) register pairs with v_pk_add / v_pk_mul / v_pk_fma_f32
 //                -- per element the same IEEE operations in the same order as the compiler's tri_test, so results stay
 //                bit-identical to every other kernel instance.  The ray's origin and direction are read from three aligned
 //                register pairs ((ox, oy) (oz, dx) (dy, dz)) through op_sel, which broadcasts either half.  The rejection
 //                tests are two chains of v_cmpx, A's first (its update moves `far`, which B's last test reads: `nearest`,
 //                ties -> later item); a leaf's odd last triangle is a pair whose B half is computed and ignored.  A hit
-//                records the pair record's byte offset; the caller turns it back into a record index once per walk.
+//                records the triangle's record index, which the pair record carries.
 //   pop          7 scalar-type.
 //
 // What it declines goes back to the C++ loop for one step (status codes below): pushes and pops beyond the LDS part of the
@@ -63,7 +63,7 @@ namespace glome {
 // The block's scratch scalar registers: 40 consecutive ones from GLOME_PKW_BASE (a multiple of 4: the wide loads want aligned
 // destinations), K0 .. K39 below.
 //   K0..K3 node set A, K4..K7 node set B (lsplit, rsplit, left, right) | K8..K25 a pair record (p1x p1y p1z e1x e1y e1z e2x e2y
-//   e2z, each as (A, B)), K26 the triangles left in its leaf, K27 unused | K28 K29 a popped entry's mask, v_cmpx's other
+//   e2z, each as (A, B)), K26 the triangles left in its leaf, K27 the first one's record index | K28 K29 a popped entry's mask, v_cmpx's other
 //   destination | K30 K31 EXEC at entry | K32 the caller's m0 | K33 the second triangle's record | K34 K35 a leaf's lanes |
 //   K36..K39 buffer descriptor over the node pool
 #ifndef GLOME_PKW_BASE
@@ -379,6 +379,22 @@ constexpr uint32_t PKREF_LEAF = 3u;  // low bits of a reference in the walk's ow
   "  s_cbranch_scc1 L_leaf_%=\n"                                                                        \
   "  s_branch L_st" S "Z_%=\n"
 
+
+// Sensitivity experiments (measurement builds only, tools/build_variants.py): extra work of one kind per branch step or per
+// pair test, results unchanged -- what the frame time answers to is what bounds the walk.
+#if defined(GLOME_PKW_EXP_SALU)
+#define PKW_EXP_STEP "  s_mov_b32 s" K27 ", s" K27 "\n  s_mov_b32 s" K27 ", s" K27 "\n  s_mov_b32 s" K27 ", s" K27 "\n  s_mov_b32 s" K27 ", s" K27 "\n  s_mov_b32 s" K27 ", s" K27 "\n  s_mov_b32 s" K27 ", s" K27 "\n  s_mov_b32 s" K27 ", s" K27 "\n  s_mov_b32 s" K27 ", s" K27 "\n"
+#elif defined(GLOME_PKW_EXP_BRANCH)
+#define PKW_EXP_STEP_(TG) "  s_branch L_x1" TG "_%=\nL_x1" TG "_%=:\n  s_branch L_x2" TG "_%=\nL_x2" TG "_%=:\n  s_branch L_x3" TG "_%=\nL_x3" TG "_%=:\n  s_branch L_x4" TG "_%=\nL_x4" TG "_%=:\n"
+#elif defined(GLOME_PKW_EXP_VALU)
+#define PKW_EXP_STEP "  v_mov_b32 v" T3 ", v" T3 "\n  v_mov_b32 v" T3 ", v" T3 "\n  v_mov_b32 v" T3 ", v" T3 "\n  v_mov_b32 v" T3 ", v" T3 "\n  v_mov_b32 v" T3 ", v" T3 "\n  v_mov_b32 v" T3 ", v" T3 "\n  v_mov_b32 v" T3 ", v" T3 "\n  v_mov_b32 v" T3 ", v" T3 "\n"
+#else
+#define PKW_EXP_STEP ""
+#endif
+#ifndef PKW_EXP_STEP_
+#define PKW_EXP_STEP_(TG) PKW_EXP_STEP
+#endif
+
 // One branch step, for a node that is in flight into (or already in) register set SET ("A" = s[K0:K3], "B" = s[K4:K7]) and
 // splits along TAG's axis; EXEC = the lanes whose interval reaches it.  PL: the set's plane pair; NC / FC: its near and far
 // child references (by the packet's direction on this axis); OTH: the other set, where the near child's node is prefetched; ON:
@@ -389,7 +405,8 @@ constexpr uint32_t PKREF_LEAF = 3u;  // low bits of a reference in the walk's ow
 #define GLOME_PKW_STEP(SET, TAG, PL, NC, FC, OTH, ON, OP, RP, H, TN, TF)                                 \
   "L_st" SET TAG "_%=:\n"                                                                               \
   "  s_waitcnt lgkmcnt(0)\n"                /* the node is here */                                      \
-  "  s_buffer_load_dwordx4 " OTH ", s[" K36 ":" K39 "], " NC "\n"  /* the near child's node, under this step's work */ \
+  PKW_PREFETCH(OTH, NC)                                                                                 \
+  PKW_EXP_STEP_(SET TAG)                                                                                \
   "  v_pk_add_f32 v[" T0 ":" T1 "], " PL ", %[" OP "] op_sel:[0," H "] op_sel_hi:[1," H "] neg_lo:[0,1] neg_hi:[0,1]\n" \
   "  v_pk_mul_f32 v[" T0 ":" T1 "], v[" T0 ":" T1 "], %[" RP "] op_sel:[0," H "] op_sel_hi:[1," H "]\n" \
   "  v_cmp_lt_f32 vcc, " TF ", %[far]\n"    /* lanes that reach the far child */                        \
@@ -409,6 +426,7 @@ constexpr uint32_t PKREF_LEAF = 3u;  // low bits of a reference in the walk's ow
   "  s_cbranch_execz L_n1" SET TAG "_%=\n"                                                              \
   "  v_min_f32 %[far], " TN ", %[far]\n"                                                                \
   "  s_mov_b32 %[ref], " NC "\n"                                                                        \
+  PKW_LATE_FETCH(OTH, NC)                                                                               \
   GLOME_PKW_DISPATCH(ON)                                                                                \
   "L_n1" SET TAG "_%=:\n"                   /* nobody enters the near child */                          \
   "  s_cbranch_vccz L_pop_%=\n"             /* nor the far one */                                       \
@@ -426,6 +444,13 @@ constexpr uint32_t PKREF_LEAF = 3u;  // low bits of a reference in the walk's ow
   GLOME_PKW_STEP_##AY(SET, "Y", PL, L, R, OTH, ON, "P0", "R0", "1")                                     \
   GLOME_PKW_STEP_##AZ(SET, "Z", PL, L, R, OTH, ON, "P1", "R1", "0")                                     \
   GLOME_PKW_DISPATCH_TAIL(SET)
+#if defined(GLOME_PKW_EXP_NOPF)  // the near child's fetch at the END of the step: the same instructions, nothing overlapped
+#define PKW_PREFETCH(OTH, NC) ""
+#define PKW_LATE_FETCH(OTH, NC) "  s_buffer_load_dwordx4 " OTH ", s[" K36 ":" K39 "], " NC "\n"
+#else
+#define PKW_PREFETCH(OTH, NC) "  s_buffer_load_dwordx4 " OTH ", s[" K36 ":" K39 "], " NC "\n"  /* the near child's node, under this step's work */
+#define PKW_LATE_FETCH(OTH, NC) ""
+#endif
 #define PKW_SETA "s[" K0 ":" K3 "]"
 #define PKW_SETB "s[" K4 ":" K7 "]"
 
@@ -565,11 +590,11 @@ constexpr uint32_t PKREF_LEAF = 3u;  // low bits of a reference in the walk's ow
       "L_tri_%=:\n"                                                                                                             \
       "  s_load_dwordx16 s[" K8 ":" K23 "], %[pairs], %[ref]\n"                                                                 \
       "  s_load_dwordx4 s[" K24 ":" K27 "], %[pairs], %[ref] offset:0x40\n"                                                     \
-      "  s_add_u32 s" K33 ", %[ref], 80\n"  /* the second triangle's record */                                                  \
       "  s_waitcnt lgkmcnt(0)\n"                                                                                                \
+      "  s_add_u32 s" K33 ", s" K27 ", 1\n" /* the second triangle's record index */                                           \
       GLOME_PKW_PAIR_ARITH                                                                                                      \
       GLOME_PKW_CHAIN_A                                                                                                         \
-      GLOME_PKW_UPDATE_##M(T2, "%[ref]")                                                                                        \
+      GLOME_PKW_UPDATE_##M(T2, "s" K27)                                                                                        \
       "  s_cmp_eq_u32 s" K26 ", 1\n"                                                                                            \
       "  s_cbranch_scc1 L_pop_%=\n"         /* that was the leaf's last */                                                      \
       "  s_mov_b64 exec, s[" K34 ":" K35 "]\n"                                                                                  \
@@ -577,7 +602,7 @@ constexpr uint32_t PKREF_LEAF = 3u;  // low bits of a reference in the walk's ow
       GLOME_PKW_UPDATE_##M(T3, "s" K33)                                                                                         \
       "  s_cmp_eq_u32 s" K26 ", 2\n"                                                                                            \
       "  s_cbranch_scc1 L_pop_%=\n"                                                                                             \
-      "  s_add_u32 %[ref], %[ref], 160\n"                                                                                       \
+      "  s_add_u32 %[ref], %[ref], 80\n"                                                                                        \
       "  s_mov_b64 exec, s[" K34 ":" K35 "]\n"                                                                                  \
       "  s_branch L_tri_%=\n"                                                                                                   \
       /* ------------------------------------------------------------ pop until an entry some lane still wants */              \
@@ -635,10 +660,8 @@ constexpr uint32_t PKREF_LEAF = 3u;  // low bits of a reference in the walk's ow
 // phase 0: go on from `ref` with the lanes `am`; phase 1: pop first.  Returns a PKW_* status.
 // `nodes` / `nbytes`: the walk's own node pool (DScene::pknodes) and its size; `ref`, like every stack entry, in its form (a
 // branch: byte offset | axis, a leaf: byte offset of its first pair record | 3); `pairs`: the pair records (DScene::tripairs).
-// best_rec receives the byte offset of the hit triangle's own pair record (| 3 for a leaf's first): pkw_triangle_of() below.
+// best_rec receives the record index of the triangle hit (the pair record carries it).
 typedef float pkw_f2 __attribute__((ext_vector_type(2)));
-constexpr uint32_t kPairBytes = 80;  // == 4 * kPairWords (rt_types.h)
-__device__ __forceinline__ uint32_t pkw_triangle_of(uint32_t recorded) { return (recorded >> 4) / (kPairBytes >> 4); }  // index into DScene::tris / tripairs
 template <int MODE, bool XF, bool YF, bool ZF, int CAP>
 __device__ __forceinline__ int bih_walk_asm(const F4* nodes, uint32_t nbytes, const float* pairs, int phase, uint32_t& ref, LaneMask& am, int& sp, float& nearv, float& farv,
                                             float& best_t, uint32_t& best_rec, LaneMask& occm, V3 o, V3 rcp, V3 d, uint32_t lds_row, uint32_t* dump) {

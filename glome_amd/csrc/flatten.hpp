@@ -17,7 +17,7 @@ struct FlatScene {
   std::vector<F4> spheres, tris, trinorms, boxes, planes, discs, quadrics, xfms, bihhdr, bihnodes, meshhdr, meshnodes, mtris, mats, wlights;
   std::vector<U4> mtrimeta, entries;
   std::vector<uint32_t> matkids;
-  std::vector<float> tripairs;  // pair record k = triangles k and k + 1 interleaved (bih_packet_asm.hpp); flat tier only
+  std::vector<float> tripairs;  // the pair records of the triangle BIHs' leaves (emit_pairs; bih_packet_asm.hpp)
   std::vector<F4> pknodes;      // the packet walk's copy of the triangle BIHs' branch nodes: same slots as bihnodes, child references in its own form
   uint32_t root_rec = 0;
   uint32_t tier = 1;
@@ -60,7 +60,6 @@ class Flattener {
     if (F.tier == 0 && F.max_bih_depth > kFlatStack) { F.tier = 1; F.why_generic = "BIH deeper than the LDS stack"; }
     if (F.tier == 0 && F.max_mesh_depth > kFlatStack) { F.tier = 1; F.why_generic = "Mesh BVH deeper than the LDS stack"; }
     if (F.tier != 0) F.entries.clear();
-    if (F.tier == 0) emit_pairs();
     // the generic tier walks BIHs / Mesh BVHs with a fixed scratch stack per level: a deeper tree is refused, not truncated
     if (F.tier != 0 && F.max_mesh_depth > kGenericStack)
       throw limit_error("Mesh tree deeper than the device traversal stack (" + std::to_string(F.max_mesh_depth) + " > " + std::to_string(kGenericStack) + ")");
@@ -74,25 +73,25 @@ class Flattener {
 
   static bool is_prim(int k) { return k >= K_SPHERE && k <= K_CONE; }
 
-  // The packet walk tests a leaf's triangles two at a time: record k holds triangles k and k + 1 (leaf order), every component
-  // of p1, e1, e2 as an (A, B) pair -- p1x p1y p1z e1x e1y e1z e2x e2y e2z, 18 floats -- then the number of triangles of k's leaf
-  // from k on (emit_bih fills it in; what the walk's loop counts down) and a pad word: kPairWords words.  A leaf's odd last
-  // triangle is read as a pair whose B half belongs to whatever comes next and is ignored (the last record of the pool repeats
-  // its own triangle).
-  void emit_pairs() {
-    const size_t n = F.tris.size() / 3;
-    F.tripairs.resize(n * kPairWords, 0.0f);
-    for (size_t k = 0; k < n; k++) {
-      const size_t b = k + 1 < n ? k + 1 : k;
-      float* r = &F.tripairs[k * kPairWords];
+  // The packet walk tests a leaf's triangles two at a time.  A leaf of n triangles owns ceil(n / 2) consecutive PAIR RECORDS of
+  // kPairWords words: every component of p1, e1, e2 of triangles 2j and 2j + 1 as an (A, B) pair -- p1x p1y p1z e1x e1y e1z e2x
+  // e2y e2z, 18 floats -- then the number of the leaf's triangles from 2j on (what the walk's loop counts down) and the record
+  // index of triangle 2j (what a hit reports).  An odd last triangle is paired with itself; the walk ignores that half.
+  uint32_t emit_pairs(uint32_t first_prim, uint32_t count, uint32_t first_rec) {
+    const uint32_t at = (uint32_t)F.tripairs.size();
+    for (uint32_t j = 0; j < count; j += 2) {
+      const size_t a = first_prim + j, b = j + 1 < count ? a + 1 : a;
+      float r[kPairWords];
       for (int w = 0; w < 3; w++) {  // word w of a triangle record: (p1, .) (e1, .) (e2, .)
-        const F4 &A = F.tris[3 * k + w], &B = F.tris[3 * b + w];
+        const F4 &A = F.tris[3 * a + w], &B = F.tris[3 * b + w];
         r[6 * w + 0] = A.x; r[6 * w + 1] = B.x; r[6 * w + 2] = A.y; r[6 * w + 3] = B.y; r[6 * w + 4] = A.z; r[6 * w + 5] = B.z;
       }
-      r[18] = as_float_bits(k < pair_left.size() ? pair_left[k] : 1u);
+      r[18] = as_float_bits(count - j);
+      r[19] = as_float_bits(first_rec + j);
+      F.tripairs.insert(F.tripairs.end(), r, r + kPairWords);
     }
+    return at * 4u;  // byte offset of the leaf's first record
   }
-  std::vector<uint32_t> pair_left;  // per triangle of `tris`: triangles of its BIH leaf from it on (1 outside a triangle BIH)
 
   void pad() {  // never hand a null pool to a kernel
     auto p4 = [](std::vector<F4>& v) { if (v.empty()) v.push_back(F4{0, 0, 0, 0}); };
@@ -101,7 +100,7 @@ class Flattener {
     if (F.mtrimeta.empty()) F.mtrimeta.push_back(U4{0, 0, 0, 0});
     if (F.entries.empty()) F.entries.push_back(U4{0, 0, 0, 0});
     if (F.matkids.empty()) F.matkids.push_back(0);
-    if (F.tripairs.empty()) F.tripairs.assign(18, 0.0f);
+    if (F.tripairs.empty()) F.tripairs.assign(kPairWords, 0.0f);
     if (F.pknodes.size() < F.bihnodes.size()) F.pknodes.resize(F.bihnodes.size(), F4{0, 0, 0, 0});
   }
 
@@ -482,11 +481,9 @@ class Flattener {
         if (have_delta && dl != delta) throw scene_error("internal: BIH leaf pools are not contiguous");
         delta = dl; have_delta = true;
       }
-      if (cls == BC_TRI && count) {
-        if ((uint64_t)(first_prim + count) * kPairWords * 4 >= (1ull << 31)) pk = false;  // (a pair record's byte offset is a reference)
-        pkleaf[k] = first_prim * (uint32_t)(kPairWords * 4) | 3u;
-        if (pair_left.size() < (size_t)first_prim + count) pair_left.resize((size_t)first_prim + count, 1u);
-        for (uint32_t q = 0; q < count; q++) pair_left[first_prim + q] = count - q;
+      if (cls == BC_TRI && count && pk) {
+        if (((uint64_t)F.tripairs.size() + (uint64_t)count * kPairWords) * 4 >= (1ull << 31)) pk = false;  // (a pair record's byte offset is a reference)
+        else pkleaf[k] = emit_pairs(first_prim, count, first_rec) | 3u;
       }
       if (count == 0) ref[k] = BREF_LEAF_BIT;
       else if (count <= 6) ref[k] = BREF_LEAF_BIT | (count << 26) | first_rec;

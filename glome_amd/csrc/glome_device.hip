@@ -182,21 +182,43 @@ __device__ __forceinline__ bool work_to_pixel(const DRenderArgs& A, uint32_t w, 
 // atomics queued on its line: measured 4x slower), so a wave rarely pays for more than one failed take.  The last wave to
 // leave puts everything back to zero: the next launch on the slot needs no reset packet on the stream.
 constexpr uint32_t kNoTicket = 0xffffffffu;
+// A wave may take several tickets per atomic while the head is far from empty and single ones towards the end (guided
+// self-scheduling).  Measured in round 3 and left OFF (largest batch 1): in-kernel stamps put a wave's wait for a ticket at
+// 2,500-3,100 cycles, 3-4 % of its lifetime on the flagship frame (21 % on a frame of empty sky, where the 46 us that 32,400
+// serialised atomics take on 8 heads are most of the frame); batches of 4 or 8 won 0-7 % pipelined and lost 15-30 % on a launch
+// alone, whose last items then run on too few waves (tools/probe/empty_frame.py; fixed and guided batches alike).
+#ifndef GLOME_TICKET_BATCH
+#define GLOME_TICKET_BATCH 1  // the largest batch
+#endif
 struct TicketQueue {
   uint32_t shard, dry;
-  __device__ __forceinline__ TicketQueue() : shard(blockIdx.x % kQueueShards), dry(0) {}
+  uint32_t inext = 0, left = 0, cur = 0;  // a batch in hand: its next queue index, tickets left in it, the head it came from (lane 0's)
+  uint32_t batch;
+  __device__ __forceinline__ uint32_t batch_for(const DRenderArgs& A, uint32_t remaining) const {  // ~half a fair share of what is left, 1..GLOME_TICKET_BATCH
+    const uint32_t waves_per_head = (gridDim.x + kQueueShards - 1) / kQueueShards;
+    const uint32_t b = remaining / (2u * waves_per_head);
+    return b < 1u ? 1u : (b > (uint32_t)GLOME_TICKET_BATCH ? (uint32_t)GLOME_TICKET_BATCH : b);
+  }
+  __device__ __forceinline__ TicketQueue(const DRenderArgs& A) : shard(blockIdx.x % kQueueShards), dry(0) { batch = batch_for(A, A.shard_cap); }
   __device__ __forceinline__ uint32_t take(const DRenderArgs& A) {  // lane 0 only
     constexpr uint32_t kAll = (1u << kQueueShards) - 1u;
-    while (dry != kAll) {
+    for (;;) {
+      if (left) {
+        left--;
+        const uint32_t i = inext++;
+        if (i < A.shard_cap) return ((i / kQueueChunk) * kQueueShards + cur) * kQueueChunk + (i % kQueueChunk);
+        left = 0;  // the batch reached past the head's last ticket
+      }
+      if (dry == kAll) return kNoTicket;
       if (!((dry >> shard) & 1u)) {
-        const uint32_t i = atomicAdd(&A.counters->heads[shard * kQueueHeadStride], 1u);
-        if (i < A.shard_cap) return ((i / kQueueChunk) * kQueueShards + shard) * kQueueChunk + (i % kQueueChunk);
+        const uint32_t i = atomicAdd(&A.counters->heads[shard * kQueueHeadStride], batch);
+        if (i < A.shard_cap) { inext = i; left = batch; cur = shard; batch = batch_for(A, A.shard_cap - i); continue; }
         atomicOr(&A.counters->dry, 1u << shard);
         dry |= (1u << shard) | __hip_atomic_load(&A.counters->dry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        batch = 1;  // what other heads have left is shared by everybody who comes by
       }
       shard = (shard + 1) % kQueueShards;
     }
-    return kNoTicket;
   }
   __device__ __forceinline__ void leave(const DRenderArgs& A) {  // lane 0 only, after its last take
     if (atomicAdd(&A.counters->done, 1u) == gridDim.x - 1u) {  // every other wave has taken its last ticket
@@ -207,39 +229,85 @@ struct TicketQueue {
   }
 };
 
+// GLOME_PROBE (a measurement build, tools/probe/empty_frame.py; never the product): GLOME_DEBUG_FLAGS leaves parts of a work item
+// out (1 no pixel store, 2 no trace, 4 no item -> pixel lookup, 8 static items instead of tickets) or (16) stamps its sections
+// with s_memtime into DCounters::dbg.  Compiled out of the product: the stamps alone cost the flagship kernel 5 %.
+#ifdef GLOME_PROBE
+#define GLOME_PROBE_FLAG(A, bit) ((A).debug_flags & (bit))
+#else
+#define GLOME_PROBE_FLAG(A, bit) false
+#endif
 template <class TIER>
 __device__ __forceinline__ void render_loop(const DRenderArgs& A, TIER& T) {
   int lane = threadIdx.x & 63;
-  TicketQueue Q;
+  TicketQueue Q(A);
+#ifdef GLOME_PROBE
+  uint32_t stat = blockIdx.x;
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, t_s[3] = {0, 0, 0};  // item -> pixel lookup, ray generation, trace
+  unsigned long long t_take = 0, n_take = 0, t_begin = (A.debug_flags & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
+#endif
   for (;;) {
     uint32_t w = kNoTicket;
+#ifdef GLOME_PROBE
+    if (A.debug_flags & 8) { w = stat < A.total_waves * (uint32_t)A.nframes ? stat : kNoTicket; stat += gridDim.x; }
+    else {
+      const unsigned long long t0 = (A.debug_flags & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
+      if (lane == 0) w = Q.take(A);
+      w = __shfl(w, 0, 64);
+      if (A.debug_flags & 16) { ts0 = __builtin_amdgcn_s_memtime(); t_take += ts0 - t0; n_take++; }
+    }
+#else
     if (lane == 0) w = Q.take(A);
     w = __shfl(w, 0, 64);
+#endif
     if (w == kNoTicket) break;
     if (w >= A.total_waves * (uint32_t)A.nframes) continue;  // padding of the last round of chunks
     const uint32_t frame = w / A.total_waves;  // wave-uniform
     w -= frame * A.total_waves;
     int px = 0, py = 0;
     size_t dense_off = 0;
-    const bool valid = work_to_pixel(A, w, lane, px, py, dense_off);  // lanes past the end of a leftover strip idle along
+    bool valid;
+    if (GLOME_PROBE_FLAG(A, 4)) { px = (int)((w * 64u + lane) % (uint32_t)A.width); py = (int)((w * 64u + lane) / (uint32_t)A.width); valid = py < A.height; }
+    else valid = work_to_pixel(A, w, lane, px, py, dense_off);  // lanes past the end of a leftover strip idle along
+#ifdef GLOME_PROBE
+    if (A.debug_flags & 16) { asm volatile("" :: "v"(px), "v"(py)); ts1 = __builtin_amdgcn_s_memtime(); }
+#endif
     float xc, yc;
     get_coordsf(A.width, A.height, (float)px, (float)py, xc, yc);
     Ray ray = primary_ray(frame == 0 ? A.cam : A.more_cams[frame - 1], xc, yc);
     if (valid) T.cnt.primary++;
+#ifdef GLOME_PROBE
+    if (A.debug_flags & 16) { asm volatile("" :: "v"(ray.d.x), "v"(ray.d.y), "v"(ray.d.z)); ts2 = __builtin_amdgcn_s_memtime(); }
+#endif
     HitG h;
-    CA c = trace_primary(T, ray, kInf, A.maxdepth, valid, &h);  // Trace.trace lights shader sld ray infinity maxdepth (Glome.hs:33)
+    CA c;
+    if (GLOME_PROBE_FLAG(A, 2)) { c = ca(ray.d.x, ray.d.y, ray.d.z, 1.0f); h = hit_miss(); }
+    else c = trace_primary(T, ray, kInf, A.maxdepth, valid, &h);  // Trace.trace lights shader sld ray infinity maxdepth (Glome.hs:33)
+#ifdef GLOME_PROBE
+    if (A.debug_flags & 16) { asm volatile("" :: "v"(c.r), "v"(c.g), "v"(c.b)); ts3 = __builtin_amdgcn_s_memtime(); t_s[0] += ts1 - ts0; t_s[1] += ts2 - ts1; t_s[2] += ts3 - ts2; }
+#endif
     if (!valid) continue;
     float depth = h.hit ? h.t : kInf;      // ridepth
     float r = c.r;
     if (A.fog) r = r + (depth / 400);      // renderTile's debug fog (Glome.hs:174, Q20)
     size_t o = (A.dense ? dense_off : (size_t)py * A.width + px) + (size_t)frame * A.frame_stride;
+    if (GLOME_PROBE_FLAG(A, 1)) { if (r == 12345.678f) A.packed[o] = 1u; continue; }
     if (A.out5) {
       float* out = A.out5 + o * 5;
       out[0] = r; out[1] = c.g; out[2] = c.b; out[3] = c.a; out[4] = depth;
     }
     if (A.packed) A.packed[o] = rgbf(r * c.a, c.g * c.a, c.b * c.a);  // blitTile (Glome.hs:353-358)
   }
+#ifdef GLOME_PROBE
+  if ((A.debug_flags & 16) && lane == 0) {  // cycles waiting for tickets, tickets asked for, the wave's lifetime, waves, cycles per section
+    atomicAdd(&A.counters->dbg[0], t_take); atomicAdd(&A.counters->dbg[1], n_take);
+    atomicAdd(&A.counters->dbg[2], __builtin_amdgcn_s_memtime() - t_begin); atomicAdd(&A.counters->dbg[3], 1ull);
+    atomicAdd(&A.counters->dbg[4], t_s[0]); atomicAdd(&A.counters->dbg[5], t_s[1]); atomicAdd(&A.counters->dbg[6], t_s[2]);
+  }
+  if (lane == 0 && !(A.debug_flags & 8)) Q.leave(A);
+#else
   if (lane == 0) Q.leave(A);
+#endif
 }
 
 // TWO_ROWS: the wave's LDS holds two stack rows per entry instead of three (lane_stack); legal when no lane ever pushes on
@@ -1121,6 +1189,9 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
   const bool bare = !stats && P->mode == GLOME_MODE_TILE && !P->faithful && !P->count_work;
   if (!bare && (rc = reset_counters(ctx))) return rc;
   A.want_counters = (bare || (P->mode == GLOME_MODE_SUBSAMPLE && !stats)) ? 0 : 1;  // nobody reads them without `stats`
+#ifdef GLOME_PROBE
+  if (const char* e = getenv("GLOME_DEBUG_FLAGS")) A.debug_flags = atoi(e);  // (render_loop)
+#endif
   hipEvent_t ev_start = ctx->ev0, ev_stop = ctx->ev1;
   if (A.ntiles > 0 && P->mode == GLOME_MODE_SUBSAMPLE) {
     // scratch: v (5 float planes over the owned pixels) | queue heads, one per 128-byte line, then the dry mask | one

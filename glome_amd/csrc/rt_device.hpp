@@ -795,8 +795,6 @@ GD PacketResult bih_tri_packet_hw(const F4* nodes, uint32_t nbytes, const float*
       phase = am != 0 ? 0 : 1;
     }
   }
-  // the walk records a hit as the byte offset of the triangle's pair record: back to the record index the callers expect
-  if (R.best_rec != kNoRec) R.best_rec = pkw_triangle_of(R.best_rec) - delta;
   R.occ_lo = (uint32_t)occm; R.occ_hi = (uint32_t)(occm >> 32);
   return R;
 }

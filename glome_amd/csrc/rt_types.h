@@ -60,7 +60,7 @@ constexpr int kMaxTraceDepth = 4;  // maxdepth values the render kernels are ins
 constexpr int kMaxMatNest = 2;
 constexpr int kMaxBatchFrames = 8;  // frames one render launch can carry     // Blend / AdditiveLayers nesting the shader is instantiated for
 
-constexpr int kPairWords = 20;  // a pair record: 18 floats, the leaf's remaining count, one pad word (80 bytes)
+constexpr int kPairWords = 20;  // a pair record: 18 floats, the leaf's remaining count, the first triangle's record index (80 bytes)
 
 struct F4 { float x, y, z, w; };
 struct U4 { uint32_t x, y, z, w; };
@@ -69,8 +69,8 @@ struct DScene {
   const U4* recs;
   const F4* spheres;
   const F4* tris;
-  const float* tripairs;  // record k (kPairWords words) = triangles k and k + 1 of `tris`, every component of p1, e1, e2 as (A, B), then the
-                          // number of triangles of k's leaf from k on: the packet walk's pair tests (bih_packet_asm.hpp)
+  const float* tripairs;  // the triangle BIHs' leaves as pair records (flatten.hpp emit_pairs): two triangles with every component of
+                          // p1, e1, e2 as (A, B), the leaf's remaining count, the record index -- the packet walk's pair tests
   const F4* trinorms;
   const F4* boxes;
   const F4* planes;
@@ -145,6 +145,7 @@ struct DRenderArgs {
   int32_t nframes;
   uint32_t frame_stride;
   int32_t want_counters;  // 0: nobody will read the ray / work counters of this launch -- the waves skip the flush
+  int32_t debug_flags;    // GLOME_PROBE builds only (glome_device.hip render_loop)
   DCamera more_cams[kMaxBatchFrames - 1];
 };
 
