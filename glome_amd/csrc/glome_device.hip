@@ -245,6 +245,9 @@ __device__ __forceinline__ void render_loop(const DRenderArgs& A, TIER& T) {
   uint32_t stat = blockIdx.x;
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, t_s[3] = {0, 0, 0};  // item -> pixel lookup, ray generation, trace
   unsigned long long t_take = 0, n_take = 0, t_begin = (A.debug_flags & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();  // the 100 MHz clock every CU shares
+  unsigned long long rt_last_item = rt_begin, worst = 0;
+  uint32_t worst_steps = 0, steps_before = 0;
 #endif
   for (;;) {
     uint32_t w = kNoTicket;
@@ -261,6 +264,9 @@ __device__ __forceinline__ void render_loop(const DRenderArgs& A, TIER& T) {
     w = __shfl(w, 0, 64);
 #endif
     if (w == kNoTicket) break;
+#ifdef GLOME_PROBE
+    rt_last_item = __builtin_amdgcn_s_memrealtime();
+#endif
     if (w >= A.total_waves * (uint32_t)A.nframes) continue;  // padding of the last round of chunks
     const uint32_t frame = w / A.total_waves;  // wave-uniform
     w -= frame * A.total_waves;
@@ -285,6 +291,11 @@ __device__ __forceinline__ void render_loop(const DRenderArgs& A, TIER& T) {
     else c = trace_primary(T, ray, kInf, A.maxdepth, valid, &h);  // Trace.trace lights shader sld ray infinity maxdepth (Glome.hs:33)
 #ifdef GLOME_PROBE
     if (A.debug_flags & 16) { asm volatile("" :: "v"(c.r), "v"(c.g), "v"(c.b)); ts3 = __builtin_amdgcn_s_memtime(); t_s[0] += ts1 - ts0; t_s[1] += ts2 - ts1; t_s[2] += ts3 - ts2; }
+    if (A.debug_flags & 32) {  // the longest item, and the C++ steps its walks needed
+      const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - rt_last_item;
+      if (lane == 0) { if (dt > worst) { worst = dt; worst_steps = w; } }  // (which item)
+      steps_before = T.cnt.bih;
+    }
 #endif
     if (!valid) continue;
     float depth = h.hit ? h.t : kInf;      // ridepth
@@ -296,6 +307,9 @@ __device__ __forceinline__ void render_loop(const DRenderArgs& A, TIER& T) {
       float* out = A.out5 + o * 5;
       out[0] = r; out[1] = c.g; out[2] = c.b; out[3] = c.a; out[4] = depth;
     }
+#ifdef GLOME_PROBE
+    if (A.debug_flags & 64) { A.packed[o] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - rt_last_item); continue; }  // a cost image: the item's duration (10 ns units) in its pixels
+#endif
     if (A.packed) A.packed[o] = rgbf(r * c.a, c.g * c.a, c.b * c.a);  // blitTile (Glome.hs:353-358)
   }
 #ifdef GLOME_PROBE
@@ -303,6 +317,14 @@ __device__ __forceinline__ void render_loop(const DRenderArgs& A, TIER& T) {
     atomicAdd(&A.counters->dbg[0], t_take); atomicAdd(&A.counters->dbg[1], n_take);
     atomicAdd(&A.counters->dbg[2], __builtin_amdgcn_s_memtime() - t_begin); atomicAdd(&A.counters->dbg[3], 1ull);
     atomicAdd(&A.counters->dbg[4], t_s[0]); atomicAdd(&A.counters->dbg[5], t_s[1]); atomicAdd(&A.counters->dbg[6], t_s[2]);
+  }
+  if ((A.debug_flags & 32) && lane == 0) {  // the launch's timeline on the shared clock: first / last wave start, first / last wave's last ticket, first / last wave end
+    const unsigned long long rt_end = __builtin_amdgcn_s_memrealtime();
+    atomicMin(&A.counters->dbg[8], rt_begin); atomicMax(&A.counters->dbg[9], rt_begin);
+    atomicMin(&A.counters->dbg[10], rt_last_item); atomicMax(&A.counters->dbg[11], rt_last_item);
+    atomicMin(&A.counters->dbg[12], rt_end); atomicMax(&A.counters->dbg[13], rt_end);
+    atomicAdd(&A.counters->dbg[14], (unsigned long long)T.cnt.bih);                        // C++ steps of all walks
+    atomicMax(&A.counters->dbg[15], (worst << 20) | (unsigned long long)worst_steps);     // the longest item (10 ns units) and its C++ steps
   }
   if (lane == 0 && !(A.debug_flags & 8)) Q.leave(A);
 #else
@@ -838,6 +860,10 @@ glome_ctx* glome_ctx_create(int device_ordinal) {
   if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return fail("hipEventCreate", e);
   for (int k = 0; k < glome_ctx::kSlots; k++)
     if ((e = hipMalloc((void**)&c->slots[k].d_counters, sizeof(DCounters))) != hipSuccess || (e = hipMemset(c->slots[k].d_counters, 0, sizeof(DCounters))) != hipSuccess) return fail("hipMalloc", e);
+#ifdef GLOME_PROBE
+  for (int k = 0; k < glome_ctx::kSlots; k++)
+    for (int q : {8, 10, 12}) (void)hipMemset(&c->slots[k].d_counters->dbg[q], 0xff, sizeof(unsigned long long));  // (the timeline's minima, render_loop)
+#endif
   return c;
 }
 void glome_ctx_destroy(glome_ctx* c) {

@@ -766,6 +766,9 @@ GD PacketResult bih_tri_packet_hw(const F4* nodes, uint32_t nbytes, const float*
 #undef GLOME_WALK
     st = (int)uni((uint32_t)st);
     if (st == PKW_DONE) break;
+#ifdef GLOME_PROBE
+    R.n_bih++;  // (probe builds: steps handed back to C++, render_loop sums them into DCounters::dbg[14])
+#endif
     ref = uni(ref); am = uni(am); sp = (int)uni((uint32_t)sp);
     if (st == PKW_PUSH_OVERFLOW) {  // one branch step of bih_tri_packet; its push goes to the overflow columns
       F4 n = ld4u(nodes, ref >> 4);
@@ -856,6 +859,9 @@ GD bool bih_tri_wave(const DScene& S, uint32_t hdr, const Ray& r, float d, bool 
                                                                      nearv, farv, r.o, r.d, rcp, best_t, stk);
       else { R.best_t = best_t; R.best_rec = kNoRec; R.occ_lo = R.occ_hi = R.n_bih = R.n_prim = 0; }  // (a kernel with two stack rows is only launched for what bih_walk_asm walks)
     }
+#ifdef GLOME_PROBE
+    if (!COUNT) cnt.bih += R.n_bih;  // (every lane: the wave's count of C++ steps)
+#endif
     if (lane_of(am)) {
       if (COUNT) { cnt.bih += R.n_bih; cnt.prim += R.n_prim; }
       if (MODE != 2 && R.best_rec != kNoRec) { best_t = R.best_t; best_rec = R.best_rec; }
