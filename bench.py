@@ -140,9 +140,14 @@ def main():
         elif world == 2:
             args.group = 1 if args.steps < 8 else (4 if args.steps < 64 else 8)
         elif world <= 4:
-            args.group = 2 if args.steps < 16 else 8
+            args.group = 2 if args.steps < 16 else (8 if args.steps < 128 else 16)
         else:
-            args.group = 4 if args.steps < 40 else 8
+            # (a rank's shard of a frame is a small launch: sixteen frames per launch halve what its fixed part costs per frame --
+            # one-GPU rehearsal of rank 0's pipeline at 8 ranks, tools/shard_timing.py: 0.038 / 0.030 / 0.027 ms per frame with
+            # 4 / 8 / 16 frames per launch, profiles/r03_shard_timing.log)
+            args.group = 4 if args.steps < 40 else (8 if args.steps < 128 else 16)
+            if args.group == 16 and args.lanes == 4:
+                args.lanes = 3
     sf = dist.ShardedFrame(scene, P, rank, world, device, lanes=args.lanes, product=args.product, group=args.group, force_pipeline=args.force_dist)
 
     def barrier():

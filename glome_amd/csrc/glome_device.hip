@@ -4,7 +4,7 @@
 // Kernel catalogue
 //   k_render_flat<FAITHFUL,COUNT,FULL,CLS,LB,TWO_ROWS>
 //                                       persistent: one wave pulls 64-pixel work items (8x8 blocks of a 65x65
-//                                       reference tile, Glome.hs:371-386; up to 8 frames per launch) from a ticket
+//                                       reference tile, Glome.hs:371-386; up to 16 frames per launch) from a ticket
 //                                       queue of eight heads; the wave walks a triangle / sphere BIH once for its 64 rays
 //                                       (packet: rt_device.hpp bih_tri_wave; for triangles the hand-written walk of
 //                                       bih_packet_asm.hpp) -> shadow rays -> shade; secondary rays re-enter the same walk
@@ -1193,7 +1193,7 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
   memset(&A, 0, sizeof(A));
   A.S = s->dev;
   memcpy(&A.cam, cam, sizeof(DCamera));
-  if (nframes < 1 || nframes > kMaxBatchFrames) { ctx->err = "a launch carries 1..8 frames"; return GLOME_E_LIMIT; }
+  if (nframes < 1 || nframes > kMaxBatchFrames) { ctx->err = "a launch carries 1..16 frames"; return GLOME_E_LIMIT; }
   if (nframes > 1 && (frame_stride <= 0 || frame_stride > 0xffffffffll)) { ctx->err = "frame batches: positive frame stride"; return GLOME_E_INVALID; }
   for (int f = 1; f < nframes; f++) memcpy(&A.more_cams[f - 1], cam + f, sizeof(DCamera));
   A.nframes = nframes; A.frame_stride = nframes > 1 ? (uint32_t)frame_stride : 0u;
@@ -1583,7 +1583,7 @@ int glome_tiles_blit_dev(glome_ctx* ctx, const glome_render_params* P, int tile_
 // ================================================================================================ several GPUs, one process
 // renderTiles' `runPar $ parMap` over tiles followed by `forM_ tiles (blitTile surf)` (Glome.hs:379-386) across the GPUs of a
 // node, for a host that drives all of them from one process (the Haskell host of INTEGRATION.md): scenes[i] is the scene
-// committed on context i, tile k of the frame belongs to rank k mod n, a rank renders its tiles of up to 8 frames in one
+// committed on context i, tile k of the frame belongs to rank k mod n, a rank renders its tiles of up to 16 frames in one
 // launch straight into a packed payload, the payloads travel to rank 0's GPU over xGMI, one launch there blits the frames.
 // The exchange is the path's only communication step.  Transport: RCCL send / recv in one group (librccl is opened at run
 // time, so the library carries no link-time dependency on it) when the ranks sit on distinct devices; peer copies on rank
@@ -1721,7 +1721,7 @@ const char* glome_multi_transport(const glome_multi* m) { return !m ? "" : (m->n
 
 int glome_multi_render(glome_multi* m, const glome_camera* cams, int nframes, const glome_light* lights, int nlights, uint32_t* packed_dev) {
   if (!m || !cams || !packed_dev) return GLOME_E_INVALID;
-  if (nframes < 1 || nframes > kMaxBatchFrames || (m->P.mode != GLOME_MODE_TILE && nframes != 1)) { m->err = "a call carries 1..8 frames (one in adaptive mode)"; return GLOME_E_LIMIT; }
+  if (nframes < 1 || nframes > kMaxBatchFrames || (m->P.mode != GLOME_MODE_TILE && nframes != 1)) { m->err = "a call carries 1..16 frames (one in adaptive mode)"; return GLOME_E_LIMIT; }
   const int n = m->n;
   glome_ctx* c0 = m->scenes[0]->ctx;
   const size_t slab = (size_t)kMaxBatchFrames * (size_t)m->maxp;

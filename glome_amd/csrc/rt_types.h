@@ -58,7 +58,7 @@ constexpr int kCsgMaxAdvance = 32; // ray-advance steps per CSG node before givi
 constexpr int kIsectFrames = 40;   // explicit frames for rayint_intersection's list recursion (flat tier's CSG items)
 constexpr int kMaxTraceDepth = 4;  // maxdepth values the render kernels are instantiated for
 constexpr int kMaxMatNest = 2;
-constexpr int kMaxBatchFrames = 8;  // frames one render launch can carry     // Blend / AdditiveLayers nesting the shader is instantiated for
+constexpr int kMaxBatchFrames = 16;  // frames one render launch can carry     // Blend / AdditiveLayers nesting the shader is instantiated for
 
 constexpr int kPairWords = 20;  // a pair record: 18 floats, the leaf's remaining count, the first triangle's record index (80 bytes)
 

@@ -891,14 +891,14 @@ def test_refused_parameters_fail_with_a_status_not_a_frame(gpu_ctx):
     b, nm, sc = commit(gpu_ctx, sd)
     cam, lights = product_camera_lights(sd)
     la = (L.Light * len(lights))(*lights)
-    buf = torch.zeros((9, 64, 64), dtype=torch.int32, device=torch.device("cuda:0"))
+    buf = torch.zeros((17, 64, 64), dtype=torch.int32, device=torch.device("cuda:0"))
     for kw in (dict(width=0), dict(height=-3), dict(maxdepth=0), dict(maxdepth=9), dict(blocksize=0), dict(tile_stride=0), dict(tile_first=-1), dict(rank0_share_pct=101)):
         P = api.render_params(**{**dict(width=64, height=64, maxdepth=1), **kw})
         rc = sc.lib.glome_render_dev(sc.h, C.byref(cam), la, len(lights), C.byref(P), None, C.c_void_p(buf.data_ptr()), None)
         assert rc in (L.E_INVALID, L.E_LIMIT) and gpu_ctx.err(), kw
     P = api.render_params(width=64, height=64, maxdepth=1)
-    cams = (L.Camera * 9)(*[cam] * 9)
-    assert sc.lib.glome_render_packed_batch_dev(sc.h, cams, 9, la, len(lights), C.byref(P), C.c_void_p(buf.data_ptr()), 64 * 64, None) == L.E_LIMIT  # 1..8 frames
+    cams = (L.Camera * 17)(*[cam] * 17)
+    assert sc.lib.glome_render_packed_batch_dev(sc.h, cams, 17, la, len(lights), C.byref(P), C.c_void_p(buf.data_ptr()), 64 * 64, None) == L.E_LIMIT  # 1..16 frames
     assert sc.lib.glome_render_packed_batch_dev(sc.h, cams, 2, la, len(lights), C.byref(P), C.c_void_p(buf.data_ptr()), 0, None) == L.E_INVALID   # frame stride
     too_many = (L.Light * 17)(*[lights[0]] * 17)  # (the light list holds 16)
     assert sc.lib.glome_render_dev(sc.h, C.byref(cam), too_many, 17, C.byref(P), None, C.c_void_p(buf.data_ptr()), None) in (L.E_INVALID, L.E_LIMIT)

@@ -47,7 +47,7 @@ for world in (() if os.environ.get("SHARD_PIPE_ONLY") else (1, 2, 4, 8)):
 class _Done:
     def wait(self):
         return True
-for world, lanes, group in ((8, 4, 4), (8, 2, 8), (8, 4, 8), (8, 4, 2), (4, 4, 4), (4, 4, 8), (2, 4, 8), (2, 4, 4), (1, 4, 1), (1, 4, 2), (1, 2, 4)):
+for world, lanes, group in ((8, 4, 16), (8, 2, 16), (8, 3, 16), (4, 4, 16), (2, 4, 16), (8, 4, 8), (8, 4, 4), (4, 4, 4), (4, 4, 8), (2, 4, 8), (2, 4, 4), (1, 4, 1), (1, 4, 2), (1, 2, 4)):
     sf = dist.ShardedFrame(sc, P, 0, world, dev, lanes=lanes, product="packed", group=group)
     def fake(payload, gathered, async_op=False):
         gathered[0].copy_(payload)
