@@ -101,6 +101,7 @@ SYMBOLS = [
     ("glome_sb_innerbound", C.c_int32, [vp, C.c_int32, C.c_int32]),
     ("glome_sb_flatten_transform", C.c_int32, [vp, C.c_int32]),
     ("glome_sb_tolist", C.c_int32, [vp, C.c_int32]),
+    ("glome_sb_list_items", C.c_int32, [vp, C.c_int32, c_ip, C.c_int32]),
     ("glome_sb_material_surface", C.c_int32, [vp, c_dp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]),
     ("glome_sb_material_reflect", C.c_int32, [vp, C.c_double]),
     ("glome_sb_material_refract", C.c_int32, [vp, C.c_double, C.c_double, C.c_double]),

@@ -196,6 +196,15 @@ class Builder:
     def flatten_transform(self, node): return self._chk(self.lib.glome_sb_flatten_transform(self.h, int(node)), "glome_sb_flatten_transform")
     def tolist(self, node): return self._chk(self.lib.glome_sb_tolist(self.h, int(node)), "glome_sb_tolist")
 
+    def list_items(self, node):
+        """the [SolidItem] that `tolist node` yields, as node ids"""
+        n = self._chk(self.lib.glome_sb_list_items(self.h, int(node), None, 0), "glome_sb_list_items")
+        out = np.zeros(max(1, n), np.int32)
+        self._chk(self.lib.glome_sb_list_items(self.h, int(node), out.ctypes.data_as(L.c_ip), n), "glome_sb_list_items")
+        return [int(x) for x in out[:n]]
+
+    def bih_tolist(self, node): return self.bih(self.list_items(node))  # `bih (tolist node)`, TestScene.hs:109
+
     def material_surface(self, color, alpha, amb, kd, ks, shine):
         return self._call("glome_sb_material_surface", color, float(alpha), float(amb), float(kd), float(ks), float(shine))
     def material_reflect(self, refl): return self._call("glome_sb_material_reflect", float(refl))

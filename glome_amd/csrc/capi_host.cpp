@@ -115,6 +115,14 @@ int32_t glome_sb_bound_object(glome_sb* sb, int32_t a, int32_t b) { return guard
 int32_t glome_sb_innerbound(glome_sb* sb, int32_t a, int32_t b) { return guard(sb, [&] { return sb->graph.bound_object(a, b, true); }); }
 int32_t glome_sb_flatten_transform(glome_sb* sb, int32_t id) { return guard(sb, [&] { return sb->graph.flatten_transform_item(id); }); }
 int32_t glome_sb_tolist(glome_sb* sb, int32_t id) { return guard(sb, [&] { return sb->graph.tolist_node(id); }); }
+int32_t glome_sb_list_items(glome_sb* sb, int32_t id, int32_t* out, int32_t cap) {
+  return guard(sb, [&] {
+    std::vector<int> items;
+    sb->graph.tolist(id, items);
+    for (size_t k = 0; k < items.size() && (int32_t)k < cap && out; k++) out[k] = items[k];
+    return (int)items.size();
+  });
+}
 
 int32_t glome_sb_material_surface(glome_sb* sb, const double color[3], double alpha, double amb, double kd, double ks, double shine) {
   return guard(sb, [&] { Mat m; m.kind = MAT_SURFACE; m.color[0] = color[0]; m.color[1] = color[1]; m.color[2] = color[2]; m.alpha = alpha; m.amb = amb; m.kd = kd; m.ks = ks; m.shine = shine; return sb->graph.add_mat(m); });

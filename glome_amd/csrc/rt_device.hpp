@@ -1013,7 +1013,7 @@ GD TexStack leaf_meta(const DScene& S, U4 rec) {  // get_metainfo of a primitive
 // rayint_difference, Csg.hs:33-54 (Q13); the self-recursion through rayint_advance (Solid.hs:85-91) is a loop
 template <bool C> GD HitG csg_diff(const DScene& S, Cnt& cnt, unsigned int& err, U4 rec, const Ray& r0, float d0, TexStack tex) {
   const U4 ra = ldu4(S.recs, rec.y), rb = ldu4(S.recs, rec.z);
-  float adds[kCsgMaxAdvance];
+  float adds[kCsgFlatAdvance];
   int na = 0;
   Ray r = r0;
   float d = d0;
@@ -1035,7 +1035,7 @@ template <bool C> GD HitG csg_diff(const DScene& S, Cnt& cnt, unsigned int& err,
       if (!hb.hit) { res = ha; break; }
       if (ha.t < hb.t) { res = ha; break; }
     }
-    if (na >= kCsgMaxAdvance) { err = 1; break; }
+    if (na >= kCsgFlatAdvance) { err = 1; break; }
     const float a = hb.t + kDel;
     adds[na++] = a;
     r.o = vscaleadd(r.o, r.d, a);  // ray_move

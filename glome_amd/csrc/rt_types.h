@@ -54,11 +54,12 @@ constexpr int kGenericStack = 32;  // scratch traversal-stack entries per BIH/Me
 constexpr int kVmWords = 768, kVmHitWords = 17, kVmListR = 7 + kVmHitWords, kVmInstR = 10, kVmBoundR = 5, kVmIbR = 4, kVmDiffFixed = 10 + kVmHitWords,
               kVmIsectWords = 11, kVmBihFixedR = 12 + kVmHitWords, kVmBihFixedS = 12;
 constexpr int kVmIsectChain = 8;   // Intersection frames the commit-time estimate allows for (a chain longer than the memory is caught at run time)
-constexpr int kCsgMaxAdvance = 32; // ray-advance steps per CSG node before giving up (reference: unbounded)
+constexpr int kCsgMaxAdvance = 32; // ray-advance steps per Difference the generic tier's commit-time frame estimate allows for (at run time: its frame memory)
+constexpr int kCsgFlatAdvance = 256; // ray-advance steps per CSG item of the flat tier (its list of advances is a fixed array; reference: unbounded)
 constexpr int kIsectFrames = 40;   // explicit frames for rayint_intersection's list recursion (flat tier's CSG items)
-constexpr int kMaxTraceDepth = 4;  // maxdepth values the render kernels are instantiated for
-constexpr int kMaxMatNest = 2;
-constexpr int kMaxBatchFrames = 16;  // frames one render launch can carry     // Blend / AdditiveLayers nesting the shader is instantiated for
+constexpr int kMaxTraceDepth = 8;  // maxdepth values the shading state machine has trace frames for (reference: any)
+constexpr int kMaxMatNest = 4;     // Blend / AdditiveLayers nesting it has material frames for (reference: any)
+constexpr int kMaxBatchFrames = 16;  // frames one render launch can carry
 
 constexpr int kPairWords = 20;  // a pair record: 18 floats, the leaf's remaining count, the first triangle's record index (80 bytes)
 

@@ -66,6 +66,7 @@ class SceneDesc:
     def innerbound(self, a, b): return self._node("innerbound", a, b)
     def flatten_transform(self, node): return self._node("flatten_transform", node)
     def tolist(self, node): return self._node("tolist", node)
+    def bih_tolist(self, node): return self._node("bih_tolist", node)  # `bih (tolist node)`: a bih of the list's items, TestScene.hs:109
 
     def triangles_bulk(self, pts9):
         """Many triangles at once (n x 9).  Returns the list of node ids."""
@@ -128,7 +129,7 @@ class SceneDesc:
                 nmap.append(getattr(backend, name)(N(args[0]), N(args[1])))
             elif name == "tex":
                 nmap.append(backend.tex(N(args[0]), mmap[args[1]]))
-            elif name in ("tag", "noshadow", "onlyshadow", "flatten_transform", "tolist"):
+            elif name in ("tag", "noshadow", "onlyshadow", "flatten_transform", "tolist", "bih_tolist"):
                 nmap.append(getattr(backend, name)(N(args[0])))
             elif name == "mesh":
                 nmap.append(backend.mesh(args[0], args[1], args[2], [mmap[m] for m in args[3]]))

@@ -133,10 +133,71 @@ def _polyhedron(sd, points, pos, r, name):
     return sd.tag(sd.intersection([sd.sphere(pos, 1.26 * r)] + planes), name)
 
 
-def testscene(lattice_n=10):
-    """GlomeView's own default scene, `geom''` of TestScene.hs:183-197 with TestScene's lights, camera and textures --
-    every item but the `oak` (TestScene.hs:68-110 draws its branching from System.Random, which is not part of the
-    reference tree): the chessboard of 64 textured boxes carved by a sphere (a Difference whose first operand is a
+class _Draws:
+    """The random draws of `oak` (TestScene.hs:68-110).  The reference takes them from System.Random (`mkStdGen 42`, `split`,
+    `randomR`): the `random` package is not part of the reference tree and its generator differs between versions, so the
+    draws are SUPPLIED AS DATA by a stated generator instead -- NOT GHC's: a SplitMix64 step per draw, `split` = two states
+    hashed from the parent's.  Same tree shape and the same ranges as the reference; the individual angles and lengths are
+    this generator's."""
+    M = (1 << 64) - 1
+
+    def __init__(self, state):
+        self.s = state & self.M
+
+    @staticmethod
+    def _mix(z):
+        M = _Draws.M
+        z = (z + 0x9E3779B97F4A7C15) & M
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        return z ^ (z >> 31)
+
+    def split(self):
+        return _Draws(self._mix(self.s ^ 0x1234567)), _Draws(self._mix(self.s ^ 0x7654321))
+
+    def randomR(self, lo, hi):
+        z = self._mix(self.s)
+        u = (z >> 11) / float(1 << 53)
+        return lo + (hi - lo) * u, _Draws(z)
+
+
+def oak(sd, age, seed=42):
+    """TestScene.hs:68-110: a tree that branches once per year -- `tree n` = a cone segment and two scaled, rotated copies of
+    `tree (n - 1)` under a bounding sphere (bound_object), `tree 1` a green sphere; the whole flattened (flatten_transform,
+    tolist) under one bih, matte brown.  age 11.4: 1,023 cones and 1,024 spheres."""
+    if age < 0:
+        return sd.group([])  # nothing
+    year = int(np.floor(age))
+    season = age - year
+    thickness, minbranch, maxbranch = 0.03, api.deg(10), api.deg(25)
+    leaf_mat = matte(sd, (0.2, 1, 0.4))
+
+    def tree(n_, r):
+        if n_ == 0:
+            return sd.group([])
+        if n_ == 1:
+            return sd.tex(sd.sphere((0, 0, 0), season), leaf_mat)
+        nf = float(n_)
+        rng1, rng2 = r.split()
+        rng3, rng4 = rng1.split()
+        r1, rng5 = rng4.randomR(0.0, 0.5)
+        r2, rng6 = rng5.randomR(minbranch, maxbranch)
+        r3, rng7 = rng6.randomR(0.8, 0.95)
+        r4, _ = rng7.randomR(0.0, 1.0)
+        seglen, branchang, scaling = 0.5 + r1, r2, r3
+        height, n = (nf / 2, int(np.ceil(nf / 2))) if r4 > 1.0 else (nf, n_)  # (never: r4 is in [0, 1], as in the reference)
+        kids = [sd.cone((0, 0, 0), thickness * height, (0, seglen, 0), thickness * (height - 1) * scaling)]
+        for sub, ang in ((rng2, branchang), (rng3, -branchang)):
+            kids.append(sd.transform(tree(n - 1, sub), [api.scale((scaling, scaling, scaling)), api.rotate((0, 0, 1), ang), api.rotate((0, 1, 0), api.deg(30)),
+                                                        api.translate((0, seglen, 0))]))
+        return sd.bound_object(sd.sphere((0, height / 2, 0), height / 2), sd.group(kids))
+
+    return sd.tag(sd.tex(sd.bih_tolist(sd.flatten_transform(tree(year, _Draws(seed)))), matte(sd, (0.8, 0.5, 0.4))), "tree")
+
+
+def testscene(lattice_n=10, with_oak=True):
+    """GlomeView's own default scene, `geom''` of TestScene.hs:183-197 with TestScene's lights, camera and textures, every
+    item of it (the `oak`'s random draws come from a stated generator, not GHC's: see _Draws): the chessboard of 64 textured boxes carved by a sphere (a Difference whose first operand is a
     transformed group), the dodecahedron and the transformed icosahedron (Intersections of a sphere with 12 / 20 planes)
     under the stripe and the perlin Blend textures, a cone, the lattice of (2n+1)^3 spheres under its own bih, rotated,
     scaled and hollowed out by a sphere, the portal (a Warp material looking into this very scene) inside a transform, and
@@ -176,8 +237,19 @@ def testscene(lattice_n=10):
     warp = sd.material_warp(frame, None, LIGHTS, api.compose([api.rotate((1, 0, 0), api.deg(-85)), api.translate((8, 40, -4))]))
     door = sd.transform(sd.group([frame, sd.tex(surface, warp)]), [api.rotate((0, 1, 0), api.deg(8)), api.translate((-3, 0.5, -5))])
     glass = sd.transform(sd.tex(sd.sphere((-2.3, 0.3, 4.2), 1.7), sd.material_refract(0.35, 0.8, 1.5)), [api.scale((1, 0.4, 1))])  # :196
-    sd.set_root(sd.bih([carved_board, dodeca, icosa, cone, hollow, door, glass]))
+    items = [carved_board, dodeca, icosa, cone]
+    if with_oak:
+        items.append(sd.transform(oak(sd, 11.4, 42), [api.scale((2, 2, 2)), api.translate((2, -1, -8))]))                 # :190
+    items += [hollow, door, glass]
+    sd.set_root(sd.bih(items))
     _common(sd, 2)
+    if with_oak:
+        # Bounds the parity checks read (tests/parity.py): every cone segment of the oak ends inside the next one and inside the two
+        # child segments' starts, and 1,024 leaf spheres sit on the twig ends -- surfaces that coincide to within fp32 rounding, so
+        # which of two primitives an fp32 ray reports at a joint differs from the fp64 checker's on 2-4 % of the hits (same distance:
+        # no hit / miss flips, no depth outliers), and a pixel on a joint takes the other primitive's normal
+        # (and a twig-end sphere is 0.1-0.2 across, ten transforms deep, 12 units from the eye: 2e-4 of hit distance is 3e-3 of its normal)
+        sd.same_prim_min, sd.pixel_outlier_max, sd.pixel_mean_max, sd.normal_atol = 0.95, 4e-3, 2e-4, 5e-3
     return sd
 
 

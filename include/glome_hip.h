@@ -111,6 +111,9 @@ int32_t glome_sb_bound_object(glome_sb*, int32_t bounding, int32_t bounded);    
 int32_t glome_sb_innerbound(glome_sb*, int32_t inner, int32_t outer);                            /* Bound.hs:116 */
 int32_t glome_sb_flatten_transform(glome_sb*, int32_t id);  /* `SolidItem (flatten_transform s)`, Solid.hs:192,273 */
 int32_t glome_sb_tolist(glome_sb*, int32_t id);             /* `tolist`, Solid.hs:177,230: a list node of the flattened items */
+/* the [SolidItem] that `tolist id` yields, as node ids: writes up to cap of them and returns their number -- what a host passes
+   on to a constructor that takes a list, e.g. TestScene.hs:109's `bih (tolist (SolidItem (flatten_transform tree)))` */
+int32_t glome_sb_list_items(glome_sb*, int32_t id, int32_t* out, int32_t cap);
 /* A whole scene in the Neutral File Format of Eric Haines' SPD (GlomeTrace/Data/Glome/Spd.hs:89-254): statements v (camera),
  * l (light, colour optional), b (background), f (fill -> Surface clr (1-T) 0 kd ks shine), s (sphere), c (cone), p / pp
  * (polygon / polygon with normals -> a triangle fan); `#` comments.  Returns the root node -- `bih` of one
@@ -219,7 +222,7 @@ typedef struct glome_render_params {
   int32_t width, height;
   int32_t mode;          /* GLOME_MODE_* */
   int32_t blocksize;     /* tile edge, Glome.hs:116 (65) */
-  int32_t maxdepth;      /* Glome.hs:25 (3); 1..4 supported */
+  int32_t maxdepth;      /* Glome.hs:25 (3); 1..8 supported */
   int32_t fog;           /* 1: TILE mode stores (r + depth/400, g, b, a, depth) exactly as renderTile does (Glome.hs:174,
                             Q20: a miss stores r = 2500); 0 -- the DEFAULT, a deliberate deviation from renderTile -- stores
                             the tuple get_color returns (Glome.hs:53-55) before that debug term */

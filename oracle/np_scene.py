@@ -142,6 +142,12 @@ class Solid:
     def get_metainfo(self, p): return ()                                           # Solid.hs:254
     def tolist(self): return [self]                                                 # Solid.hs:230
     def transform(self, xf): return Instance(self, xf)                              # Solid.hs:235 (xf = composed (fwd, inv))
+    def transform_leaf(self, xf): return self.transform(xf)                         # Solid.hs:240
+    def flatten_transform(self): return self.tolist()                               # Solid.hs:246
+
+
+def flatten_item(s):  # the SolidItem instance, Solid.hs:273: flatten_transform (SolidItem s) = [SolidItem (flatten_transform s)]
+    return Group(s.flatten_transform())
 
 
 class Sphere(Solid):  # Sphere.hs
@@ -274,6 +280,8 @@ class Group(Solid):  # the list instance, Solid.hs:326-339
         for s in self.xs: bb = bbjoin(bb, s.bound())
         return bb
     def tolist(self): return [y for s in self.xs for y in s.tolist()]
+    def transform_leaf(self, xf): return Group([x.transform_leaf(xf) for x in self.tolist()])   # Solid.hs:334
+    def flatten_transform(self): return [flatten_item(x) for x in self.xs]                     # Solid.hs:335: concat (map flatten_transform xs), xs :: [SolidItem]
     def get_metainfo(self, p):
         acc = ()
         for s in self.xs:
@@ -317,6 +325,9 @@ class Instance(Solid):  # Solid.hs:386-532
     def get_metainfo(self, p): return self.s.get_metainfo(xfm_point(self.i, p))
     def transform(self, xf):  # merges: compose ([xfm2] ++ xfm1), :494-496
         return self.s.transform((mat_mult(xf[0], self.f), mat_mult(self.i, xf[1])))
+    def transform_leaf(self, xf):  # :498-500: transform_leaf s [compose ([xfm2] ++ xfm1)]
+        return self.s.transform_leaf((mat_mult(xf[0], self.f), mat_mult(self.i, xf[1])))
+    def flatten_transform(self): return [self.s.transform_leaf((self.f, self.i))]                # :509-511
 
 
 NVZ, VZ = (0.0, 0.0, -1.0), (0.0, 0.0, 1.0)
@@ -451,6 +462,8 @@ class Bound(Solid):  # Bound.hs:27-66: sb is looked at only by rays that start i
     def inside(self, p): return self.a.inside(p) and self.b.inside(p)
     def get_metainfo(self, p): return self.b.get_metainfo(p) if self.a.inside(p) else ()
     def bound(self): return bboverlap(self.a.bound(), self.b.bound())
+    def transform_leaf(self, xf): return self.b.transform_leaf(xf)                               # Bound.hs:69-71
+    def flatten_transform(self): return [flatten_item(self.b)]                                   # Bound.hs:73-74 (sb is a SolidItem)
 
 
 class InnerBound(Solid):  # Bound.hs:93-108: sb is searched no farther than sa's hit
@@ -459,6 +472,8 @@ class InnerBound(Solid):  # Bound.hs:93-108: sb is searched no farther than sa's
     def shadow(self, o, d, dist): return self.a.shadow(o, d, dist) or self.b.shadow(o, d, dist)
     def inside(self, p): return self.a.inside(p) or self.b.inside(p)
     def bound(self): return self.b.bound()
+    def transform_leaf(self, xf): return self.b.transform_leaf(xf)                               # Bound.hs:112
+    def flatten_transform(self): return [flatten_item(self.b)]                                   # Bound.hs:111
 
 
 def orth(v1):  # Vec.hs:366-378
@@ -760,6 +775,9 @@ class Scene:
     def plane_offset(self, n, off): return self._add(Plane(tuple(n), off))  # Plane.hs:23-24
     def group(self, ids): return self._add(group([self.nodes[i] for i in ids]))
     def bih(self, ids): return self._add(Bih([self.nodes[i] for i in ids]) if ids else Void())
+    def bih_tolist(self, i):                                                        # `bih (tolist s)`, TestScene.hs:109
+        xs = self.nodes[i].tolist()
+        return self._add(Bih(xs) if xs else Void())
     def difference(self, a, b): return self._add(Difference(self.nodes[a], self.nodes[b]))
     def intersection(self, ids): return self._add(Intersection([self.nodes[i] for i in ids]))
     def transform(self, node, xfms): return self._add(self.nodes[node].transform(compose(xfms)))
@@ -782,6 +800,8 @@ class Scene:
     def disc(self, pos, n, r): return self._add(Disc(pos, n, r))
     def noshadow(self, node): return self._add(NoShadow(self.nodes[node]))
     def onlyshadow(self, node): return self._add(OnlyShadow(self.nodes[node]))
+    def flatten_transform(self, i): return self._add(flatten_item(self.nodes[i]))                # `SolidItem (flatten_transform s)`
+    def tolist(self, i): return self._add(Group(self.nodes[i].tolist()))
     def bound_object(self, a, b): return self._add(Bound(self.nodes[a], self.nodes[b]))
     def innerbound(self, a, b): return self._add(InnerBound(self.nodes[a], self.nodes[b]))
     def material_blend_fn(self, a, b, fn, params):  # TestScene.hs:213-231: Blend a b (f pos); fn 1 = perlin (pos * s), 3 = stripe axis triangle_wave

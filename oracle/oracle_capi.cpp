@@ -34,6 +34,7 @@ struct IOracle {
   virtual int bound_object(int a, int b, int inner) = 0;
   virtual int flatten_transform(int id) = 0;
   virtual int tolist_group(int id) = 0;
+  virtual int bih_tolist(int id) = 0;
   virtual int mat_surface(const double* color, double alpha, double amb, double kd, double ks, double shine) = 0;
   virtual int mat_reflect(double refl) = 0;
   virtual int mat_refract(double refl, double refr, double ior) = 0;
@@ -203,6 +204,9 @@ template <class R> struct Impl : IOracle {
   int tolist_group(int id) override {  // `tolist`, Solid.hs:177,230 -> a list solid of the flattened items
     return add(make_list<R>(get(id)->tolist()));
   }
+  int bih_tolist(int id) override {  // `bih (tolist s)`, TestScene.hs:109
+    return add(glo::bih<R>(get(id)->tolist(), nextid()));
+  }
   int addmat(const Material<R>& m) { scene.mats.push_back(m); return (int)scene.mats.size() - 1; }
   int mat_surface(const double* c, double alpha, double amb, double kd, double ks, double shine) override {  // Shader.hs:44
     Material<R> m; m.kind = M_SURFACE; m.color = {R(c[0]), R(c[1]), R(c[2])};
@@ -345,6 +349,7 @@ int glo_bound_object(void* h, int a, int b) { return guard(h, [&](IOracle* o) { 
 int glo_innerbound(void* h, int a, int b) { return guard(h, [&](IOracle* o) { return o->bound_object(a, b, 1); }); }
 int glo_flatten_transform(void* h, int id) { return guard(h, [&](IOracle* o) { return o->flatten_transform(id); }); }
 int glo_tolist(void* h, int id) { return guard(h, [&](IOracle* o) { return o->tolist_group(id); }); }
+int glo_bih_tolist(void* h, int id) { return guard(h, [&](IOracle* o) { return o->bih_tolist(id); }); }
 int glo_material_surface(void* h, const double* c, double alpha, double amb, double kd, double ks, double shine) {
   return guard(h, [&](IOracle* o) { return o->mat_surface(c, alpha, amb, kd, ks, shine); });
 }

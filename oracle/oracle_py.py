@@ -123,6 +123,7 @@ class Oracle:
     def innerbound(self, a, b): return self._chk(self.L.glo_innerbound(self.h, C.c_int(int(a)), C.c_int(int(b))), "glo_innerbound")
     def flatten_transform(self, node): return self._chk(self.L.glo_flatten_transform(self.h, C.c_int(int(node))), "glo_flatten_transform")
     def tolist(self, node): return self._chk(self.L.glo_tolist(self.h, C.c_int(int(node))), "glo_tolist")
+    def bih_tolist(self, node): return self._chk(self.L.glo_bih_tolist(self.h, C.c_int(int(node))), "glo_bih_tolist")
     def material_surface(self, color, alpha, amb, kd, ks, shine): return self._call("glo_material_surface", color, float(alpha), float(amb), float(kd), float(ks), float(shine))
     def material_reflect(self, refl): return self._call("glo_material_reflect", float(refl))
     def material_refract(self, refl, refr, ior): return self._call("glo_material_refract", float(refl), float(refr), float(ior))

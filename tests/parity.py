@@ -41,8 +41,10 @@ def check_rays(backend_rayint, backend_shadow, backend_inside, sd, nm, n=20000, 
     assert np.mean(err > T_RTOL) <= OUTLIER_MAX, f"t outliers {np.mean(err > T_RTOL)} (max {emax})"
     both = (got["t"] >= 0) & (ref["t"] >= 0)
     inv, invo = id_maps(nm, om)
-    same_prim = inv[got["prim"][both]] == invo[ref["prim"][both]]
-    assert same_prim.mean() > 0.995, f"primitive agreement {same_prim.mean()}"  # coplanar faces tie differently in fp32
+    known = invo[ref["prim"][both]] >= 0  # (primitives a constructor made inside the backend -- flatten_transform's -- have no common id)
+    same_prim = (inv[got["prim"][both]] == invo[ref["prim"][both]]) & known
+    # coplanar faces tie differently in fp32; a scene may state a lower bar with its reason (scenes.testscene: the oak's overlapping joints)
+    assert same_prim[known].mean() > getattr(sd, "same_prim_min", 0.995), f"primitive agreement {same_prim[known].mean()}"
     tex_ok = np.all(got["tex"][both] == ref["tex"][both], axis=1)
     assert np.mean(tex_ok[same_prim]) > 0.999, "texture stacks differ on the same primitive"
     nerr = np.abs(got["n"][both] - ref["n"][both]).max(axis=1)
@@ -56,7 +58,7 @@ def check_rays(backend_rayint, backend_shadow, backend_inside, sd, nm, n=20000, 
     io = o.inside(om[sd.root], pts.astype(np.float64))
     ig = backend_inside(pts)
     assert np.mean(io != ig) <= MISMATCH_MAX, f"inside mismatch {np.mean(io != ig)}"
-    lv = {"mismatch": mism, "t_err_max": emax, "t_outliers": float(np.mean(err > T_RTOL)) if err.size else 0.0, "same_prim": float(same_prim.mean()),
+    lv = {"mismatch": mism, "t_err_max": emax, "t_outliers": float(np.mean(err > T_RTOL)) if err.size else 0.0, "same_prim": float(same_prim[known].mean()),
           "shadow_mismatch": float(np.mean(so != sg)), "inside_mismatch": float(np.mean(io != ig)), "hit_frac": float(np.mean(ref["t"] >= 0))}
     _log("rays", sd, lv)
     return lv

@@ -23,16 +23,17 @@ def load_gold(name):
     return mg, json.load(open(os.path.join(GOLD, name + ".json")))
 
 
-def compare_backend_to_gold(g, got, got_shadow, img, nm):
+def compare_backend_to_gold(g, got, got_shadow, img, nm, same_prim_min=0.97, normal_atol=2e-3):
     t = np.asarray(g["t"])
     assert np.array_equal(got["t"] >= 0, t >= 0)
     h = t >= 0
     assert np.allclose(got["t"][h], t[h], rtol=2e-4, atol=1e-5)
     inv = np.full(max(nm) + 2, -1); inv[np.asarray(nm)] = np.arange(len(nm))
-    same = inv[got["prim"][h]] == np.asarray(g["prim"])[h]
-    assert same.mean() > 0.97
+    gp = np.asarray(g["prim"])[h]
+    same = (inv[got["prim"][h]] == gp) & (gp >= 0)  # (primitives a constructor made inside the backend -- flatten_transform's -- have no common id)
+    assert same[gp >= 0].mean() > same_prim_min  # (a scene may state a lower bar with its reason: parity.same_prim_min)
     assert np.array_equal(got["tex"][h][same], np.asarray(g["tex"])[h][same])
-    assert np.allclose(got["n"][h][same], np.asarray(g["n"])[h][same], atol=2e-3)
+    assert np.allclose(got["n"][h][same], np.asarray(g["n"])[h][same], atol=normal_atol)
     assert np.array_equal(got_shadow, np.asarray(g["shadow"], bool))
     ref = np.asarray(g["image"]["rgbad"]).reshape(g["image"]["h"], g["image"]["w"], 5)
     e = (np.abs(img[..., :4] - ref[..., :4]) / np.maximum(1, np.abs(ref[..., :4]))).max(-1)
@@ -62,4 +63,4 @@ def test_device_code_on_host_matches_golden(built, name):
     ro, rd = mg.golden_inputs()
     cam, lights = product_camera_lights(sd)
     img, _ = hs.render(cam, lights, g["image"]["w"], g["image"]["h"], g["image"]["maxdepth"])
-    compare_backend_to_gold(g, hs.rayint(ro, rd), hs.shadow(ro, rd, np.full(len(ro), g["shadow_tmax"], np.float32)), img, nm)
+    compare_backend_to_gold(g, hs.rayint(ro, rd), hs.shadow(ro, rd, np.full(len(ro), g["shadow_tmax"], np.float32)), img, nm, getattr(sd, "same_prim_min", 0.97), getattr(sd, "normal_atol", 2e-3))

@@ -294,6 +294,20 @@ def test_full_size_csg_vs_oracle_tile_sample(gpu_ctx, name, tier):
     sc.release()
 
 
+def test_limits_lifted_in_round_3(gpu_ctx):
+    """maxdepth 8 between two facing mirrors and four levels of nested Blend / AdditiveLayers (zoo.hall_of_mirrors) against the
+    oracle, both render modes (until round 3: maxdepth <= 4, nesting <= 2)."""
+    sd = zoo.hall_of_mirrors()
+    b, nm, sc = commit(gpu_ctx, sd)
+    cam, lights = product_camera_lights(sd)
+    img, packed, st = sc.render(cam, lights, api.render_params(width=240, height=160, maxdepth=8))
+    parity.check_image(img, (st["rays_primary"], st["rays_shadow"], st["rays_secondary"]), sd, 240, 160, 8)
+    assert st["rays_secondary"] > st["rays_primary"]  # (the hall is mostly mirror)
+    img, packed, st = sc.render(cam, lights, api.render_params(width=195, height=130, mode=1, maxdepth=6))
+    parity.check_subsample_image(img, (st["rays_primary"], st["rays_shadow"], st["rays_secondary"]), sd, 195, 130, 6)
+    sc.release()
+
+
 @pytest.mark.parametrize("name,w,h", [("S1", 720, 480), ("S3small", 131, 66), ("materials", 200, 150), ("S4", 260, 195), ("mesh", 130, 65)])
 def test_adaptive_sampler_vs_oracle(gpu_ctx, name, w, h):
     """GLOME_MODE_SUBSAMPLE = renderTileSubsample (Glome.hs:226-323), incl. S1 at BASELINE configs[0..1]'s 720x480."""

@@ -108,6 +108,20 @@ def test_quirks_survive_flattening(built):
     assert hs.rayint([[.25, .25, -1]], [[0, 0, 1]])["t"][0] == pytest.approx(1) and not hs.shadow([[.25, .25, -1]], [[0, 0, 1]], 5.0)[0]
 
 
+def test_limits_lifted_in_round_3(built):
+    """maxdepth 8 (two facing mirrors) and four levels of nested Blend / AdditiveLayers materials: the shading state machine's
+    trace and material frames (rt_device.hpp shade_vm) against the oracle's recursion; maxdepth 9 is still refused by the C ABI."""
+    sd = zoo.hall_of_mirrors()
+    b = api.Builder()
+    nm, _ = sd.replay(b)
+    hs = HostSim(b, nm[sd.root])
+    cam, lights = product_camera_lights(sd)
+    for md in (8, 5):
+        img, cnt = hs.render(cam, lights, 120, 80, md)
+        c = parity.check_image(img, [int(x) for x in cnt], sd, 120, 80, md)
+    assert int(cnt[2]) > 0
+
+
 @pytest.mark.parametrize("name,w,h", [("S1", 200, 150), ("S3small", 131, 66), ("materials", 160, 90), ("S4", 130, 130)])
 def test_adaptive_sampler(built, name, w, h):
     """renderTileSubsample (Glome.hs:226-323): ragged tiles (200 = 3*65 + 5), 5 passes, sub-pixel pass-5 samples."""

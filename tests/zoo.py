@@ -161,6 +161,30 @@ def textures():
     return sd
 
 
+def hall_of_mirrors():
+    """The limits lifted in round 3 (the reference has none: Trace.hs:59-82 recurses to any maxdepth, Shader.hs:177-184 nests
+    Blend / AdditiveLayers freely): two facing mirrors with objects between them, for maxdepth 8, and a sphere under a Blend of
+    an AdditiveLayers of a Blend of an AdditiveLayers -- four levels of nested materials."""
+    sd = SceneDesc()
+    m = scenes.materials(sd)
+    red = sd.material_surface((0.9, 0.2, 0.2), 1, 0.2, 0.7, 0.3, 8)
+    blue = scenes.matte(sd, (0.15, 0.3, 0.8))
+    l1 = sd.material_layers([sd.material_surface((0.2, 0.9, 0.2), 0.5, 0.3, 0.6, 0.2, 6), blue])
+    b2 = sd.material_blend(l1, red, 0.35)
+    l3 = sd.material_layers([b2, sd.material_surface((0.9, 0.9, 0.1), 0.3, 0.2, 0.5, 0, 0)])
+    b4 = sd.material_blend(l3, m["mirror"], 0.6)
+    pl = sd.tex(sd.plane((0, 0, 0), (0, 1, 0)), scenes.matte(sd, (0.3, 0.7, 0.4)))
+    items = [
+        sd.tex(sd.box((-6, 0, -3.2), (6, 5, -3.0)), m["mirror"]),   # two walls of mirror facing each other
+        sd.tex(sd.box((-6, 0, 3.0), (6, 5, 3.2)), m["mirror"]),
+        sd.tex(sd.sphere((-1.5, 1, 0), 1.0), b4),
+        sd.tex(sd.sphere((1.8, 0.8, 0.6), 0.8), red),
+        sd.tex(sd.box((3.5, 0, -1), (4.2, 2.2, 0)), blue),
+    ]
+    sd.set_camera((-5.5, 2.2, 2.4), (1.0, 1.2, -3.1), (0, 1, 0), 55)
+    return _finish(sd, sd.group([pl, sd.bih(items)]))
+
+
 ALL = {"flat_mixed": flat_mixed, "quadrics": quadrics, "csg": csg, "nested": nested, "mesh": mesh_scene, "materials": materials, "textures": textures}
 
 
