@@ -164,8 +164,8 @@ def load():
         pass
     lib = C.CDLL(LIB_PATH)
     for name, res, args in SYMBOLS:
-        if name == "glome_ctx_debug_words" and os.environ.get("GLOME_DEBUG_LIB") and not hasattr(lib, name):
-            continue  # (an older build of the library loaded for an A/B measurement: the debugging aid came in round 3)
+        if os.environ.get("GLOME_DEBUG_LIB") and not hasattr(lib, name):
+            continue  # (an older build of the library loaded for an A/B measurement may lack entries that came later)
         f = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         f.restype = res
         f.argtypes = args
