@@ -9,9 +9,8 @@
 //                   (bih_tri_wave: wave-uniform node reference, scalar loads, per-lane intervals; the production
 //                   triangle walk is hand-written, bih_packet_asm.hpp); everything else traverses per lane with its
 //                   stack in LDS (one column per lane, conflict-free).
-//   generic tier -- arbitrary nesting (Instance, CSG, Bound, nested BIH): an interpreter whose
-//                   recursion is unrolled at compile time (rayint_g<D> calls rayint_g<D-1>), so
-//                   the call graph is static and the stacks are fixed-size scratch.
+//   generic tier -- arbitrary nesting (Instance, CSG, Bound, nested BIH): rt_generic.hpp, the four class methods as loops
+//                   over explicit frames in a word stack per ray (no recursion, no nesting limit but the frame memory).
 #pragma once
 #include "rt_types.h"
 
@@ -21,11 +20,11 @@
 #define GD __device__ __forceinline__
 #define GDN __device__ __noinline__
 #define GHD __host__ __device__ inline
-#else
-// Host compilation exists for the CPU test suite only (tests/hostsim compiles these headers with g++ to check the
-// traversal / shading logic and the flattened layout without a GPU): the shim supplies GD / GHD, the bit casts, a one-lane
-// "wave" (wave_ballot, uni, ld4u, ...) and a host LaneStack.  Nothing in the product includes it.
-#include "host_shim.hpp"
+#elif !defined(GLOME_DEVICE_HEADERS_ON_HOST)
+// This is device code.  (The CPU test suite compiles these headers with g++ to check the traversal / shading logic without a
+// GPU: its translation unit defines GLOME_DEVICE_HEADERS_ON_HOST after supplying GD / GHD, the bit casts, a one-lane "wave"
+// (wave_ballot, uni, ld4u, ...), dir_rcp and a LaneStack of its own.  The product includes nothing of that.)
+#error "rt_device.hpp is device code: compile it with hipcc"
 #endif
 
 namespace glome {
@@ -115,10 +114,10 @@ struct Cnt {  // per-lane work counters (only live when COUNT)
 // 2.5 ulp) but loses that licence on some after hoisting them, and those come out correctly rounded: a last-bit disagreement
 // between a leaf's interval and its item's slab that the generic tier's loop showed on 1 shadow ray in 10,000 (found by the
 // GPU fuzz soak; the host build divides exactly everywhere and never saw it).
-#ifdef __HIP_DEVICE_COMPILE__
+#if defined(__HIP_DEVICE_COMPILE__)
 GD float dir_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-#else
-GD float dir_rcp(float x) { return 1.0f / x; }
+#elif defined(__HIPCC__)
+GD float dir_rcp(float x) { return 1.0f / x; }  // (hipcc's host pass: never called there)
 #endif
 
 // ------------------------------------------------------------------ slab tests (Vec.hs:725-762)

@@ -2,8 +2,10 @@
 // (tests/hostsim): the function-attribute macros, the bit casts, a one-lane "wave" and a host LaneStack.  With one lane a
 // packet walk is a single-ray traversal, so the same traversal / shading logic the kernels run is checked against the
 // oracle on a GPU-less machine; the wave intrinsics, the scalar loads and the hand-written assembly are device-only and are
-// covered by the -m gpu suite.  Nothing in the product includes this file.
+// covered by the -m gpu suite.  Nothing in the product includes this file: the test build includes it FIRST, and the device
+// headers then see GLOME_DEVICE_HEADERS_ON_HOST.
 #pragma once
+#define GLOME_DEVICE_HEADERS_ON_HOST 1
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -27,6 +29,10 @@ GD uint32_t first_lane_value(LaneMask, uint32_t v) { return v; }
 GD F4 ld4u(const F4* p, uint32_t i) { return p[i]; }
 GD void ld_tri_u(const F4* p, uint32_t tri, F4& q0, F4& q1, F4& q2) { q0 = p[3 * tri]; q1 = p[3 * tri + 1]; q2 = p[3 * tri + 2]; }
 GD int wave_count(bool pred) { return pred ? 64 : 0;  }
+// 1 / (a direction component): the device takes v_rcp_f32 (1 ulp) everywhere; the host build divides exactly.  The one place
+// the last bit of it decides something -- a box ending on a split plane -- is held against the GPU by
+// test_gpu_equals_the_host_build_where_boxes_end_on_split_planes on many seeds.
+GD float dir_rcp(float x) { return 1.0f / x; }
 
 // one column per "lane" with stride 1; a packet entry keeps its one-bit lane mask in bit 31 of the reference
 struct LaneStack {

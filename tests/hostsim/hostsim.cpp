@@ -5,6 +5,7 @@
 #include <cstring>
 #include <set>
 
+#include "host_shim.hpp"  // first: GD / GHD, the one-lane wave, LaneStack -- then the device headers compile for the host
 #include "../../glome_amd/csrc/capi_shared.hpp"
 #include "../../glome_amd/csrc/flatten.hpp"
 #include "../../glome_amd/csrc/rt_device.hpp"

@@ -157,7 +157,7 @@ def textures():
     sd = _finish(sd, sd.group([pl, sd.bih(items)]))
     # square_wave / the stripe edges are step functions of the hit point: an fp32 hit point a few ulp from an edge takes the
     # other material (measured on MI355X: 25 of 57,600 pixels, errors up to 0.2); everything else is at the usual level
-    sd.pixel_outlier_max, sd.pixel_mean_max = 1e-3, 2e-4
+    sd.pixel_outlier_max, sd.pixel_mean_max, sd.rel_outlier_max = 1e-3, 2e-4, 1e-2
     return sd
 
 
