@@ -273,32 +273,53 @@ def main():
     roofline = {"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None, "kernel": kname, "kernel_ms": round(kernel_ms, 4),
                 "kernel_ms_all": [round(x, 4) for x in lone_ms], "launch_shape": f"1 launch in flight, {G_lone} frame(s) per launch, rank 0's tiles", "ceilings": None,
                 "pmc_source": None, "model": model}
-    cands = sorted(glob.glob(os.path.join(HERE, "profiles", f"r*_pmc_{args.scene}_mode{args.mode}.json")))
+    # the newest committed counter pass of this scene and mode, by round number (r9 < r10), made from THESE kernel sources
+    import re
+    cands = sorted(glob.glob(os.path.join(HERE, "profiles", f"r*_pmc_{args.scene}_mode{args.mode}.json")),
+                   key=lambda p: (int(re.match(r"r(\d+)", os.path.basename(p)).group(1)), os.path.basename(p)))
     if cands and world == 1:
         try:
+            sys.path.insert(0, os.path.join(HERE, "tools"))
+            from pmc_roofline import source_sha16
             pm = json.load(open(cands[-1]))
+            roofline["pmc_source"] = os.path.relpath(cands[-1], HERE)
+            if pm.get("source_sha16") and pm["source_sha16"] != source_sha16(HERE):
+                # counters of another build say nothing about this one: no fractions rather than stale ones
+                roofline.update({"stale": True, "note": "the committed counter pass was made from other kernel sources than the library timed here: re-run tools/pmc_roofline.sh"})
+                raise StopIteration
             cn = pm["counters"]
             sc_ = G_lone / float(pm["frames_per_launch"])  # counts are proportional to the frames a launch carries
-            clock_hz = float(pm["clock_ghz"]) * 1e9
+            clock_hz = float(pm.get("clock_ghz") or 2.35) * 1e9
             cyc = kernel_s * clock_hz  # cycles of one CU over the launch
             hbm_bytes = (cn["FETCH_SIZE"] * 2.0 + cn["WRITE_SIZE"]) * 1024.0 * sc_  # KiB; gfx950 FETCH_SIZE reads half (MI355X_MICROARCH.md, HBM)
             l2_bytes = cn["TCC_REQ_sum"] * 128.0 * sc_                               # an upper bound: every request priced as a full 128-B line
-            sal = (cn["SQ_INSTS_SALU"] + cn["SQ_INSTS_SMEM"]) * sc_
+            sal = (cn["SQ_INSTS_SALU"] + cn["SQ_INSTS_SMEM"] + cn["SQ_INSTS_BRANCH"]) * sc_
+            allin = sal + (cn["SQ_INSTS_VALU"] + cn.get("SQ_INSTS_LDS", 0.0) + cn.get("SQ_INSTS_VMEM_RD", 0.0) + cn.get("SQ_INSTS_VMEM_WR", 0.0)) * sc_
+            # issue peaks measured on this GPU (tools/probe/valu_rate.hip, profiles/r03_valu_rate.txt): a SIMD issues 0.236 scalar
+            # instructions per cycle, 0.24 vector instructions with a scalar operand (0.32-0.40 with vector operands only), and
+            # 0.43 instructions of all kinds; x 4 SIMDs per CU
             ceil = {
                 "hbm": {"achieved": round(hbm_bytes / kernel_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_bytes / kernel_s / 1e9 / HBM_PEAK_GBS, 4),
                         "note": "fabric-side bytes (FETCH_SIZE x 2 + WRITE_SIZE); Infinity-Cache hits included, so true HBM traffic is at most this"},
                 "l2": {"achieved": round(l2_bytes / kernel_s / 1e9, 1), "peak": 34500.0, "unit": "GB/s", "frac": round(l2_bytes / kernel_s / 1e9 / 34500.0, 4)},
-                "scalar_issue": {"achieved": round(sal / (cus * cyc), 4), "peak": 1.0, "unit": "scalar (SALU + SMEM) instructions per cycle per CU", "frac": round(sal / (cus * cyc), 4),
-                                 "branch_per_cycle_per_cu": round(cn["SQ_INSTS_BRANCH"] * sc_ / (cus * cyc), 4)},
-                "valu_issue": {"achieved": round(cn["SQ_INSTS_VALU"] * sc_ / (cus * cyc), 4), "peak": 2.0, "unit": "wave64 vector instructions per cycle per CU (4 SIMD-32, 2 cycles each)",
-                               "frac": round(cn["SQ_INSTS_VALU"] * sc_ / (cus * cyc) / 2.0, 4)},
+                "scalar_issue": {"achieved": round(sal / (cus * cyc), 4), "peak": 0.95, "unit": "scalar-type (SALU + SMEM + branch) instructions per cycle per CU", "frac": round(sal / (cus * cyc) / 0.95, 4)},
+                "valu_issue": {"achieved": round(cn["SQ_INSTS_VALU"] * sc_ / (cus * cyc), 4), "peak": 0.96, "unit": "wave64 vector instructions per cycle per CU (measured rate of one with a scalar operand)",
+                               "frac": round(cn["SQ_INSTS_VALU"] * sc_ / (cus * cyc) / 0.96, 4)},
+                "issue_all": {"achieved": round(allin / (cus * cyc), 4), "peak": 1.72, "unit": "instructions of all kinds per cycle per CU", "frac": round(allin / (cus * cyc) / 1.72, 4)},
             }
             top = max(ceil, key=lambda k: ceil[k]["frac"])
+            wc = cn.get("SQ_WAVE_CYCLES")
             roofline.update({"bound": top, "achieved": ceil[top]["achieved"], "peak": ceil[top]["peak"], "unit": ceil[top]["unit"], "frac": ceil[top]["frac"],
-                             "traffic": int(hbm_bytes), "ceilings": ceil, "clock_ghz": pm["clock_ghz"],
-                             "wave_wait_frac": round(cn["SQ_WAIT_ANY"] / cn["SQ_WAVE_CYCLES"], 4) if cn.get("SQ_WAVE_CYCLES") else None,
-                             "pmc_source": os.path.relpath(cands[-1], HERE), "pmc_kernel_ms": pm.get("kernel_ms"),
+                             "traffic": int(hbm_bytes), "ceilings": ceil, "clock_ghz": pm.get("clock_ghz"),
+                             "wave_wait_frac": round(cn["SQ_WAIT_ANY"] / wc, 4) if wc else None,
+                             "wave_issue_stall_frac": round(cn["SQ_WAIT_INST_ANY"] / wc, 4) if wc and cn.get("SQ_WAIT_INST_ANY") else None,
+                             "scalar_cache_hit": round(cn["SQC_DCACHE_HITS"] / (cn["SQC_DCACHE_HITS"] + cn["SQC_DCACHE_MISSES"]), 4) if cn.get("SQC_DCACHE_HITS") else None,
+                             "lane_utilisation": round(cn["SQ_THREAD_CYCLES_VALU"] / (cn["SQ_ACTIVE_INST_VALU"] * 64.0), 4) if cn.get("SQ_THREAD_CYCLES_VALU") and cn.get("SQ_ACTIVE_INST_VALU") else None,
+                             "pmc_kernel_ms": pm.get("kernel_ms"),
+                             "reading": "no pipe is near its ceiling: the waves wait (wave_wait_frac) -- a latency-bound walk; see DESIGN.md 4.6",
                              "note": "counters per launch from the committed rocprofv3 --pmc passes of this launch shape; duration measured live (HIP events); cycles = duration x the clock the counter passes measured"})
+        except StopIteration:
+            pass
         except Exception as e:  # a malformed profile must not void the bench line
             roofline["pmc_error"] = repr(e)
 

@@ -434,7 +434,11 @@ def test_gpu_equals_the_host_build_on_a_sweep_of_fuzz_scenes(gpu_ctx):
     odd = 0
     for seed in range(100, 124):
         sd = zoo.random_rig(zoo.random_composites(seed) if seed % 2 else zoo.random_flat(seed), seed)
-        b, nm, sc = commit(gpu_ctx, sd)
+        try:
+            b, nm, sc = commit(gpu_ctx, sd)
+        except api.GlomeError as e:  # (a generator may stack five textures: refused at commit)
+            assert "nested textures" in str(e), e
+            continue
         hs = HostSim(b, nm[sd.root])
         cam, lights = product_camera_lights(sd)
         img, _, st = sc.render(cam, lights, api.render_params(width=128, height=72, maxdepth=3), want_packed=False)

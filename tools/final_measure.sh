@@ -5,9 +5,10 @@ out=gpurun_out/$tag
 root=$(pwd)
 mkdir -p $out
 # 1. counter passes behind the roofline, for the launch shapes bench.py times alone
-for spec in "S3 0 8" "S5 0 8" "S4 0 8" "S3 1 8" "TS 0 8"; do set -- $spec
+round=${tag%%_*}
+for spec in "S3 0 8" "S5 0 8" "S4 0 8" "S3 1 8" "S5 1 8" "S1 0 8" "S2 0 8" "S2 1 8" "S3mesh 0 8" "S5mesh 0 8" "TS 0 8" "TS 1 8"; do set -- $spec   # every line bench.py can print
   tools/pmc_roofline.sh $tag $1 $2 $3 > $out/pmc_$1_mode$2.log 2>&1 || echo "pmc $1 $2 failed"
-  cp gpurun_out/${tag}_pmc_$1_mode$2.json profiles/r02_pmc_$1_mode$2.json 2>/dev/null
+  cp gpurun_out/${tag}_pmc_$1_mode$2.json profiles/${round}_pmc_$1_mode$2.json 2>/dev/null
   cp gpurun_out/${tag}_pmc_$1_mode$2.json $out/ 2>/dev/null
 done
 # 2. the bench line (default invocation) and the driver's invocation

@@ -9,48 +9,67 @@ GRBM_GUI_ACTIVE / 8 XCDs / dispatch duration (same guide, DVFS paragraph), from 
 import collections
 import csv
 import glob
+import hashlib
 import json
+import os
 import sys
 
-passdir, scene, mode, group, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
-rows = []
-for f in sorted(glob.glob(passdir + "/**/*counter_collection.csv", recursive=True)):
-    for r in csv.DictReader(open(f)):
-        rows.append((f, r))
-# dominant kernel family: by total duration over distinct dispatches
-dur = collections.defaultdict(float)
-seen = set()
-for f, r in rows:
-    key = (f, r["Dispatch_Id"])
-    if key in seen:
-        continue
-    seen.add(key)
-    dur[r["Kernel_Name"].split("(")[0]] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
-fam = max((k for k in dur if ("k_ss_frame" in k if mode != 0 else "k_render" in k)), key=lambda k: dur[k])
-per_pass = collections.defaultdict(lambda: collections.defaultdict(list))  # file -> counter -> values per dispatch
-times = collections.defaultdict(dict)
-names = set()
-for f, r in rows:
-    kn = r["Kernel_Name"].split("(")[0]
-    if fam not in kn:
-        continue
-    names.add(kn)
-    per_pass[f][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    times[f][r["Dispatch_Id"]] = (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-6  # ms
-counters, kernel_ms, clock = {}, [], None
-per_unit = 1  # dispatches that make one frame group (the adaptive sampler, too, is one launch per frame)
-for f, cs in per_pass.items():
-    t = list(times[f].values())
-    n_units = max(1, len(t) // per_unit)
-    ms = sum(t) / n_units
-    kernel_ms.append(ms)
-    for c, v in cs.items():
-        counters[c] = sum(v) / n_units
-    if "GRBM_GUI_ACTIVE" in cs:
-        clock = (sum(cs["GRBM_GUI_ACTIVE"]) / n_units) / 8.0 / (ms * 1e-3) / 1e9
-res = {"scene": scene, "mode": mode, "kernel": sorted(names), "frames_per_launch": group, "launches_per_pass": max(len(t) // per_unit for t in times.values()) if times else 0,
-       "kernel_ms": round(sum(kernel_ms) / max(1, len(kernel_ms)), 4), "kernel_ms_per_pass": [round(x, 4) for x in kernel_ms], "clock_ghz": round(clock, 4) if clock else None,
-       "counters": {k: round(v, 1) for k, v in sorted(counters.items())},
-       "how": "tools/pmc_roofline.sh: one rocprofv3 --kernel-trace --pmc pass per counter group over tools/pmc_run.py (lanes 1: one launch in flight); means per launch of the dominant kernel"}
-json.dump(res, open(out, "w"), indent=1)
-print(json.dumps(res))
+
+def source_sha16(root):
+    """what bench.py compares a profile with: a hash of the kernel sources the library is built from"""
+    h = hashlib.sha256()
+    for d in ("glome_amd/csrc", "include"):
+        for f in sorted(os.listdir(os.path.join(root, d))):
+            if f.endswith((".hpp", ".h", ".hip", ".cpp")):
+                h.update(f.encode()); h.update(open(os.path.join(root, d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def main():
+    passdir, scene, mode, group, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    rows = []
+    for f in sorted(glob.glob(passdir + "/**/*counter_collection.csv", recursive=True)):
+        for r in csv.DictReader(open(f)):
+            rows.append((f, r))
+    # dominant kernel family: by total duration over distinct dispatches
+    dur = collections.defaultdict(float)
+    seen = set()
+    for f, r in rows:
+        key = (f, r["Dispatch_Id"])
+        if key in seen:
+            continue
+        seen.add(key)
+        dur[r["Kernel_Name"].split("(")[0]] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    fam = max((k for k in dur if ("k_ss_frame" in k if mode != 0 else "k_render" in k)), key=lambda k: dur[k])
+    per_pass = collections.defaultdict(lambda: collections.defaultdict(list))  # file -> counter -> values per dispatch
+    times = collections.defaultdict(dict)
+    names = set()
+    for f, r in rows:
+        kn = r["Kernel_Name"].split("(")[0]
+        if fam not in kn:
+            continue
+        names.add(kn)
+        per_pass[f][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        times[f][r["Dispatch_Id"]] = (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-6  # ms
+    counters, kernel_ms, clock = {}, [], None
+    per_unit = 1  # dispatches that make one frame group (the adaptive sampler, too, is one launch per frame)
+    for f, cs in per_pass.items():
+        t = list(times[f].values())
+        n_units = max(1, len(t) // per_unit)
+        ms = sum(t) / n_units
+        kernel_ms.append(ms)
+        for c, v in cs.items():
+            counters[c] = sum(v) / n_units
+        if "GRBM_GUI_ACTIVE" in cs:
+            clock = (sum(cs["GRBM_GUI_ACTIVE"]) / n_units) / 8.0 / (ms * 1e-3) / 1e9
+    res = {"scene": scene, "mode": mode, "kernel": sorted(names), "frames_per_launch": group, "launches_per_pass": max(len(t) // per_unit for t in times.values()) if times else 0,
+           "kernel_ms": round(sum(kernel_ms) / max(1, len(kernel_ms)), 4), "kernel_ms_per_pass": [round(x, 4) for x in kernel_ms], "clock_ghz": round(clock, 4) if clock else None,
+           "counters": {k: round(v, 1) for k, v in sorted(counters.items())},
+           "source_sha16": source_sha16(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),
+           "how": "tools/pmc_roofline.sh: one rocprofv3 --kernel-trace --pmc pass per counter group over tools/pmc_run.py (lanes 1: one launch in flight); means per launch of the dominant kernel"}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
