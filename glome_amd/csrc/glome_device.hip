@@ -649,6 +649,9 @@ __global__ void k_tiles_blit_packed(const DTile* tiles, int ntiles, int width, c
 
 // ------------------------------------------------------------------------------------------------ kernel instances by part
 // Every instance the host runtime can ask for, listed once; the part that holds an instance defines the launcher that knows it.
+#ifndef GLOME_CSG_LB
+#define GLOME_CSG_LB 2  // waves per SIMD of the (CSG | primitives) instances
+#endif
 #ifndef GLOME_FLAG_LB
 #define GLOME_FLAG_LB 6  // waves per SIMD of the flagship instance (two stack rows, every ray a packet)
 #endif
@@ -662,13 +665,15 @@ constexpr int ss_flat_key(bool U, int CLS, int LB, bool TWO, bool F) { return (F
 #define GLOME_RENDER_FLAT_P2(X) /* production, full (secondary rays, nested materials) */                                   \
   X(false, false, true, CLS_BIH_TRI, 1, false) X(false, false, true, (CLS_BIH_SPHERE | CLS_PRIMS), 1, false) X(false, false, true, CLS_MESH, 1, false) \
   X(false, false, true, CLS_ALL, 1, false)
-#define GLOME_RENDER_FLAT_P3(X) /* the CSG class (two waves per SIMD: S4 0.72 -> 0.52 ms; three spill) */                    \
-  X(false, false, false, CLS_EVERY, 2, false) X(false, false, true, CLS_EVERY, 2, false)
+#define GLOME_RENDER_FLAT_P3(X) /* the CSG class (two waves per SIMD: S4 0.72 -> 0.52 ms; three spill).  Round 3: an instance of its own for scenes of CSG items and plain primitives only -- 223 / 256 registers with 0 / 17 spills where the every-class one spills 22 / 39: S4 0.455 -> 0.393 ms */                    \
+  X(false, false, false, CLS_EVERY, 2, false) X(false, false, true, CLS_EVERY, 2, false)                                     \
+  X(false, false, false, (CLS_CSG | CLS_PRIMS), GLOME_CSG_LB, false) X(false, false, true, (CLS_CSG | CLS_PRIMS), GLOME_CSG_LB, false) /* CSG items and plain primitives only (S4) */
 #define GLOME_RENDER_FLAT_P4(X) /* faithful / counting */                                                                   \
   X(true, true, true, CLS_EVERY, 1, false) X(true, true, false, CLS_EVERY, 1, false) X(false, true, true, CLS_EVERY, 1, false) X(false, true, false, CLS_EVERY, 1, false)
 // k_ss_frame_flat<FULL, CLS, LB, TWO_ROWS, FAITHFUL>
 #define GLOME_SS_FLAT_P5(X) X(false, CLS_BIH_TRI, 5, true, false) X(false, CLS_BIH_TRI, 4, true, false) X(false, CLS_BIH_TRI, 1, false, false) X(true, CLS_BIH_TRI, 1, false, false)
-#define GLOME_SS_FLAT_P9(X) X(true, CLS_EVERY, 1, false, true) X(false, CLS_EVERY, 2, false, false) X(true, CLS_EVERY, 2, false, false)
+#define GLOME_SS_FLAT_P9(X) X(true, CLS_EVERY, 1, false, true) X(false, CLS_EVERY, 2, false, false) X(true, CLS_EVERY, 2, false, false) \
+  X(false, (CLS_CSG | CLS_PRIMS), 2, false, false) X(true, (CLS_CSG | CLS_PRIMS), 2, false, false)
 constexpr int kParts = 10;
 
 #define GLOME_TRY_RENDER_FLAT(F, C, U, K, B, T)                                                                                                   \
@@ -1136,7 +1141,7 @@ static int reset_counters(glome_ctx* ctx) {
 
 static int scene_class(const glome_scene* s) {  // scene class -> the smallest kernel instance that covers it (SPECIALIZE analogue, Bih.hs:370-374)
   int m = s->cls_mask;
-  if (m & CLS_CSG) return CLS_EVERY;
+  if (m & CLS_CSG) return (m & ~(CLS_CSG | CLS_PRIMS)) == 0 ? (CLS_CSG | CLS_PRIMS) : CLS_EVERY;
   return (m & ~CLS_BIH_TRI) == 0 ? CLS_BIH_TRI : ((m & ~(CLS_BIH_SPHERE | CLS_PRIMS)) == 0 ? (CLS_BIH_SPHERE | CLS_PRIMS) : ((m & ~CLS_MESH) == 0 ? CLS_MESH : CLS_ALL));
 }
 // every ray of the frame is walked as a packet (see k_render_flat): two stack rows per entry, six waves per SIMD
@@ -1167,7 +1172,7 @@ static bool launch_render(glome_scene* s, const DRenderArgs& A, const glome_rend
   else if (count) key = render_flat_key(false, true, full, CLS_EVERY, 1, false);
   else {
     const int cls = scene_class(s);
-    key = render_flat_key(false, false, full, cls, cls == CLS_EVERY ? 2 : 1, false);
+    key = render_flat_key(false, false, full, cls, cls == CLS_EVERY ? 2 : (cls == (CLS_CSG | CLS_PRIMS) ? GLOME_CSG_LB : 1), false);
   }
   return launch_render_flat(key, L, A);
 }
@@ -1275,7 +1280,7 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
     else if (tri && !refr) key = ss_flat_key(true, CLS_BIH_TRI, 1, false, false);
     // (a Refract material traced deeper than the primary ray: the reference's own traversal, see launch_render)
     else if (full && refr) key = ss_flat_key(true, CLS_EVERY, 1, false, true);
-    else key = ss_flat_key(full, CLS_EVERY, 2, false, false);
+    else key = ss_flat_key(full, scene_class(s) == (CLS_CSG | CLS_PRIMS) ? (CLS_CSG | CLS_PRIMS) : CLS_EVERY, 2, false, false);
     if (s->dev.tier != 0) launch_ss_generic(tgrid, ctx->stream, A);
     else if (!launch_ss_flat(key, L, A)) { ctx->err = "no sampler kernel instance for this scene class (build error)"; return GLOME_E_INVALID; }
     HIPCHK(ctx, hipGetLastError());
