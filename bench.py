@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--scene", default="S3", help="S1 S2 S3 S3mesh S4 S5, or TS = GlomeView's own default scene (default: the headline workload S3)")
+    ap.add_argument("--scene", default="S3", help="S1 S2 S3 S3mesh S4 S5 S5mesh, TS = GlomeView's own default scene, TSnooak = the same without the oak (default: the headline workload S3)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--mode", type=int, default=0, help="0 = renderTile (1 ray/pixel), 1 = renderTileSubsample (adaptive)")
     ap.add_argument("--lanes", type=int, default=4, help="launches kept in flight per GPU (HIP streams / context slots)")

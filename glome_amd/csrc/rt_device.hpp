@@ -1558,33 +1558,44 @@ struct VMTrace {  // one `trace` in progress: over `root` (a record; the scene's
 struct VMMat {    // one material being evaluated: k = children done so far, tmp (and aux) = what they have contributed
   uint32_t mat; uint32_t k; CA tmp; float aux;
 };
+// The state machine as an object, so that a lane can begin a new trace while its neighbours are still in theirs (the generic
+// tier's pixel loop refills idle lanes: glome_device.hip render_loop_lanes): start() a trace, round() until idle().
 template <class TIER>
-GD CA shade_vm(TIER& T, const Ray& ray0, float tmax, int maxdepth, bool valid, HitG* hout) {
+struct ShadeVM {
   enum : int { S_NEED_HIT, S_HIT, S_TEX, S_MAT_NEW, S_NEED_LIGHTS, S_MAT_CHILD, S_MAT_TRACED, S_MAT_RET, S_TRACE_RET, S_DONE };
   VMTrace tr[kMaxTraceDepth];
   VMMat ms[kMaxTraceDepth * (kMaxMatNest + 1)];
-  const DScene& S = T.S;
   int tl = 0, mi = 0, st = S_DONE;
-  CA ret = ca(0, 0, 0, 0);
+  CA ret;
   float vm_depth = kInf;
-  *hout = hit_miss();
-  if (valid && maxdepth > 0) { tr[0].ray = ray0; tr[0].tmax = tmax; tr[0].recurs = maxdepth; tr[0].mbase = 0; tr[0].root = S.root_rec; tr[0].lset = 0xffffffffu; st = S_NEED_HIT; }
-  for (;;) {
-    // ---- the wave's requests: every lane that waits for a closest hit is traced now, together (so are the light lists)
-    const bool wh = st == S_NEED_HIT;
+  HitG h0;  // the primary hit (what trace_primary hands out)
+  GD void start(const DScene& S, const Ray& ray0, float tmax, int maxdepth, bool valid) {
+    tl = 0; mi = 0; st = S_DONE; ret = ca(0, 0, 0, 0); vm_depth = kInf; h0 = hit_miss();
+    tr[0].ray = ray0; tr[0].tmax = tmax;
+    if (valid && maxdepth > 0) { tr[0].recurs = maxdepth; tr[0].mbase = 0; tr[0].root = S.root_rec; tr[0].lset = 0xffffffffu; st = S_NEED_HIT; }
+  }
+  GD bool idle() const { return st == S_DONE; }
+  GD bool wants_hit() const { return st == S_NEED_HIT; }
+  GD bool wants_lights() const { return st == S_NEED_LIGHTS; }
+  // one round: the wave's requests (every lane that waits for a closest hit is traced now, together; so are the light lists),
+  // then this lane's own steps until it needs the wave again.  All lanes of the wave call it together.
+  // serve: 3 = both kinds of request, 1 = closest hits only, 2 = light lists only (a caller that refills lanes serves the kind
+  // more lanes wait for, so that neither call runs for a handful of lanes)
+  GD void round(TIER& T, int serve = 3) {
+    const DScene& S = T.S;
+    const bool wh = st == S_NEED_HIT && (serve & 1);
     if (wave_any(wh)) {
-      const Ray r = wh ? tr[tl].ray : ray0;
-      const HitG h = T.closest_wave(r, wh ? tr[tl].tmax : tmax, wh, wh ? tr[tl].root : S.root_rec);
-      if (wh) { tr[tl].h = h; if constexpr (TIER::WARP) { tr[tl].lo = h.lo; tr[tl].ld = h.ld; } if (tl == 0) *hout = h; st = S_HIT; }
+      const Ray r = tr[wh ? tl : 0].ray;
+      const HitG h = T.closest_wave(r, tr[wh ? tl : 0].tmax, wh, wh ? tr[tl].root : S.root_rec);
+      if (wh) { tr[tl].h = h; if constexpr (TIER::WARP) { tr[tl].lo = h.lo; tr[tl].ld = h.ld; } if (tl == 0) h0 = h; st = S_HIT; }
     }
-    const bool wl = st == S_NEED_LIGHTS;
+    const bool wl = st == S_NEED_LIGHTS && (serve & 2);
     if (wave_any(wl)) {
       uint32_t m;
       if constexpr (TIER::WARP) m = wl ? preshade(T, tr[tl].h, light_set(T, tr[tl].lset), tr[tl].root) : 0u;  // lights and root may differ lane by lane
       else m = preshade_wave(T, tr[wl ? tl : 0].h, wl);
       if (wl) { tr[tl].lc.mask = m; tr[tl].lc.done = true; st = S_MAT_NEW; }
     }
-    if (!wave_any(st != S_DONE)) break;
     // ---- this lane's own steps, until it needs the wave again
     while (st != S_DONE && st != S_NEED_HIT && st != S_NEED_LIGHTS) {
       VMTrace& t = tr[tl];
@@ -1707,7 +1718,14 @@ GD CA shade_vm(TIER& T, const Ray& ray0, float tmax, int maxdepth, bool valid, H
       }
     }
   }
-  return ret;
+};
+template <class TIER>
+GD CA shade_vm(TIER& T, const Ray& ray0, float tmax, int maxdepth, bool valid, HitG* hout) {
+  ShadeVM<TIER> vm;
+  vm.start(T.S, ray0, tmax, maxdepth, valid);
+  while (wave_any(!vm.idle())) vm.round(T);
+  *hout = vm.h0;
+  return vm.ret;
 }
 
 // the pixel loop's entry: `Trace.trace lights shader sld ray infinity maxdepth` (Glome.hs:33), maxdepth <= kMaxTraceDepth.
