@@ -45,7 +45,7 @@ def build(force=False, verbose=True, lib=LIB, extra_flags=None, obj_dir=None, jo
 
     todo = []
     if force or _stale(host_o, [host_src] + hdrs):
-        todo.append(["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-c", host_src, "-o", host_o])
+        todo.append(["g++", "-O2", "-std=c++17", "-fPIC", "-Wall"] + [f for f in extra if f.startswith("-D")] + ["-c", host_src, "-o", host_o])
     for k, o in enumerate(part_o):
         if force or _stale(o, [dev_src] + hdrs):
             todo.append([HIPCC] + HIPFLAGS + extra + ["-DGLOME_PART=%d" % k, "-c", dev_src, "-o", o])

@@ -69,7 +69,7 @@ struct FlatTier {
   __device__ __forceinline__ bool occluded(const Ray& r, float d, uint32_t = 0) { return occluded_flat<COUNT, CLS>(S, r, d, stk, cnt, true, &err); }
   // wave-wide calls (every lane of the wave makes them together; `valid` = the lane holds a ray): triangle and sphere
   // BIHs are walked as packets, by primary, shadow and secondary rays alike
-  static constexpr bool PACKETS = (CLS & (CLS_BIH_TRI | CLS_BIH_SPHERE)) != 0;
+  static constexpr bool PACKETS = (CLS & (CLS_BIH_TRI | CLS_BIH_SPHERE | CLS_MESH)) != 0;
   __device__ __forceinline__ HitG closest_wave(const Ray& r, float tmax, bool valid, uint32_t = 0) {
     if constexpr (PACKETS) {
       HitG ch;
@@ -150,19 +150,19 @@ __device__ __forceinline__ bool work_to_pixel(const DRenderArgs& A, uint32_t w, 
   while (lo + 1 < A.ntiles && A.tiles[lo + 1].wave_base <= w) lo++;
   DTile t = A.tiles[lo];
   uint32_t j = w - t.wave_base;
-  uint32_t nbx = t.w >> 3, nby = t.h >> 3, nblk = nbx * nby;
+  uint32_t nbx = t.w / kBlockW, nby = t.h / kBlockH, nblk = nbx * nby;
   int lx, ly;
   if (j < nblk) {
-    lx = (j % nbx) * 8 + (lane & 7);
-    ly = (j / nbx) * 8 + (lane >> 3);
+    lx = (j % nbx) * kBlockW + (lane % kBlockW);
+    ly = (j / nbx) * kBlockH + (lane / kBlockW);
   } else {
     uint32_t i = (j - nblk) * 64 + lane;
-    uint32_t rw = t.w - 8 * nbx, rcount = rw * t.h;
-    if (i < rcount) { lx = 8 * nbx + i % rw; ly = i / rw; }
+    uint32_t rw = t.w - kBlockW * nbx, rcount = rw * t.h;
+    if (i < rcount) { lx = kBlockW * nbx + i % rw; ly = i / rw; }
     else {
-      uint32_t i2 = i - rcount, bw = 8 * nbx, bh = t.h - 8 * nby;
+      uint32_t i2 = i - rcount, bw = kBlockW * nbx, bh = t.h - kBlockH * nby;
       if (i2 >= bw * bh) return false;
-      lx = i2 % bw; ly = 8 * nby + i2 / bw;
+      lx = i2 % bw; ly = kBlockH * nby + i2 / bw;
     }
   }
   px = t.x + lx; py = t.y + ly;
@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(64, LB) k_render_flat(DRenderArgs A, int stack
   T.stk.dbg = A.counters->dbg;
   render_loop(A, T);
   if (A.want_counters) flush_counters(A.counters, T.cnt, T.err);
-  else if ((CLS & CLS_CSG) && __builtin_amdgcn_ballot_w64(T.err != 0) && (threadIdx.x & 63) == 0) atomicOr(&A.counters->error, 1u);
+  else if ((CLS & (CLS_CSG | CLS_MESH)) && __builtin_amdgcn_ballot_w64(T.err != 0) && (threadIdx.x & 63) == 0) atomicOr(&A.counters->error, 1u);
 }
 #if GLOME_IN_PART(6)
 __global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_render_generic(DRenderArgs A) {
@@ -532,7 +532,7 @@ __global__ void __launch_bounds__(64, LB) k_ss_frame_flat(DRenderArgs A, int sta
   FlatTier<FAITHFUL, false, FULL, CLS> T{A.S, A.lights, A.nlights, lane_stack<TWO_ROWS>(lds, stack_cap, ovf, ovf_cap), Cnt()};
   ss_frame_loop(A, T);
   if (A.want_counters) flush_counters(A.counters, T.cnt, T.err);
-  else if ((CLS & CLS_CSG) && __builtin_amdgcn_ballot_w64(T.err != 0) && (threadIdx.x & 63) == 0) atomicOr(&A.counters->error, 1u);
+  else if ((CLS & (CLS_CSG | CLS_MESH)) && __builtin_amdgcn_ballot_w64(T.err != 0) && (threadIdx.x & 63) == 0) atomicOr(&A.counters->error, 1u);
 }
 #if GLOME_IN_PART(7)
 __global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_ss_frame_generic(DRenderArgs A) {
@@ -1066,6 +1066,7 @@ glome_scene* glome_scene_commit(glome_ctx* ctx, glome_sb* sb, int32_t root) {
   constexpr int kLdsStack = kAsmLdsCap;
   int lds_cap = getenv("GLOME_DEBUG_STACK_CAP") ? atoi(getenv("GLOME_DEBUG_STACK_CAP")) : kLdsStack;
   int total = std::min(kFlatStack, std::max(4, need));
+  if (F.tier == 0 && F.max_mesh_depth > 0) total = std::max(total, std::min(kFlatStackMesh, 2 * F.max_mesh_depth));  // (the Mesh packet walk: up to two entries per level)
   s->stack_cap = std::max(4, std::min(lds_cap, total));
   s->ovf_cap = std::max(0, total - s->stack_cap);
   return s;

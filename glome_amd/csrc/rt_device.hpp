@@ -932,6 +932,88 @@ GD void mesh_closest(const DScene& S, uint32_t mh, const Ray& ray, float depth, 
 }
 
 
+#if defined(__HIPCC__)
+// rayint_mesh for the 64 rays of a wave at once (round 3).  A node is fetched once, by scalar loads; each lane clips its ray
+// against the two child boxes as mesh_closest does.  Unlike the BIH, a mesh ray takes the child whose box it enters first
+// (`lnear < rnear`, Mesh.hs:178), so the lanes of one packet can want opposite orders -- and the order decides which of two
+// equal hits on a shared edge is kept (nearest: ties -> later).  The packet therefore visits a node's children in up to three
+// passes, so that every lane sees its own order: the left subtree for the lanes that take it first, the right subtree for the
+// lanes that take it first or second, the left one again for the lanes that take it second.  With coherent rays one of the
+// groups is empty and it is two passes, like the per-lane walk.  A stack entry is (reference, per-lane interval); a lane that
+// is not in the entry stores an empty interval, and the pop's re-test against the best hit so far (Mesh.hs:190) is what tells
+// the lanes in from the lanes out.  Hits, ties and ray counts are the per-lane walk's; node visit counts are not kept.
+template <class STK>
+GD void mesh_closest_wave(const DScene& S, uint32_t mh, const Ray& ray, float depth, bool valid, STK& stk, float& best_t, uint32_t& best_tri, unsigned int* err) {
+  mh = uni(mh);
+  const F4 h0 = ld4u(S.meshhdr, 2 * mh), h1 = ld4u(S.meshhdr, 2 * mh + 1);
+  const V3 rcp = v3(dir_rcp(ray.d.x), dir_rcp(ray.d.y), dir_rcp(ray.d.z));
+  float nearv, farv;
+  bbclip_ub_rcp(ray.o, rcp, v3(h0), v3(h1), nearv, farv);
+  best_t = kInf; best_tri = 0xffffffffu;  // ridepth RayMiss = infinity
+  LaneMask am = wave_ballot(valid && !(nearv > farv || nearv > depth || farv < 0));
+  if (am == 0) return;
+  uint32_t ref = uni(as_u(h0.w));
+  const int cap = stk.total_cap();
+  const float kOut = 3.0e38f;  // a lane outside an entry: near = +kOut, far = -kOut fails every re-test
+  int sp = 0;
+  for (;;) {
+    const bool in = lane_of(am);
+    if (ref & MREF_LEAF) {  // Leaf: foldl' nearest over the triangles, each tested with tmax = far
+      uint32_t first = ref & 0x07ffffffu, count = (ref >> 27) & 15u;
+      if (count == 15u) count = uni(ldu4(S.mtrimeta, first).z);
+      float tmax = pminf(farv, best_t);
+      for (uint32_t k = 0; k < count; k++) {
+        const uint32_t ti = first + k;
+        F4 q0, q1, q2;
+        ld_tri_u(S.mtris, ti, q0, q1, q2);
+        float t, b1, b2;
+        if (tri_test(q0, q1, q2, ray, tmax, t, b1, b2) && in) { best_t = t; best_tri = ti; tmax = t; }
+      }
+      am = 0;
+    } else {
+      const F4 a0 = ld4u(S.meshnodes, 4 * ref), a1 = ld4u(S.meshnodes, 4 * ref + 1), b0 = ld4u(S.meshnodes, 4 * ref + 2), b1 = ld4u(S.meshnodes, 4 * ref + 3);
+      float lnp, lfp, rnp, rfp;
+      bbclip_ub_rcp(ray.o, rcp, v3(a0), v3(a1), lnp, lfp);
+      bbclip_ub_rcp(ray.o, rcp, v3(b0), v3(b1), rnp, rfp);
+      const float lnear = pmaxf(nearv, lnp), lfar = pminf(farv, lfp), rnear = pmaxf(nearv, rnp), rfar = pminf(farv, rfp);
+      const bool lfirst = lnear < rnear;
+      const float fnear = lfirst ? lnear : rnear, ffar = lfirst ? lfar : rfar;
+      const float snear = lfirst ? rnear : lnear, sfar = lfirst ? rfar : lfar;
+      const bool gof = in && !(fnear > ffar || fnear > depth || ffar < 0);
+      const float sfar2 = pminf(sfar, best_t);
+      const bool gos = in && !(snear > sfar2 || snear > depth || sfar2 < 0);
+      // what this lane does: its first child now (or, if that is a miss, its second at once), its second later
+      const bool now_l = gof ? lfirst : (gos && !lfirst), now_r = gof ? !lfirst : (gos && lfirst);
+      const bool later_l = gof && gos && !lfirst, later_r = gof && gos && lfirst;
+      const LaneMask mNL = wave_ballot(now_l), mNR = wave_ballot(now_r), mLL = wave_ballot(later_l), mLR = wave_ballot(later_r);
+      const uint32_t lref = uni(as_u(a0.w)), rref = uni(as_u(b0.w));
+      // passes in order: left (mNL), right (mNR | mLR), left again (mLL) -- or, with nobody going left now, right (mNR) then left (mLL)
+      const bool in_r = now_r || later_r;
+      const LaneMask mR = mNR | mLR;
+      if (mNL != 0) {
+        if (sp + 2 > cap) { if (err) *err = 1; return; }  // (commit sizes the stack for two entries per level: never, short of a limit)
+        if (mLL != 0) { stk.push(sp, lref, later_l ? lnear : kOut, later_l ? lfar : -kOut); sp++; }
+        if (mR != 0) { stk.push(sp, rref, in_r ? rnear : kOut, in_r ? rfar : -kOut); sp++; }
+        ref = lref; am = mNL; nearv = lnear; farv = lfar;
+      } else if (mR != 0) {
+        if (sp + 1 > cap) { if (err) *err = 1; return; }
+        if (mLL != 0) { stk.push(sp, lref, later_l ? lnear : kOut, later_l ? lfar : -kOut); sp++; }
+        ref = rref; am = mR; nearv = rnear; farv = rfar;
+      } else am = 0;
+    }
+    while (am == 0) {  // pop until an entry some lane still wants: rfar' = min rfar (ridepth lresult), Mesh.hs:190
+      if (sp == 0) return;
+      sp--;
+      uint32_t w;
+      stk.pop(sp, w, nearv, farv);
+      ref = uni(w);
+      const float f2 = pminf(farv, best_t);
+      am = wave_ballot(!(nearv > f2 || nearv > depth || f2 < 0));
+    }
+  }
+}
+#endif
+
 struct HitCore {  // a Rayint (Solid.hs:20-28) as the shader reads it
   bool hit;
   float t;
@@ -1199,7 +1281,8 @@ GD Cand closest_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt,
     if (kind == R_BIH) { cls = as_u(ld4(S.bihhdr, 3 * rec.y + 1).w); if (WAVE) cls = uni(cls); }
     const bool tri_bih = kind == R_BIH && (CLS & CLS_BIH_TRI) && (CLS == CLS_BIH_TRI || cls == BC_TRI);
     const bool sph_bih = kind == R_BIH && (CLS & CLS_BIH_SPHERE) && cls == BC_SPHERE;
-    if (WAVE && !valid && !tri_bih && !sph_bih) continue;  // only the packet walks need the lanes without a ray
+    const bool mesh_pk = WAVE && !FAITHFUL && !COUNT && (CLS & CLS_MESH) && kind == R_MESH;
+    if (WAVE && !valid && !tri_bih && !sph_bih && !mesh_pk) continue;  // only the packet walks need the lanes without a ray
     // tmax for this entry; a hit replaces the running best when !(best.t < t)  (nearest: ties -> later)
     float dd = (FAITHFUL || best.id == CAND_NONE) ? d : gminf(d, best.t);
     if (kind == R_BIH) {
@@ -1242,6 +1325,10 @@ GD Cand closest_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt,
       }
     } else if ((CLS & CLS_MESH) && kind == R_MESH) {
       float mt; uint32_t mtri;
+#if defined(__HIPCC__)
+      if constexpr (WAVE && !FAITHFUL && !COUNT) mesh_closest_wave(S, rec.y, r, d, valid, stk, mt, mtri, err);  // the wave's 64 rays at once
+      else
+#endif
       mesh_closest<COUNT>(S, rec.y, r, d, stk, stk.total_cap(), cnt, mt, mtri);  // depth = the list's d (Q12)
       if (mtri != 0xffffffffu && (best.id == CAND_NONE || !(best.t < mt))) { best.t = mt; best.id = mtri; best.aux = e | CAND_MESH; }
     } else if ((CLS & CLS_CSG) && (kind == R_DIFF || kind == R_ISECT || kind == R_INSTANCE || kind == R_TEX)) {  // a CSG item in the root list

@@ -48,7 +48,8 @@ enum DMatKind : uint32_t { DM_SURFACE = 0, DM_REFLECT = 1, DM_REFRACT = 2, DM_LA
 typedef uint64_t TexStack;
 constexpr int kMaxTexDepth = 4;
 constexpr int kMaxLights = 16;
-constexpr int kFlatStack = 32;     // LDS traversal-stack entries per lane in the flat-tier kernels
+constexpr int kFlatStack = 32;     // deepest BIH / Mesh tree the flat tier traverses (stack entries per lane: LDS part + global overflow columns)
+constexpr int kFlatStackMesh = 64; // ... the Mesh PACKET walk may hold two entries per tree level (rt_device.hpp mesh_closest_wave)
 constexpr int kGenericStack = 32;  // scratch traversal-stack entries per BIH/Mesh level in the generic tier
 // the generic tier's frame stack (rt_generic.hpp): words per ray, and the frame sizes the host's commit-time estimate shares
 constexpr int kVmWords = 768, kVmHitWords = 17, kVmListR = 7 + kVmHitWords, kVmInstR = 10, kVmBoundR = 5, kVmIbR = 4, kVmDiffFixed = 10 + kVmHitWords,
@@ -102,6 +103,11 @@ struct DLight { float pos[3], color[3], rad; int32_t shadow; };
 
 struct DTile { int32_t x, y, w, h; uint32_t wave_base; uint32_t pix_base; };  // pix_base: offset of the tile in a dense payload
 
+// a work item's 64 pixels: a block of kBlockW x kBlockH (8 x 8: the most coherent packet; 16 x 4 writes 64-byte row segments)
+#ifndef GLOME_BLOCK_W
+#define GLOME_BLOCK_W 8
+#endif
+constexpr int kBlockW = GLOME_BLOCK_W, kBlockH = 64 / GLOME_BLOCK_W;
 constexpr uint32_t kQueueShards = 8;       // heads of a render launch's work queue (one per XCD)
 constexpr uint32_t kQueueHeadStride = 32;  // words between heads: every head on its own 128-byte line
 constexpr uint32_t kQueueChunk = 64;       // consecutive tickets that belong to one head (one 64x64 work tile of 8x8 blocks)

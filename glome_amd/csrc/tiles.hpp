@@ -18,9 +18,9 @@ inline std::vector<std::pair<int, int>> chunk(int size, int blocksize) {  // Glo
   }
   return o;
 }
-// 64-pixel work items per tile: full 8x8 blocks, then the right / bottom leftovers packed 64 at a time
+// 64-pixel work items per tile: full kBlockW x kBlockH blocks (8x8), then the right / bottom leftovers packed 64 at a time
 inline uint32_t tile_waves(int w, int h) {
-  uint32_t nbx = w >> 3, nby = h >> 3;
+  uint32_t nbx = w / kBlockW, nby = h / kBlockH;
   uint32_t rest = (uint32_t)(w * h) - nbx * nby * 64;
   return nbx * nby + (rest + 63) / 64;
 }

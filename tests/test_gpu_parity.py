@@ -845,6 +845,28 @@ def s5_mesh(gpu_ctx):
     sc.release()
 
 
+def test_mesh_packet_walk_equals_the_per_lane_walk(gpu_ctx, s5_mesh):
+    """rayint_mesh for a wave's 64 rays at once (rt_device.hpp mesh_closest_wave: a node's children in up to three passes so that
+    every lane keeps its own `lnear < rnear` order, Mesh.hs:178) against the per-lane walk (the faithful instance): the same
+    frame bit for bit -- the 100k-triangle mesh at 1080p, the 1M-triangle mesh at 4K, and a small mesh seen from inside its
+    bounds with a camera on an axis (lanes that want opposite orders)."""
+    cases = [(scenes.s3(224, as_mesh=True), None, 1920, 1080), (None, s5_mesh, 3840, 2160), (scenes.s3(12, as_mesh=True), None, 333, 222)]
+    for sd, fix, W, H in cases:
+        if fix is not None:
+            sd, sc = fix[0], fix[1]
+        else:
+            b, nm, sc = commit(gpu_ctx, sd)
+        cam, lights = product_camera_lights(sd)
+        if W == 333:
+            cam = api.camera((0.0, 0.4, 0.0), (0.0, 0.0, 5.0), (0, 1, 0), 80)  # inside the height field's box, looking along +z
+        a, pa, sa = sc.render(cam, lights, api.render_params(width=W, height=H, maxdepth=1))
+        f, pf, sf = sc.render(cam, lights, api.render_params(width=W, height=H, maxdepth=1, faithful=1))
+        assert np.array_equal(pa, pf) and np.array_equal(a, f), (W, int((pa != pf).sum()))
+        assert (sa["rays_primary"], sa["rays_shadow"]) == (sf["rays_primary"], sf["rays_shadow"])
+        if fix is None:
+            sc.release()
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_s5_as_a_mesh_of_a_million_triangles_4k_tile_sample_vs_oracle(s5_mesh, mode):
     """configs[4] names a Mesh: the same 1,002,528 triangles as `mesh verts [] tris` (rayint_mesh, Mesh.hs:136-198; the BVH of
