@@ -766,7 +766,8 @@ struct glome_ctx {
     size_t ovf_bytes = 0;
     float* d_scratch = nullptr;  // adaptive sampler working buffer
     size_t scratch_bytes = 0;
-    bool launched = false;  // a render launch went out on this slot since its error word was last polled
+    bool launched = false;  // a launch went out on this slot since its error word was last polled
+    hipStream_t launched_on = nullptr;  // ... on this stream (a caller's own stream is the caller's to synchronise)
   };
   static constexpr int kSlots = 8;
   Slot slots[kSlots];
@@ -944,8 +945,15 @@ int glome_ctx_synchronize(glome_ctx* c) {
   // limits hit by launches nobody asked statistics of; lanes on the caller's own streams are the caller's to synchronise
   // first (an error raised by a launch still in flight is reported by the next call)
   int rc = 0;
-  for (auto& sl : c->slots)
-    if (sl.launched) { sl.launched = false; int r = poll_device_error(c, sl); if (r) rc = r; }
+  for (auto& sl : c->slots) {
+    if (!sl.launched) continue;
+    // a slot bound to a caller's stream (glome_ctx_use_slot) may still be running: its word is read once that stream is idle,
+    // by this call or a later one -- never while a kernel could still OR into it
+    if (sl.launched_on != c->stream && hipStreamQuery(sl.launched_on) == hipErrorNotReady) continue;
+    sl.launched = false;
+    int r = poll_device_error(c, sl);
+    if (r) rc = r;
+  }
   return rc;
 }
 int glome_ctx_debug_words(glome_ctx* c, uint64_t* out16) {  // DCounters::dbg of the current slot (measurement builds write them)
@@ -1319,7 +1327,7 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
       HIPCHK(ctx, hipMemset(&ctx->slot().d_counters->error, 0, sizeof(unsigned int)));
       ctx->err = "device-side limit hit (traversal stack or CSG advance cap)"; return GLOME_E_LIMIT;
     }
-  } else if (A.ntiles > 0) ctx->slot().launched = true;
+  } else if (A.ntiles > 0) { ctx->slot().launched = true; ctx->slot().launched_on = ctx->stream; }
   return 0;
 }
 
@@ -1395,6 +1403,7 @@ int glome_rayint_batch_dev(glome_scene* s, size_t n, const float* ox, const floa
     if (int rcc = reset_counters(ctx)) return rcc;
     launch_rayint_batch_generic(batch_grid(ctx, n, 0), ctx->stream, s->dev, n, R, H, ctx->slot().d_counters);
   }
+  ctx->slot().launched = true; ctx->slot().launched_on = ctx->stream;  // (a limit hit here is this call's to report, at the next synchronize)
   HIPCHK(ctx, hipGetLastError());
   return 0;
 }
@@ -1415,6 +1424,7 @@ int glome_shadow_batch_dev(glome_scene* s, size_t n, const float* ox, const floa
     if (int rcc = reset_counters(ctx)) return rcc;
     launch_shadow_batch_generic(batch_grid(ctx, n, 0), ctx->stream, s->dev, n, R, occluded, ctx->slot().d_counters);
   }
+  ctx->slot().launched = true; ctx->slot().launched_on = ctx->stream;
   HIPCHK(ctx, hipGetLastError());
   return 0;
 }
@@ -1593,7 +1603,7 @@ int glome_tiles_blit_dev(glome_ctx* ctx, const glome_render_params* P, int tile_
 // ================================================================================================ several GPUs, one process
 // renderTiles' `runPar $ parMap` over tiles followed by `forM_ tiles (blitTile surf)` (Glome.hs:379-386) across the GPUs of a
 // node, for a host that drives all of them from one process (the Haskell host of INTEGRATION.md): scenes[i] is the scene
-// committed on context i, tile k of the frame belongs to rank k mod n, a rank renders its tiles of up to 16 frames in one
+// committed on context i, tile k of the frame belongs to rank k mod n (or to the rank rank0_share_pct's pattern gives it), a rank renders its tiles of up to 16 frames in one
 // launch straight into a packed payload, the payloads travel to rank 0's GPU over xGMI, one launch there blits the frames.
 // The exchange is the path's only communication step.  Transport: RCCL send / recv in one group (librccl is opened at run
 // time, so the library carries no link-time dependency on it) when the ranks sit on distinct devices; peer copies on rank

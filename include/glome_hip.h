@@ -278,11 +278,14 @@ int glome_render_packed_batch_dev(glome_scene*, const glome_camera* cams, int nf
 /* ---- the whole-frame seam on several GPUs driven by ONE process (renderTiles' parMap over tiles + blitTile, Glome.hs:379-386) ----
  * scenes[i] = the same scene committed on context i (a context per GPU; rank 0's GPU receives the frame).  Tile k of the
  * frame -- 64x64 work tiles in renderTile mode, the 65x65 reference tiles in adaptive mode (whose pixels depend on the tile
- * map, Q21) -- belongs to rank k mod n.  A call renders nframes <= 16 views (one in adaptive mode): every rank renders its
+ * map, Q21) -- belongs to rank k mod n, or to the rank the weighted pattern of glome_render_params.rank0_share_pct gives it.
+ * A call renders nframes <= 16 views (one in adaptive mode): every rank renders its
  * tiles of all of them in one launch into a packed 0x00RRGGBB payload, the payloads move to rank 0's GPU over xGMI -- RCCL
  * send / recv in one group when use_rccl != 0, librccl.so can be opened and the ranks sit on distinct devices, peer copies
  * otherwise (glome_multi_transport says which) -- and one launch there blits the frames into packed_dev (frame f at
- * f * width * height words).  Asynchronous; glome_multi_synchronize waits for all ranks and reports device-side limits. */
+ * f * width * height words).  Asynchronous; glome_multi_synchronize waits for all ranks and reports device-side limits.
+ * The RCCL branch needs distinct devices and has not run on real RCCL with more than one rank on this pool (one-GPU boxes): it
+ * is exercised against a stand-in transport whose send / recv pairs are stream-ordered device copies (tests/rcclstub). */
 typedef struct glome_multi glome_multi;
 glome_multi* glome_multi_create(glome_scene* const* scenes, int n, const glome_render_params*, int use_rccl); /* NULL: glome_global_error() */
 void glome_multi_destroy(glome_multi*);
