@@ -373,11 +373,11 @@ class Scene:
         return n, cols
 
     def rayint(self, o, d, tmax=1000000.0):
-        """rayint over a batch (Solid.hs:146-151): returns dict t (-1 = miss), prim, n (nx3), tex (nx4)."""
+        """rayint over a batch (Solid.hs:146-151): returns dict t (-1 = miss), prim, n (nx3), tex (nx8: the stack innermost first, -1 padded)."""
         n, cols = self._rays(o, d, tmax)
         t = np.zeros(n, np.float32); prim = np.zeros(n, np.int32)
         nx = np.zeros(n, np.float32); ny = np.zeros(n, np.float32); nz = np.zeros(n, np.float32)
-        tex = np.zeros((n, 4), np.int32)
+        tex = np.zeros((n, 8), np.int32)
         self._chk(self.lib.glome_rayint_batch(self.h, n, *[c.ctypes.data_as(L.c_fp) for c in cols], t.ctypes.data_as(L.c_fp),
                                               prim.ctypes.data_as(L.c_ip), nx.ctypes.data_as(L.c_fp), ny.ctypes.data_as(L.c_fp),
                                               nz.ctypes.data_as(L.c_fp), tex.ctypes.data_as(L.c_ip)), "glome_rayint_batch")

@@ -22,6 +22,7 @@ struct FlatScene {
   uint32_t root_rec = 0;
   uint32_t tier = 1;
   int nesting_depth = 0, max_bih_depth = 0, max_mesh_depth = 0;
+  uint32_t tex_bits = 16;   // bits per id of a TexStack (rt_types.h): 8 when the scene has at most 254 materials
   int64_t n_other_prims = 0;
   std::string why_generic;  // why the flat tier was not chosen
   bool pk_all = true;       // every triangle BIH has the packet walk's node form (emit_bih)
@@ -48,8 +49,11 @@ class Flattener {
     F.root_rec = (uint32_t)F.recs.size();
     F.recs.push_back(r);
     F.nesting_depth = depth_of(root);
-    if (tex_depth_of(root) > kMaxTexDepth)
-      throw limit_error("a primitive lies under " + std::to_string(tex_depth_of(root)) + " nested textures; the device's texture stack holds " + std::to_string(kMaxTexDepth));
+    F.tex_bits = G.mats.size() <= 254 ? 8 : 16;
+    tex_cap = 64 / (int)F.tex_bits;
+    if (tex_depth_of(root) > tex_cap)
+      throw limit_error("a primitive lies under " + std::to_string(tex_depth_of(root)) + " nested textures; the device's texture stack holds " + std::to_string(tex_cap) +
+                        (tex_cap < kMaxTexDepth ? " in a scene of more than 254 materials (" + std::to_string(kMaxTexDepth) + " otherwise)" : ""));
     const bool warps = bind_warps();  // Warp materials refer to records: the frame's, and the scene's they look into
     if (vm_words_of(root) + 2 > kVmWords)
       throw limit_error("scene nests deeper than the device interpreter's frame memory holds (" + std::to_string(vm_words_of(root) + 2) + " of " + std::to_string(kVmWords) + " words)");
@@ -136,7 +140,7 @@ class Flattener {
       any = true;
       const uint32_t frame = slot(emit(m.wframe)), scene = m.wscene < 0 ? F.root_rec : slot(emit(m.wscene));
       F.nesting_depth = std::max(F.nesting_depth, std::max(depth_of(m.wframe), m.wscene < 0 ? 0 : depth_of(m.wscene)));
-      if (std::max(tex_depth_of(m.wframe), m.wscene < 0 ? 0 : tex_depth_of(m.wscene)) > kMaxTexDepth) throw limit_error("a Warp material's frame / scene has more nested textures than the device's texture stack holds");
+      if (std::max(tex_depth_of(m.wframe), m.wscene < 0 ? 0 : tex_depth_of(m.wscene)) > tex_cap) throw limit_error("a Warp material's frame / scene has more nested textures than the device's texture stack holds");
       if (std::max(vm_words_of(m.wframe), m.wscene < 0 ? 0 : vm_words_of(m.wscene)) + 2 > kVmWords)
         throw limit_error("a Warp material's frame / scene nests deeper than the device interpreter's frame memory holds");
       const uint32_t xf = (uint32_t)(F.xfms.size() / 6);
@@ -247,6 +251,7 @@ class Flattener {
   // longest texture stack a hit can carry: the Tex wrappers on a path from `id` down to a primitive (a Mesh adds its
   // per-triangle texture, Mesh.hs:148-150).  The device stack holds kMaxTexDepth materials; a deeper one is refused at
   // commit -- the traversal would silently drop the outermost textures.
+  int tex_cap = kMaxTexDepth;  // ids a TexStack holds in this scene
   mutable std::unordered_map<int, int> tex_memo;
   int tex_depth_of(int id) const {
     auto it = tex_memo.find(id);

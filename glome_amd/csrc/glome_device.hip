@@ -348,8 +348,9 @@ __global__ void __launch_bounds__(64, LB) k_render_flat(DRenderArgs A, int stack
 #if GLOME_IN_PART(6)
 __global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_render_generic(DRenderArgs A) {
   GenericTier T{A.S, A.lights, A.nlights, Cnt()};
-  // (Tried in round 3 and dropped: refilling a lane with the next pixel as soon as its trace is through -- ShadeVM is resumable for
-  // that.  The lanes fall out of step, every closest-hit call then runs for a part of the wave, and the frame took 5.8 ms
+  // (Tried in round 3 and dropped: refilling a lane with the next pixel as soon as its trace is through, with shade_vm as a
+  // resumable object.  The object form alone cost S4 0.39 -> 0.50 ms and this tier 4.3 -> 4.85 ms (its state no longer stays in
+  // registers), and with refilling the lanes fall out of step, every closest-hit call then runs for a part of the wave, and the frame took 5.8 ms
   // against 4.3: what keeps the lanes idle -- 28 % of the vector lane slots are used -- is the interpreter's own divergence
   // inside a call, not pixels of unequal cost.)
   render_loop(A, T);
@@ -545,17 +546,17 @@ __global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_ss_frame_generic(DRend
 
 // ------------------------------------------------------------------------------------------------ batch seams
 struct RayStream { const float *ox, *oy, *oz, *dx, *dy, *dz, *tmax; };
-struct HitStream { float* t; int32_t* prim; float *nx, *ny, *nz; int32_t* tex4; };
+struct HitStream { float* t; int32_t* prim; float *nx, *ny, *nz; int32_t* tex8; };
 
-__device__ __forceinline__ void store_hit(const HitStream& H, size_t i, const HitG& h) {
+__device__ __forceinline__ void store_hit(const HitStream& H, size_t i, const HitG& h, int B) {
   if (H.t) H.t[i] = h.hit ? h.t : -1.0f;
   if (H.prim) H.prim[i] = h.hit ? (int32_t)h.uid : -1;
   if (H.nx) H.nx[i] = h.n.x;
   if (H.ny) H.ny[i] = h.n.y;
   if (H.nz) H.nz[i] = h.n.z;
-  if (H.tex4) {
+  if (H.tex8) {
     TexStack ts = h.hit ? h.tex : 0;
-    for (int k = 0; k < 4; k++) { H.tex4[4 * i + k] = (int32_t)((ts >> (16 * k)) & 0xffffu) - 1; }
+    for (int k = 0; k < 8; k++) { H.tex8[8 * i + k] = (int32_t)tex_head(ts, B) - 1; ts = k * B + B < 64 ? ts >> B : 0; }
   }
 }
 __device__ __forceinline__ Ray load_ray(const RayStream& R, size_t i) {
@@ -570,12 +571,12 @@ __global__ void __launch_bounds__(64) k_rayint_batch_flat(DScene S, size_t n, Ra
   FlatTier<FAITHFUL, false, false, CLS_EVERY> T{S, nullptr, 0, lane_stack(lds, stack_cap, ovf, ovf_cap), Cnt()};
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const Ray r = load_ray(R, i);
-    if (FAITHFUL || unit_length(r.d)) { store_hit(H, i, T.closest(r, R.tmax[i])); continue; }
+    if (FAITHFUL || unit_length(r.d)) { store_hit(H, i, T.closest(r, R.tmax[i]), (int)S.tex_bits); continue; }
     // a caller's ray that is not unit length: the reference's own traversal (rayint_sphere reports hits for such rays that lie
     // outside the sphere's box, so the ordered early-out's pruning is not exact for them)
     HitG ch;
     Cand c = closest_flat<true, false, CLS_EVERY>(S, r, R.tmax[i], T.stk, T.cnt, true, &ch, &T.err);
-    store_hit(H, i, finalize_flat<CLS_EVERY>(S, r, c, &ch));
+    store_hit(H, i, finalize_flat<CLS_EVERY>(S, r, c, &ch), (int)S.tex_bits);
   }
   if (T.err) atomicOr(&c->error, 1u);
 }
@@ -591,7 +592,7 @@ __global__ void __launch_bounds__(64) k_shadow_batch_flat(DScene S, size_t n, Ra
 __global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_rayint_batch_generic(DScene S, size_t n, RayStream R, HitStream H, DCounters* c) {
   GenericTier T{S, nullptr, 0, Cnt()};
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    store_hit(H, i, T.closest(load_ray(R, i), R.tmax[i]));
+    store_hit(H, i, T.closest(load_ray(R, i), R.tmax[i]), (int)S.tex_bits);
   if (T.err) atomicOr(&c->error, 1u);
 }
 __global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_shadow_batch_generic(DScene S, size_t n, RayStream R, uint8_t* occ, DCounters* c) {
@@ -1043,7 +1044,7 @@ glome_scene* glome_scene_commit(glome_ctx* ctx, glome_sb* sb, int32_t root) {
   rc |= upload(s, F.entries, &D.entries);
   if (rc) { glome_scene_release(s); return nullptr; }
   D.n_entries = F.tier == 0 ? (uint32_t)F.entries.size() : 0;
-  D.root_rec = F.root_rec; D.tier = F.tier; D.n_mats = (uint32_t)sb_graph(sb).mats.size();
+  D.root_rec = F.root_rec; D.tier = F.tier; D.n_mats = (uint32_t)sb_graph(sb).mats.size(); D.tex_bits = F.tex_bits;
   glome_scene_info& I = s->info;
   I.tier = (int32_t)F.tier; I.nesting_depth = F.nesting_depth;
   I.n_records = (int64_t)F.recs.size(); I.n_bih_nodes = (int64_t)F.bihnodes.size(); I.n_mesh_nodes = (int64_t)F.meshnodes.size() / 4;
@@ -1386,14 +1387,14 @@ static int batch_grid(glome_ctx* ctx, size_t n, size_t lds) {
   return (int)std::max<size_t>(1, std::min<size_t>(blocks, (size_t)persistent_grid(ctx, lds, 0x7fffffff) * 4));
 }
 int glome_rayint_batch_dev(glome_scene* s, size_t n, const float* ox, const float* oy, const float* oz, const float* dx, const float* dy,
-                           const float* dz, const float* tmax, float* t, int32_t* prim, float* nx, float* ny, float* nz, int32_t* tex4) {
+                           const float* dz, const float* tmax, float* t, int32_t* prim, float* nx, float* ny, float* nz, int32_t* tex8) {
   if (!s) return GLOME_E_INVALID;
   glome_ctx* ctx = s->ctx;
   if (n == 0) return 0;
   if (!ox || !oy || !oz || !dx || !dy || !dz || !tmax) { ctx->err = "null ray stream"; return GLOME_E_INVALID; }
   HIPCHK(ctx, hipSetDevice(ctx->device));
   RayStream R{ox, oy, oz, dx, dy, dz, tmax};
-  HitStream H{t, prim, nx, ny, nz, tex4};
+  HitStream H{t, prim, nx, ny, nz, tex8};
   if (s->dev.tier == 0) {
     size_t lds = flat_lds_bytes(s->stack_cap);
     int grid = batch_grid(ctx, n, lds), rc;
@@ -1443,7 +1444,7 @@ struct Staging {
   }
 };
 int glome_rayint_batch(glome_scene* s, size_t n, const float* ox, const float* oy, const float* oz, const float* dx, const float* dy,
-                       const float* dz, const float* tmax, float* t, int32_t* prim, float* nx, float* ny, float* nz, int32_t* tex4) {
+                       const float* dz, const float* tmax, float* t, int32_t* prim, float* nx, float* ny, float* nz, int32_t* tex8) {
   if (!s) return GLOME_E_INVALID;
   glome_ctx* ctx = s->ctx;
   if (n == 0) return 0;
@@ -1458,7 +1459,7 @@ int glome_rayint_batch(glome_scene* s, size_t n, const float* ox, const float* o
   float* dnx = nx ? st.in<float>(nullptr, n) : nullptr;
   float* dny = ny ? st.in<float>(nullptr, n) : nullptr;
   float* dnz = nz ? st.in<float>(nullptr, n) : nullptr;
-  int32_t* dtex = tex4 ? st.in<int32_t>(nullptr, 4 * n) : nullptr;
+  int32_t* dtex = tex8 ? st.in<int32_t>(nullptr, 8 * n) : nullptr;
   int rc = glome_rayint_batch_dev(s, n, din[0], din[1], din[2], din[3], din[4], din[5], din[6], dt, dprim, dnx, dny, dnz, dtex);
   if (rc) return rc;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1468,7 +1469,7 @@ int glome_rayint_batch(glome_scene* s, size_t n, const float* ox, const float* o
   if (nx) HIPCHK(ctx, hipMemcpy(nx, dnx, n * 4, hipMemcpyDeviceToHost));
   if (ny) HIPCHK(ctx, hipMemcpy(ny, dny, n * 4, hipMemcpyDeviceToHost));
   if (nz) HIPCHK(ctx, hipMemcpy(nz, dnz, n * 4, hipMemcpyDeviceToHost));
-  if (tex4) HIPCHK(ctx, hipMemcpy(tex4, dtex, n * 16, hipMemcpyDeviceToHost));
+  if (tex8) HIPCHK(ctx, hipMemcpy(tex8, dtex, n * 32, hipMemcpyDeviceToHost));
   return 0;
 }
 int glome_shadow_batch(glome_scene* s, size_t n, const float* ox, const float* oy, const float* oz, const float* dx, const float* dy,

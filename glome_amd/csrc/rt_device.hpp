@@ -99,10 +99,14 @@ GD void ld_tri_u(const F4* p, uint32_t tri, F4& q0, F4& q1, F4& q2) {
 }
 #endif
 
-// texture stacks: 4 x 16 bit, innermost first, id+1 (rt_types.h)
-GD TexStack tex_push(TexStack s, uint32_t mat) { return (s << 16) | (TexStack)(mat + 1); }  // tex:texs, Tex.hs:66
-GD int tex_len(TexStack s) { return (s >> 48) ? 4 : ((s >> 32) ? 3 : ((s >> 16) ? 2 : (s ? 1 : 0))); }
-GD TexStack tex_cat(TexStack a, TexStack b) { return a | (b << (16 * tex_len(a))); }        // a ++ b (overflow truncates; commit validates depth)
+// texture stacks: ids of B = DScene::tex_bits bits, innermost first, id+1 (rt_types.h)
+GD TexStack tex_push(TexStack s, uint32_t mat, int B) { return (s << B) | (TexStack)(mat + 1); }  // tex:texs, Tex.hs:66
+GD int tex_len(TexStack s, int B) {  // ids in s
+  return s ? ((63 - __builtin_clzll(s)) >> (B == 8 ? 3 : 4)) + 1 : 0;  // (B is 8 or 16: no division)
+}
+GD TexStack tex_cat(TexStack a, TexStack b, int B) { const int n = tex_len(a, B); return n * B >= 64 ? a : a | (b << (n * B)); }  // a ++ b (overflow truncates; commit validates depth)
+GD TexStack tex_from16(uint32_t two, int B) { return (TexStack)(two & 0xffffu) | ((TexStack)(two >> 16) << B); }  // a record's / entry's own one or two ids (16 bits each)
+GD uint32_t tex_head(TexStack s, int B) { return (uint32_t)(s & ((1ull << B) - 1ull)); }
 
 struct Cnt {  // per-lane work counters (only live when COUNT)
   uint32_t bih = 0, mesh = 0, prim = 0, shadow = 0, secondary = 0, primary = 0;
@@ -1042,9 +1046,9 @@ GD HitG nearest_hit(const HitG& a, const HitG& b) {  // nearest, Solid.hs:37-44:
   if (!a.hit) return b;
   return (a.t < b.t) ? a : b;
 }
-GD TexStack own_stack_rayint(uint32_t own) { return (TexStack)own; }  // innermost Tex first (Tex.hs:66)
-GD TexStack own_stack_meta(uint32_t own) {                             // get_metainfo: outermost Tex first (Tex.hs:73-74)
-  if (own >> 16) return (TexStack)((own >> 16) | ((own & 0xffffu) << 16));
+GD TexStack own_stack_rayint(uint32_t own, int B) { return tex_from16(own, B); }  // innermost Tex first (Tex.hs:66)
+GD TexStack own_stack_meta(uint32_t own, int B) {                      // get_metainfo: outermost Tex first (Tex.hs:73-74)
+  if (own >> 16) return (TexStack)(own >> 16) | ((TexStack)(own & 0xffffu) << B);
   return (TexStack)own;
 }
 
@@ -1070,7 +1074,7 @@ template <bool C> GD HitG leaf_rayint(const DScene& S, Cnt& cnt, U4 rec, const R
   for (;;) {  // Tex s tex: rayint s r d (tex:texs) tags, Tex.hs:66
     if (rec.x & RF_NOVIS) return hit_miss();
     if ((rec.x & RF_KINDMASK) != R_TEX) break;
-    tex = tex_push(tex, rec.z);
+    tex = tex_push(tex, rec.z, (int)S.tex_bits);
     rec = ldu4(S.recs, rec.y);
   }
   HitG h = hit_miss();
@@ -1078,7 +1082,7 @@ template <bool C> GD HitG leaf_rayint(const DScene& S, Cnt& cnt, U4 rec, const R
   float t; V3 n;
   if (!prim_test<true>(S, rec.x & RF_KINDMASK, rec.y, r, d, t, n)) return h;
   h.hit = true; h.t = t; h.n = n; h.p = vscaleadd(r.o, r.d, t);
-  h.tex = tex_cat(own_stack_rayint(rec.z), tex); h.uid = rec.w;
+  h.tex = tex_cat(own_stack_rayint(rec.z, (int)S.tex_bits), tex, (int)S.tex_bits); h.uid = rec.w;
   return h;
 }
 GD U4 skip_tex(const DScene& S, U4 rec) {  // strip Tex records (and stop at the first non-Tex record)
@@ -1088,8 +1092,8 @@ GD U4 skip_tex(const DScene& S, U4 rec) {  // strip Tex records (and stop at the
 GD bool leaf_inside(const DScene& S, U4 rec, V3 p) { rec = skip_tex(S, rec); return prim_inside(S, rec.x & RF_KINDMASK, rec.y, p); }
 GD TexStack leaf_meta(const DScene& S, U4 rec) {  // get_metainfo of a primitive under Tex records: tex : texs, outermost first (Tex.hs:73-74)
   TexStack pre = 0;
-  while ((rec.x & RF_KINDMASK) == R_TEX) { pre = tex_cat(pre, (TexStack)(rec.z + 1)); rec = ldu4(S.recs, rec.y); }
-  return tex_cat(pre, own_stack_meta(rec.z));
+  while ((rec.x & RF_KINDMASK) == R_TEX) { pre = tex_cat(pre, (TexStack)(rec.z + 1), (int)S.tex_bits); rec = ldu4(S.recs, rec.y); }
+  return tex_cat(pre, own_stack_meta(rec.z, (int)S.tex_bits), (int)S.tex_bits);
 }
 // rayint_difference, Csg.hs:33-54 (Q13); the self-recursion through rayint_advance (Solid.hs:85-91) is a loop
 template <bool C> GD HitG csg_diff(const DScene& S, Cnt& cnt, unsigned int& err, U4 rec, const Ray& r0, float d0, TexStack tex) {
@@ -1184,7 +1188,7 @@ template <bool C> GD HitG csg_item_rayint(const DScene& S, Cnt& cnt, unsigned in
   for (;;) {  // Tex records over a composite
     if (rec.x & RF_NOVIS) return hit_miss();
     if ((rec.x & RF_KINDMASK) != R_TEX) break;
-    tex = tex_push(tex, rec.z);
+    tex = tex_push(tex, rec.z, (int)S.tex_bits);
     rec = ldu4(S.recs, rec.y);
   }
   Ray r = ray;
@@ -1202,7 +1206,7 @@ template <bool C> GD HitG csg_item_rayint(const DScene& S, Cnt& cnt, unsigned in
     for (;;) {  // Tex records between the Instance and a composite child
       if (rec.x & RF_NOVIS) return hit_miss();
       if ((rec.x & RF_KINDMASK) != R_TEX) break;
-      tex = tex_push(tex, rec.z);
+      tex = tex_push(tex, rec.z, (int)S.tex_bits);
       rec = ldu4(S.recs, rec.y);
     }
   }
@@ -1305,7 +1309,7 @@ GD Cand closest_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt,
         bih_traverse<FAITHFUL ? 0 : 1, COUNT, false>(S, rec.y, r, d, stk, stk.total_cap(), cnt,
           [&](uint32_t frec, uint32_t, uint32_t count, float tmax) {
             for (uint32_t k = 0; k < count; k++) {
-              const HitG h = csg_item_rayint<COUNT>(S, cnt, *err, ldu4(S.recs, frec + k), r, tmax, (TexStack)ent.y);  // `rayint s r far`
+              const HitG h = csg_item_rayint<COUNT>(S, cnt, *err, ldu4(S.recs, frec + k), r, tmax, tex_from16(ent.y, (int)S.tex_bits));  // `rayint s r far`
               if (h.hit && (best.id == CAND_NONE || !(best.t < h.t))) { best.t = h.t; best.id = frec + k; best.aux = e | CAND_CSG; *csgh = h; }
             }
             return false;
@@ -1332,7 +1336,7 @@ GD Cand closest_flat(const DScene& S, const Ray& r, float d, STK& stk, Cnt& cnt,
       mesh_closest<COUNT>(S, rec.y, r, d, stk, stk.total_cap(), cnt, mt, mtri);  // depth = the list's d (Q12)
       if (mtri != 0xffffffffu && (best.id == CAND_NONE || !(best.t < mt))) { best.t = mt; best.id = mtri; best.aux = e | CAND_MESH; }
     } else if ((CLS & CLS_CSG) && (kind == R_DIFF || kind == R_ISECT || kind == R_INSTANCE || kind == R_TEX)) {  // a CSG item in the root list
-      const HitG h = csg_item_rayint<COUNT>(S, cnt, *err, rec, r, d, (TexStack)ent.y);  // (every list item with the same d, Solid.hs:327: a cone's answer depends on it)
+      const HitG h = csg_item_rayint<COUNT>(S, cnt, *err, rec, r, d, tex_from16(ent.y, (int)S.tex_bits));  // (every list item with the same d, Solid.hs:327: a cone's answer depends on it)
       if (h.hit && (best.id == CAND_NONE || !(best.t < h.t))) { best.t = h.t; best.id = ent.x; best.aux = e | CAND_CSG; *csgh = h; }
     } else if ((CLS & CLS_PRIMS) && kind != R_VOID && kind != R_MESH && kind <= R_CONE) {
       float t; V3 n;
@@ -1367,7 +1371,7 @@ GD HitG finalize_flat(const DScene& S, const Ray& r, const Cand& c, const HitG* 
       h.n = vnorm(v3(a1.x + a2.x + a3.x, a1.y + a2.y + a3.y, a1.z + a2.z + a3.z));
     }
     TexStack own = meta.y ? (TexStack)meta.y : 0;  // (texv ! texi) : texs, Mesh.hs:148-150 (already id+1)
-    h.tex = tex_cat(own, (TexStack)ent.y);
+    h.tex = tex_cat(own, tex_from16(ent.y, (int)S.tex_bits), (int)S.tex_bits);
     h.uid = rec.w;
     return h;
   }
@@ -1378,7 +1382,7 @@ GD HitG finalize_flat(const DScene& S, const Ray& r, const Cand& c, const HitG* 
     float t;
     prim_test<true>(S, rec.x & RF_KINDMASK, rec.y, r, kInf * 8.0f, t, h.n);
   }
-  h.tex = tex_cat((TexStack)rec.z, (TexStack)ent.y);
+  h.tex = tex_cat(own_stack_rayint(rec.z, (int)S.tex_bits), tex_from16(ent.y, (int)S.tex_bits), (int)S.tex_bits);
   h.uid = rec.w;
   return h;
 }
@@ -1628,11 +1632,11 @@ GD CA shade_hit_lean(TIER& T, const Ray& ray, const HitCore& h, LightCache& lc, 
   CA acc = ca(0, 0, 0, 0);
   TexStack ts = h.tex;
   for (int k = 0; k < kMaxTexDepth; k++) {
-    uint32_t id = (uint32_t)(ts & 0xffffu);
+    uint32_t id = tex_head(ts, (int)T.S.tex_bits);
     if (id == 0) break;
     if (acc.a + kDel >= 1) break;  // opaque, Trace.hs:50-51
     acc = cafold(acc, postshade_lean(T, lc, id - 1, ray, h, recurs));
-    ts >>= 16;
+    ts >>= T.S.tex_bits;
   }
   return acc;
 }
@@ -1645,44 +1649,33 @@ struct VMTrace {  // one `trace` in progress: over `root` (a record; the scene's
 struct VMMat {    // one material being evaluated: k = children done so far, tmp (and aux) = what they have contributed
   uint32_t mat; uint32_t k; CA tmp; float aux;
 };
-// The state machine as an object, so that a lane can begin a new trace while its neighbours are still in theirs (the generic
-// tier's pixel loop refills idle lanes: glome_device.hip render_loop_lanes): start() a trace, round() until idle().
 template <class TIER>
-struct ShadeVM {
+GD CA shade_vm(TIER& T, const Ray& ray0, float tmax, int maxdepth, bool valid, HitG* hout) {
   enum : int { S_NEED_HIT, S_HIT, S_TEX, S_MAT_NEW, S_NEED_LIGHTS, S_MAT_CHILD, S_MAT_TRACED, S_MAT_RET, S_TRACE_RET, S_DONE };
   VMTrace tr[kMaxTraceDepth];
   VMMat ms[kMaxTraceDepth * (kMaxMatNest + 1)];
+  const DScene& S = T.S;
   int tl = 0, mi = 0, st = S_DONE;
-  CA ret;
+  CA ret = ca(0, 0, 0, 0);
   float vm_depth = kInf;
-  HitG h0;  // the primary hit (what trace_primary hands out)
-  GD void start(const DScene& S, const Ray& ray0, float tmax, int maxdepth, bool valid) {
-    tl = 0; mi = 0; st = S_DONE; ret = ca(0, 0, 0, 0); vm_depth = kInf; h0 = hit_miss();
-    tr[0].ray = ray0; tr[0].tmax = tmax;
-    if (valid && maxdepth > 0) { tr[0].recurs = maxdepth; tr[0].mbase = 0; tr[0].root = S.root_rec; tr[0].lset = 0xffffffffu; st = S_NEED_HIT; }
-  }
-  GD bool idle() const { return st == S_DONE; }
-  GD bool wants_hit() const { return st == S_NEED_HIT; }
-  GD bool wants_lights() const { return st == S_NEED_LIGHTS; }
-  // one round: the wave's requests (every lane that waits for a closest hit is traced now, together; so are the light lists),
-  // then this lane's own steps until it needs the wave again.  All lanes of the wave call it together.
-  // serve: 3 = both kinds of request, 1 = closest hits only, 2 = light lists only (a caller that refills lanes serves the kind
-  // more lanes wait for, so that neither call runs for a handful of lanes)
-  GD void round(TIER& T, int serve = 3) {
-    const DScene& S = T.S;
-    const bool wh = st == S_NEED_HIT && (serve & 1);
+  *hout = hit_miss();
+  if (valid && maxdepth > 0) { tr[0].ray = ray0; tr[0].tmax = tmax; tr[0].recurs = maxdepth; tr[0].mbase = 0; tr[0].root = S.root_rec; tr[0].lset = 0xffffffffu; st = S_NEED_HIT; }
+  for (;;) {
+    // ---- the wave's requests: every lane that waits for a closest hit is traced now, together (so are the light lists)
+    const bool wh = st == S_NEED_HIT;
     if (wave_any(wh)) {
-      const Ray r = tr[wh ? tl : 0].ray;
-      const HitG h = T.closest_wave(r, tr[wh ? tl : 0].tmax, wh, wh ? tr[tl].root : S.root_rec);
-      if (wh) { tr[tl].h = h; if constexpr (TIER::WARP) { tr[tl].lo = h.lo; tr[tl].ld = h.ld; } if (tl == 0) h0 = h; st = S_HIT; }
+      const Ray r = wh ? tr[tl].ray : ray0;
+      const HitG h = T.closest_wave(r, wh ? tr[tl].tmax : tmax, wh, wh ? tr[tl].root : S.root_rec);
+      if (wh) { tr[tl].h = h; if constexpr (TIER::WARP) { tr[tl].lo = h.lo; tr[tl].ld = h.ld; } if (tl == 0) *hout = h; st = S_HIT; }
     }
-    const bool wl = st == S_NEED_LIGHTS && (serve & 2);
+    const bool wl = st == S_NEED_LIGHTS;
     if (wave_any(wl)) {
       uint32_t m;
       if constexpr (TIER::WARP) m = wl ? preshade(T, tr[tl].h, light_set(T, tr[tl].lset), tr[tl].root) : 0u;  // lights and root may differ lane by lane
       else m = preshade_wave(T, tr[wl ? tl : 0].h, wl);
       if (wl) { tr[tl].lc.mask = m; tr[tl].lc.done = true; st = S_MAT_NEW; }
     }
+    if (!wave_any(st != S_DONE)) break;
     // ---- this lane's own steps, until it needs the wave again
     while (st != S_DONE && st != S_NEED_HIT && st != S_NEED_LIGHTS) {
       VMTrace& t = tr[tl];
@@ -1693,7 +1686,7 @@ struct ShadeVM {
           st = S_TEX;
           break;
         case S_TEX: {  // fold the texture stack head first until opaque (Trace.hs:67-80, Q16)
-          const uint32_t id = (uint32_t)(t.ts & 0xffffu);
+          const uint32_t id = tex_head(t.ts, (int)S.tex_bits);
           if (t.k >= kMaxTexDepth || id == 0 || t.acc.a + kDel >= 1) { ret = t.acc; st = S_TRACE_RET; break; }
           ms[mi].mat = id - 1; ms[mi].k = 0; mi++;
           st = S_MAT_NEW;
@@ -1793,7 +1786,7 @@ struct ShadeVM {
         }
         case S_MAT_RET:  // ms[mi - 1] is evaluated: `ret`
           mi--;
-          if (mi == t.mbase) { t.acc = cafold(t.acc, ret); t.ts >>= 16; t.k++; st = S_TEX; }
+          if (mi == t.mbase) { t.acc = cafold(t.acc, ret); t.ts >>= S.tex_bits; t.k++; st = S_TEX; }
           else st = S_MAT_CHILD;
           break;
         case S_TRACE_RET:  // the trace of level tl is evaluated: `ret`; vm_depth = ridepth of its Rayint (Warp compares those)
@@ -1805,14 +1798,7 @@ struct ShadeVM {
       }
     }
   }
-};
-template <class TIER>
-GD CA shade_vm(TIER& T, const Ray& ray0, float tmax, int maxdepth, bool valid, HitG* hout) {
-  ShadeVM<TIER> vm;
-  vm.start(T.S, ray0, tmax, maxdepth, valid);
-  while (wave_any(!vm.idle())) vm.round(T);
-  *hout = vm.h0;
-  return vm.ret;
+  return ret;
 }
 
 // the pixel loop's entry: `Trace.trace lights shader sld ray infinity maxdepth` (Glome.hs:33), maxdepth <= kMaxTraceDepth.
@@ -1828,7 +1814,7 @@ template <class TIER> GD CA trace_primary(TIER& T, const Ray& ray, float tmax, i
     LightCache lc; lc.done = false; lc.mask = 0;
     bool eager = false;
     if (valid && h.hit) {
-      uint32_t id = (uint32_t)(h.tex & 0xffffu);
+      uint32_t id = tex_head(h.tex, (int)T.S.tex_bits);
       if (id != 0) eager = as_u(ld4(T.S.mats, 3 * (id - 1)).x) == DM_SURFACE;
     }
     if (wave_any(eager)) {

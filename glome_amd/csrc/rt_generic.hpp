@@ -70,7 +70,7 @@ template <bool C> GD HitG vm_mesh_rayint(const DScene& S, Cnt& cnt, U4 rec, cons
     V3 a1 = n1 * (1 - (b1 + b2)), a2 = n2 * b1, a3 = n3 * b2;
     h.n = vnorm(v3(a1.x + a2.x + a3.x, a1.y + a2.y + a3.y, a1.z + a2.z + a3.z));
   }
-  h.tex = meta.y ? tex_cat((TexStack)meta.y, tex) : tex;
+  h.tex = meta.y ? tex_cat((TexStack)meta.y, tex, (int)S.tex_bits) : tex;
   return h;
 }
 
@@ -83,7 +83,7 @@ GD int vm_resolve_r(const DScene& S, U4& rec, TexStack& tex) {
   for (;;) {
     if (c.x & RF_NOVIS) return 1;
     if ((c.x & RF_KINDMASK) != R_TEX) break;
-    t = tex_push(t, c.z);
+    t = tex_push(t, c.z, (int)S.tex_bits);
     c = ldu4(S.recs, c.y);
   }
   const uint32_t kind = c.x & RF_KINDMASK;
@@ -107,7 +107,7 @@ template <bool C> GD HitG vm_prim_hit(const DScene& S, Cnt& cnt, const U4& rec, 
   float t; V3 n;
   if (prim_test<true>(S, rec.x & RF_KINDMASK, rec.y, r, d, t, n)) {
     h.hit = true; h.t = t; h.n = n; h.p = vscaleadd(r.o, r.d, t); h.lo = r.o; h.ld = r.d;
-    h.tex = tex_cat(own_stack_rayint(rec.z), tex); h.uid = rec.w;
+    h.tex = tex_cat(own_stack_rayint(rec.z, (int)S.tex_bits), tex, (int)S.tex_bits); h.uid = rec.w;
   }
   return h;
 }
@@ -249,10 +249,10 @@ GD bool vm_inside(const DScene& S, unsigned int& err, uint32_t* m, int base, U4 
 enum : uint32_t { MT_DONE = 0, MT_LIST, MT_ISECT, MT_INST, MT_PRE, MT_BIH };
 GD TexStack vm_meta_prim(const DScene& S, U4 rec, bool& is_prim) {  // a primitive under Tex wrappers: ([],[]) plus the folded wrappers
   TexStack pre = 0;
-  while ((rec.x & RF_KINDMASK) == R_TEX) { pre = tex_cat(pre, (TexStack)(rec.z + 1)); rec = ldu4(S.recs, rec.y); }
+  while ((rec.x & RF_KINDMASK) == R_TEX) { pre = tex_cat(pre, (TexStack)(rec.z + 1), (int)S.tex_bits); rec = ldu4(S.recs, rec.y); }
   const uint32_t kind = rec.x & RF_KINDMASK;
   is_prim = kind >= R_SPHERE && kind <= R_CONE;
-  return is_prim ? tex_cat(pre, own_stack_meta(rec.z)) : 0;
+  return is_prim ? tex_cat(pre, own_stack_meta(rec.z, (int)S.tex_bits), (int)S.tex_bits) : 0;
 }
 GDN TexStack vm_meta(const DScene& S, unsigned int& err, uint32_t* m, int base, U4 rec, V3 p) {
   if (base + 1 > kVmWords) { err = 1; return 0; }
@@ -267,10 +267,10 @@ GDN TexStack vm_meta(const DScene& S, unsigned int& err, uint32_t* m, int base, 
   for (;;) {
     if (!ret) {  // evaluate `get_metainfo rec p`
       TexStack pre = 0;  // Tex records passed on the way down: tex : texs (Tex.hs:73-74), outermost first
-      while ((rec.x & RF_KINDMASK) == R_TEX) { pre = tex_cat(pre, (TexStack)(rec.z + 1)); rec = ldu4(S.recs, rec.y); }
+      while ((rec.x & RF_KINDMASK) == R_TEX) { pre = tex_cat(pre, (TexStack)(rec.z + 1), (int)S.tex_bits); rec = ldu4(S.recs, rec.y); }
       const uint32_t kind = rec.x & RF_KINDMASK;
       ret = true;
-      if (kind >= R_SPHERE && kind <= R_CONE) { val = tex_cat(pre, own_stack_meta(rec.z)); continue; }
+      if (kind >= R_SPHERE && kind <= R_CONE) { val = tex_cat(pre, own_stack_meta(rec.z, (int)S.tex_bits), (int)S.tex_bits); continue; }
       val = pre;  // (what a composite without textures at p answers: pre ++ [])
       switch (kind) {
         case R_LIST:  // Solid.hs:337-339: later containing items are prepended
@@ -311,32 +311,32 @@ GDN TexStack vm_meta(const DScene& S, unsigned int& err, uint32_t* m, int base, 
     // a value has come back to the frame on top
     const uint32_t tag = m[fb] & 0xffu;
     if (tag == MT_DONE) return val;
-    if (tag == MT_PRE) { val = tex_cat(MT_GET(1), val); MT_POP(); continue; }
-    if (tag == MT_INST) { p = v3(as_f(m[fb + 5]), as_f(m[fb + 6]), as_f(m[fb + 7])); val = tex_cat(MT_GET(1), val); MT_POP(); continue; }
+    if (tag == MT_PRE) { val = tex_cat(MT_GET(1), val, (int)S.tex_bits); MT_POP(); continue; }
+    if (tag == MT_INST) { p = v3(as_f(m[fb + 5]), as_f(m[fb + 6]), as_f(m[fb + 7])); val = tex_cat(MT_GET(1), val, (int)S.tex_bits); MT_POP(); continue; }
     if (tag == MT_LIST || tag == MT_ISECT) {
       // (the frame is entered with val = 0 and nothing pending; later with a child's answer)
       const bool is_list = tag == MT_LIST;
       TexStack res = MT_GET(3);
       uint32_t cur = m[fb + 5], left = m[fb + 6];
-      if (m[fb] & 0x80000000u) { res = is_list ? tex_cat(val, res) : tex_cat(res, val); m[fb] &= 0x7fffffffu; }
+      if (m[fb] & 0x80000000u) { res = is_list ? tex_cat(val, res, (int)S.tex_bits) : tex_cat(res, val, (int)S.tex_bits); m[fb] &= 0x7fffffffu; }
       bool called = false;
       while (left != 0) {
         const U4 c = ldu4(S.recs, cur); cur++; left--;
         if (is_list && !vm_inside(S, err, m, sp, c, p)) continue;
         bool is_prim;
         const TexStack v = vm_meta_prim(S, c, is_prim);
-        if (is_prim) { res = is_list ? tex_cat(v, res) : tex_cat(res, v); continue; }
+        if (is_prim) { res = is_list ? tex_cat(v, res, (int)S.tex_bits) : tex_cat(res, v, (int)S.tex_bits); continue; }
         MT_SET(3, res); m[fb + 5] = cur; m[fb + 6] = left; m[fb] |= 0x80000000u;  // (bit 31: a child's answer is pending)
         rec = c; ret = false; called = true;
         break;
       }
-      if (!called) { val = tex_cat(MT_GET(1), res); MT_POP(); }
+      if (!called) { val = tex_cat(MT_GET(1), res, (int)S.tex_bits); MT_POP(); }
       continue;
     }
     {  // MT_BIH
       TexStack res = MT_GET(3), leaf = MT_GET(7);
       uint32_t cur = m[fb + 5], left = m[fb + 6], ref = m[fb + 10];
-      if (m[fb] & 0x80000000u) { leaf = tex_cat(val, leaf); m[fb] &= 0x7fffffffu; }
+      if (m[fb] & 0x80000000u) { leaf = tex_cat(val, leaf, (int)S.tex_bits); m[fb] &= 0x7fffffffu; }
       bool called = false, done = false;
       for (;;) {
         while (left != 0) {  // the leaf the walk stands on, like a list
@@ -344,13 +344,13 @@ GDN TexStack vm_meta(const DScene& S, unsigned int& err, uint32_t* m, int base, 
           if (!vm_inside(S, err, m, sp, c, p)) continue;
           bool is_prim;
           const TexStack v = vm_meta_prim(S, c, is_prim);
-          if (is_prim) { leaf = tex_cat(v, leaf); continue; }
+          if (is_prim) { leaf = tex_cat(v, leaf, (int)S.tex_bits); continue; }
           MT_SET(3, res); MT_SET(7, leaf); m[fb + 5] = cur; m[fb + 6] = left; m[fb + 10] = ref; m[fb] |= 0x80000000u;
           rec = c; ret = false; called = true;
           break;
         }
         if (called) break;
-        res = tex_cat(res, leaf); leaf = 0;
+        res = tex_cat(res, leaf, (int)S.tex_bits); leaf = 0;
         if (ref == 0xffffffffu) {
           const uint32_t ne = m[fb + 9];
           if (ne == 0) { done = true; break; }
@@ -372,7 +372,7 @@ GDN TexStack vm_meta(const DScene& S, unsigned int& err, uint32_t* m, int base, 
           else ref = 0xffffffffu;
         }
       }
-      if (done) { val = tex_cat(MT_GET(1), res); MT_POP(); }
+      if (done) { val = tex_cat(MT_GET(1), res, (int)S.tex_bits); MT_POP(); }
       continue;
     }
   }
@@ -486,7 +486,7 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, int st
       for (;;) {  // Tex s tex: rayint s r d (tex:texs) tags, Tex.hs:66; OnlyShadow misses (Tex.hs:89)
         if (rec.x & RF_NOVIS) { novis = true; break; }
         if ((rec.x & RF_KINDMASK) != R_TEX) break;
-        tex = tex_push(tex, rec.z);
+        tex = tex_push(tex, rec.z, (int)S.tex_bits);
         rec = ldu4(S.recs, rec.y);
       }
       st = ST_RET;
@@ -498,7 +498,7 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, int st
         float t; V3 n;
         if (prim_test<true>(S, kind, rec.y, r, d, t, n)) {
           rh.hit = true; rh.t = t; rh.n = n; rh.p = vscaleadd(r.o, r.d, t); rh.lo = r.o; rh.ld = r.d;
-          rh.tex = tex_cat(own_stack_rayint(rec.z), tex); rh.uid = rec.w;
+          rh.tex = tex_cat(own_stack_rayint(rec.z, (int)S.tex_bits), tex, (int)S.tex_bits); rh.uid = rec.w;
         }
         break;
       }

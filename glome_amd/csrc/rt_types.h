@@ -44,9 +44,11 @@ constexpr uint32_t MESH_BRANCH = 0xffffffffu;  // count value marking "ref is a 
 
 enum DMatKind : uint32_t { DM_SURFACE = 0, DM_REFLECT = 1, DM_REFRACT = 2, DM_LAYERS = 3, DM_BLEND = 4, DM_WARP = 5 };
 
-// A texture stack is at most 4 material ids, innermost first, 16 bits each, stored as id+1 (0 = end).
+// A texture stack (a ray's accumulated `texs`, Tex.hs:53-74): material ids, innermost first, stored as id+1 (0 = end), in one
+// 64-bit word -- 8 of them at 8 bits each in a scene of at most 254 materials (DScene::tex_bits = 8), 4 at 16 bits otherwise.
+// (Records and root entries keep their one or two own Tex ids at 16 bits each: tex_from16 widens them.)
 typedef uint64_t TexStack;
-constexpr int kMaxTexDepth = 4;
+constexpr int kMaxTexDepth = 8;   // with 8-bit ids; 64 / tex_bits in general
 constexpr int kMaxLights = 16;
 constexpr int kFlatStack = 32;     // deepest BIH / Mesh tree the flat tier traverses (stack entries per lane: LDS part + global overflow columns)
 constexpr int kFlatStackMesh = 64; // ... the Mesh PACKET walk may hold two entries per tree level (rt_device.hpp mesh_closest_wave)
@@ -96,6 +98,7 @@ struct DScene {
   uint32_t root_rec;
   uint32_t tier;
   uint32_t n_mats;
+  uint32_t tex_bits;  // 8 or 16: bits per id of a TexStack in this scene
 };
 
 struct DCamera { float pos[3], fwd[3], up[3], right[3]; };

@@ -194,18 +194,18 @@ typedef struct glome_scene_info {
 int glome_scene_get_info(const glome_scene*, glome_scene_info* out);
 
 /* ---- per-ray seams (Solid.hs:146-166), host buffers ---- */
-/* closest hit: t < 0 marks a miss (RayMiss); prim = builder id of the primitive hit; tex4 = the hit's
- * texture stack, innermost first, -1 padded (4 per ray).  Any output pointer may be NULL. */
+/* closest hit: t < 0 marks a miss (RayMiss); prim = builder id of the primitive hit; tex8 = the hit's
+ * texture stack (the ids of glome_sb_material), innermost first, -1 padded (8 per ray).  Any output pointer may be NULL. */
 int glome_rayint_batch(glome_scene*, size_t n, const float* ox, const float* oy, const float* oz, const float* dx,
                        const float* dy, const float* dz, const float* tmax, float* t, int32_t* prim, float* nx,
-                       float* ny, float* nz, int32_t* tex4);
+                       float* ny, float* nz, int32_t* tex8);
 int glome_shadow_batch(glome_scene*, size_t n, const float* ox, const float* oy, const float* oz, const float* dx,
                        const float* dy, const float* dz, const float* tmax, uint8_t* occluded);
 int glome_inside_batch(glome_scene*, size_t n, const float* px, const float* py, const float* pz, uint8_t* inside);
 /* the same on device pointers, asynchronous on the ctx stream */
 int glome_rayint_batch_dev(glome_scene*, size_t n, const float* ox, const float* oy, const float* oz, const float* dx,
                            const float* dy, const float* dz, const float* tmax, float* t, int32_t* prim, float* nx,
-                           float* ny, float* nz, int32_t* tex4);
+                           float* ny, float* nz, int32_t* tex8);
 int glome_shadow_batch_dev(glome_scene*, size_t n, const float* ox, const float* oy, const float* oz, const float* dx,
                            const float* dy, const float* dz, const float* tmax, uint8_t* occluded);
 

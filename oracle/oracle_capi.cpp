@@ -259,7 +259,7 @@ template <class R> struct Impl : IOracle {
       if (pos) { pos[3 * i] = h.pos.x; pos[3 * i + 1] = h.pos.y; pos[3 * i + 2] = h.pos.z; }
       if (nrm) { nrm[3 * i] = h.norm.x; nrm[3 * i + 1] = h.norm.y; nrm[3 * i + 2] = h.norm.z; }
       if (ntex) ntex[i] = h.hit ? h.tex.n : 0;
-      if (tex0) for (int k = 0; k < 4; k++) tex0[4 * i + k] = (h.hit && k < h.tex.n) ? h.tex.v[k] : -1;
+      if (tex0) for (int k = 0; k < 8; k++) tex0[8 * i + k] = (h.hit && k < h.tex.n) ? h.tex.v[k] : -1;
     }
     return 0;
   }
@@ -371,9 +371,9 @@ int glo_add_light(void* h, const double* pos, const double* col, double rad, int
   return guard(h, [&](IOracle* o) { o->add_light(pos, col, rad, shadow); return 0; });
 }
 int glo_rayint_batch(void* h, int root, size_t n, const double* ox, const double* oy, const double* oz, const double* dx, const double* dy,
-                     const double* dz, const double* tmax, double* t, int* prim, double* pos, double* nrm, int* tex4, int* ntex) {
+                     const double* dz, const double* tmax, double* t, int* prim, double* pos, double* nrm, int* tex8, int* ntex) {
   const double* od[6] = {ox, oy, oz, dx, dy, dz};
-  return guard(h, [&](IOracle* o) { return o->rayint_batch(root, n, od, tmax, t, prim, pos, nrm, tex4, ntex); });
+  return guard(h, [&](IOracle* o) { return o->rayint_batch(root, n, od, tmax, t, prim, pos, nrm, tex8, ntex); });
 }
 int glo_shadow_batch(void* h, int root, size_t n, const double* ox, const double* oy, const double* oz, const double* dx, const double* dy,
                      const double* dz, const double* tmax, uint8_t* occ) {

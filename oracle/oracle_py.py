@@ -165,7 +165,7 @@ class Oracle:
         tm = np.ascontiguousarray(np.broadcast_to(np.asarray(tmax, dtype=np.float64), (n,)))
         cols = [np.ascontiguousarray(o[:, k]) for k in range(3)] + [np.ascontiguousarray(d[:, k]) for k in range(3)]
         t = np.zeros(n); prim = np.zeros(n, np.int32); pos = np.zeros((n, 3)); nrm = np.zeros((n, 3))
-        tex = np.zeros((n, 4), np.int32); ntex = np.zeros(n, np.int32)
+        tex = np.zeros((n, 8), np.int32); ntex = np.zeros(n, np.int32)
         self._chk(self.L.glo_rayint_batch(self.h, C.c_int(int(root)), C.c_size_t(n), *[_dp(c) for c in cols], _dp(tm), _dp(t), prim.ctypes.data_as(c_ip),
                                           _dp(pos), _dp(nrm), tex.ctypes.data_as(c_ip), ntex.ctypes.data_as(c_ip)), "glo_rayint_batch")
         return {"t": t, "prim": prim, "pos": pos, "n": nrm, "tex": tex, "ntex": ntex}

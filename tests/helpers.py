@@ -49,7 +49,7 @@ class HostSim:
 
     def rayint(self, o, d, tmax=1e6, tier=-1, analysis=0):
         n, cols = self._cols(o, d, tmax)
-        t = np.zeros(n, np.float32); prim = np.zeros(n, np.int32); nrm = np.zeros((n, 3), np.float32); tex = np.zeros((n, 4), np.int32)
+        t = np.zeros(n, np.float32); prim = np.zeros(n, np.int32); nrm = np.zeros((n, 3), np.float32); tex = np.zeros((n, 8), np.int32)
         cnt = np.zeros(3, np.uint64)
         rc = self.lib.hostsim_rayint(self.h, tier, analysis, C.c_size_t(n), *[c.ctypes.data_as(c_fp) for c in cols], t.ctypes.data_as(c_fp),
                                      prim.ctypes.data_as(C.POINTER(C.c_int)), nrm.ctypes.data_as(c_fp), tex.ctypes.data_as(C.POINTER(C.c_int)),

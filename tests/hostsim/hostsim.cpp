@@ -83,7 +83,7 @@ void* hostsim_commit(glome_sb* sb, int root, char* errbuf, int cap) {
   D.planes = F.planes.data(); D.discs = F.discs.data(); D.quadrics = F.quadrics.data(); D.xfms = F.xfms.data(); D.bihhdr = F.bihhdr.data();
   D.bihnodes = F.bihnodes.data(); D.pknodes = F.pknodes.data(); D.pknodes_bytes = (uint32_t)(F.pknodes.size() * sizeof(F4)); D.meshhdr = F.meshhdr.data(); D.meshnodes = F.meshnodes.data(); D.mtris = F.mtris.data();
   D.mtrimeta = F.mtrimeta.data(); D.mats = F.mats.data(); D.wlights = F.wlights.data(); D.matkids = F.matkids.data(); D.entries = F.entries.data();
-  D.n_entries = F.tier == 0 ? (uint32_t)F.entries.size() : 0; D.root_rec = F.root_rec; D.tier = F.tier; D.n_mats = (uint32_t)sb_graph(sb).mats.size();
+  D.n_entries = F.tier == 0 ? (uint32_t)F.entries.size() : 0; D.root_rec = F.root_rec; D.tier = F.tier; D.n_mats = (uint32_t)sb_graph(sb).mats.size(); D.tex_bits = F.tex_bits;
   return s;
 }
 void hostsim_free(void* s) { delete (SimScene*)s; }
@@ -95,7 +95,7 @@ int hostsim_info(void* sv, int* out) {  // tier, nesting, max_bih_depth, max_mes
 }
 // tier: -1 = the scene's own tier, 0 = flat (must be legal), 1 = generic; analysis: faithful traversal + counters
 int hostsim_rayint(void* sv, int tier, int analysis, size_t n, const float* ox, const float* oy, const float* oz, const float* dx, const float* dy,
-                   const float* dz, const float* tmax, float* t, int* prim, float* nrm, int* tex4, unsigned long long* counters) {
+                   const float* dz, const float* tmax, float* t, int* prim, float* nrm, int* tex8, unsigned long long* counters) {
   SimScene* s = (SimScene*)sv;
   if (tier < 0) tier = (int)s->D.tier;
   if (tier == 0 && s->D.tier != 0) return -1;
@@ -117,7 +117,7 @@ int hostsim_rayint(void* sv, int tier, int analysis, size_t n, const float* ox, 
     t[i] = h.hit ? h.t : -1.0f;
     if (prim) prim[i] = h.hit ? (int)h.uid : -1;
     if (nrm) { nrm[3 * i] = h.n.x; nrm[3 * i + 1] = h.n.y; nrm[3 * i + 2] = h.n.z; }
-    if (tex4) for (int k = 0; k < 4; k++) tex4[4 * i + k] = h.hit ? (int)((h.tex >> (16 * k)) & 0xffff) - 1 : -1;
+    if (tex8) for (int k = 0; k < 8; k++) tex8[8 * i + k] = (h.hit && k * (int)s->D.tex_bits < 64) ? (int)((h.tex >> (s->D.tex_bits * k)) & ((1ull << s->D.tex_bits) - 1)) - 1 : -1;
   }
   if (counters) { counters[0] = total.bih; counters[1] = total.mesh; counters[2] = total.prim; }
   return err ? -2 : 0;

@@ -309,6 +309,27 @@ def test_limits_lifted_in_round_3(gpu_ctx):
     sc.release()
 
 
+@pytest.mark.parametrize("extra", [0, 300])
+def test_texture_stacks_of_eight(gpu_ctx, extra):
+    """zoo.veils: eight Tex levels (8-bit ids) above a sphere, a Difference, BIH items and a mesh triangle, and four levels in a
+    table of more than 254 materials (16-bit ids), against the oracle; a level more than the stack holds is refused at commit."""
+    sd = zoo.veils(extra)
+    b, nm, sc = commit(gpu_ctx, sd)
+    parity.check_rays(lambda o, d: sc.rayint(o, d), lambda o, d, t: sc.shadow(o, d, t), sc.inside, sd, nm, n=20000)
+    ro, rd = random_rays(20000, 11, center=(0, 1.5, 0), radius=13, spread=7)
+    assert (sc.rayint(ro, rd)["tex"] >= 0).sum(1).max() == (4 if extra else 8)
+    cam, lights = product_camera_lights(sd)
+    for mode, w, h in ((0, 320, 200), (1, 195, 130)):
+        img, packed, st = sc.render(cam, lights, api.render_params(width=w, height=h, mode=mode, maxdepth=3))
+        (parity.check_subsample_image if mode else parity.check_image)(img, (st["rays_primary"], st["rays_shadow"], st["rays_secondary"]), sd, w, h, 3)
+    sc.release()
+    over = sd.tex(sd.root, 0)
+    b = api.Builder()
+    nm, _ = sd.replay(b)
+    with pytest.raises(api.GlomeError, match="nested textures"):
+        gpu_ctx.commit(b, nm[over])
+
+
 @pytest.mark.parametrize("name,w,h", [("S1", 720, 480), ("S3small", 131, 66), ("materials", 200, 150), ("S4", 260, 195), ("mesh", 130, 65)])
 def test_adaptive_sampler_vs_oracle(gpu_ctx, name, w, h):
     """GLOME_MODE_SUBSAMPLE = renderTileSubsample (Glome.hs:226-323), incl. S1 at BASELINE configs[0..1]'s 720x480."""

@@ -6,7 +6,7 @@ import pytest
 
 import parity
 import zoo
-from helpers import HostSim, product_camera_lights
+from helpers import HostSim, oracle_for, product_camera_lights, random_rays
 from glome_amd import api, scenes
 
 SCENES = dict(zoo.ALL)
@@ -188,12 +188,39 @@ def test_more_nested_textures_than_the_stack_holds_are_refused(built):
     sd = zoo.SceneDesc()
     m = sd.material_surface((1, 1, 1), 1, 0.2, 0.8, 0, 0)
     n = sd.sphere((0, 1, 0), 1)
-    for _ in range(4):
+    for _ in range(8):
         n = sd.tex(n, m)
     ok = sd.group([n, sd.sphere((3, 1, 0), 1)])
     b = api.Builder(); nm, _ = sd.replay(b)
-    HostSim(b, nm[ok])  # four nested textures: the device stack's capacity
-    deep = sd.transform(sd.group([sd.tex(ok, m)]), [api.translate((0.0, 0.0, 1.0))])  # a fifth, two composites further out
+    HostSim(b, nm[ok])  # eight nested textures: the device stack's capacity at 8 bits an id
+    deep = sd.transform(sd.group([sd.tex(ok, m)]), [api.translate((0.0, 0.0, 1.0))])  # a ninth, two composites further out
     b = api.Builder(); nm, _ = sd.replay(b)
     with pytest.raises(RuntimeError, match="nested textures"):
         HostSim(b, nm[deep])
+    # more than 254 materials: ids take 16 bits and the stack holds four
+    sd = zoo.veils(extra_materials=300)
+    b = api.Builder(); nm, _ = sd.replay(b)
+    HostSim(b, nm[sd.root])
+    five = sd.tex(sd.root, 0)
+    b = api.Builder(); nm, _ = sd.replay(b)
+    with pytest.raises(RuntimeError, match="more than 254 materials"):
+        HostSim(b, nm[five])
+
+
+@pytest.mark.parametrize("extra", [0, 300])
+def test_texture_stacks_of_eight(built, extra):
+    """zoo.veils: eight Tex levels above a sphere, a Difference, BIH items and a mesh triangle (8-bit ids), and the same scene
+    cut to four levels in a table of more than 254 materials (16-bit ids): the per-ray seam returns the whole stack, the frame
+    shows every translucent level."""
+    sd = zoo.veils(extra)
+    b = api.Builder()
+    nm, _ = sd.replay(b)
+    hs = HostSim(b, nm[sd.root])
+    o, om, _ = oracle_for(sd)
+    lv = parity.check_rays(lambda ro, rd: hs.rayint(ro, rd), lambda ro, rd, tm: hs.shadow(ro, rd, tm), lambda p: hs.inside(p), sd, nm, n=6000)
+    ro, rd = random_rays(6000, 11, center=(0, 1.5, 0), radius=13, spread=7)
+    got = hs.rayint(ro, rd)
+    assert (got["tex"] >= 0).sum(1).max() == (4 if extra else 8)
+    cam, lights = product_camera_lights(sd)
+    img, cnt = hs.render(cam, lights, 160, 100, 3)
+    parity.check_image(img, [int(x) for x in cnt], sd, 160, 100, 3)

@@ -185,7 +185,37 @@ def hall_of_mirrors():
     return _finish(sd, sd.group([pl, sd.bih(items)]))
 
 
-ALL = {"flat_mixed": flat_mixed, "quadrics": quadrics, "csg": csg, "nested": nested, "mesh": mesh_scene, "materials": materials, "textures": textures}
+def veils(extra_materials=0):
+    """Texture stacks of eight (Tex.hs:53-74 conses without a bound; the device stack holds 8 ids in a scene of at most 254
+    materials, rt_types.h TexStack): a sphere, a Difference, BIH items and a mesh with per-triangle textures, each under Tex
+    wrappers that add up to eight on the way down, the inner ones translucent so that every level reaches the pixel
+    (Trace.hs:67-80 folds until opaque).  extra_materials pads the material table (more than 254: 16-bit ids, four levels)."""
+    sd = SceneDesc()
+    for k in range(extra_materials):
+        sd.material_surface((0.001 * k, 0.5, 0.5), 1, 0.2, 0.7, 0, 0)
+    cols = [(0.9, 0.2, 0.2), (0.2, 0.9, 0.2), (0.2, 0.2, 0.9), (0.9, 0.9, 0.1), (0.1, 0.9, 0.9), (0.9, 0.1, 0.9), (0.6, 0.6, 0.6)]
+    veil = [sd.material_surface(c, 0.22 + 0.03 * k, 0.3, 0.7, 0.3 if k % 2 else 0.0, 6) for k, c in enumerate(cols)]
+    solid = scenes.matte(sd, (0.8, 0.7, 0.5))
+    deep = 4 if extra_materials > 254 else 8
+    def under(n, k, first=0):  # k Tex wrappers, innermost first = veil[first], ...
+        for j in range(k):
+            n = sd.tex(n, veil[(first + j) % len(veil)])
+        return n
+    a = sd.tex(under(sd.sphere((-2.5, 1, 0), 1.0), deep - 1), solid)                      # eight straight down
+    cut = sd.difference(sd.box((0.2, 0, -0.8), (1.8, 1.6, 0.8)), sd.sphere((1.0, 1.2, 0.0), 0.7))
+    inner = sd.bih([under(sd.sphere((3.2 + 0.9 * i, 0.5, -1.5 + 0.8 * i), 0.45), 2, i) for i in range(4)] + [sd.tex(sd.box((3, 0, 1), (4, 0.8, 2)), veil[3])])
+    V = np.array([[-1, 0.01, 2], [1, 0.01, 2], [-1, 1.5, 3], [1, 1.5, 3]], np.float64)
+    tris = np.full((2, 8), -1, np.int32); tris[0, :3] = (0, 1, 2); tris[1, :3] = (2, 1, 3); tris[0, 6] = 0
+    me = sd.mesh(V, np.zeros((0, 3)), tris, [veil[5]])
+    half = deep // 2
+    grp = sd.group([under(cut, half, 1), under(inner, half - 2, 2), under(me, half - 1, 4)])   # + the wrappers below: deep, deep, deep (- 1 on the mesh's bare triangle)
+    grp = sd.tex(under(sd.transform(grp, [api.translate((0.0, 0.0, 0.3))]), deep - half - 1, 3), solid)
+    pl = sd.tex(sd.plane((0, 0, 0), (0, 1, 0)), scenes.matte(sd, (0.3, 0.6, 0.4)))
+    sd.set_camera((0.5, 3.0, 8.0), (0.8, 0.8, 0.0), (0, 1, 0), 50)
+    return _finish(sd, sd.group([pl, a, grp]))
+
+
+ALL = {"flat_mixed": flat_mixed, "quadrics": quadrics, "csg": csg, "nested": nested, "mesh": mesh_scene, "materials": materials, "textures": textures, "veils": veils}
 
 
 def soup(n=2500, seed=5, spheres=False, floor=True):
