@@ -84,15 +84,24 @@ struct FlatTier {
     else return valid && occluded(r, d);
   }
 };
+// the kernel's own arguments where the dispatch put them (constant memory; the first explicit argument is at offset 0)
+template <class ARGS> __device__ __forceinline__ const ARGS& kernel_args() {
+  return *(const ARGS*)(const ARGS __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+}
 struct GenericTier {
   static constexpr bool FULL = true;
   static constexpr bool WARP = true;
+  // What the out-of-line interpreter calls take the address of -- counters, error flag, frame memory -- are locals of the kernel,
+  // referred to from here, and S refers to the kernel-argument segment itself (kernel_args): this struct then never needs an
+  // address, lives in registers, and a pool's base is one scalar load from the argument segment.  (With the members inside the
+  // struct and S a reference to the by-value argument, both were kept in scratch: every pool access began with a per-lane flat load
+  // of the pool's base pointer from the scratch copy of DScene -- two dependent round trips per primitive test.)
   const DScene& S;
   const DLight* lights;
   int nlights;
-  Cnt cnt;
-  unsigned int err = 0;
-  uint32_t vm[kVmWords];  // the interpreter's frames: one word stack per lane for the whole kernel (scratch)
+  Cnt& cnt;
+  unsigned int& err;
+  uint32_t* vm;  // the interpreter's frames: one word stack of kVmWords per lane for the whole kernel (scratch)
   // `root`: the record the trace runs over -- the scene's, or the frame / scene of a Warp material
   __device__ __forceinline__ HitG closest(const Ray& r, float tmax, uint32_t root) { return vm_closest<true>(S, cnt, err, vm, r, tmax, root); }
   __device__ __forceinline__ bool occluded(const Ray& r, float d, uint32_t root) { return vm_occluded<true>(S, cnt, err, vm, r, d, root); }
@@ -346,8 +355,10 @@ __global__ void __launch_bounds__(64, LB) k_render_flat(DRenderArgs A, int stack
   else if ((CLS & (CLS_CSG | CLS_MESH)) && __builtin_amdgcn_ballot_w64(T.err != 0) && (threadIdx.x & 63) == 0) atomicOr(&A.counters->error, 1u);
 }
 #if GLOME_IN_PART(6)
-__global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_render_generic(DRenderArgs A) {
-  GenericTier T{A.S, A.lights, A.nlights, Cnt()};
+__global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_render_generic(DRenderArgs) {
+  const DRenderArgs& A = kernel_args<DRenderArgs>();
+  Cnt cnt; unsigned int err = 0; uint32_t vm[kVmWords];
+  GenericTier T{A.S, A.lights, A.nlights, cnt, err, vm};
   // (Tried in round 3 and dropped: refilling a lane with the next pixel as soon as its trace is through, with shade_vm as a
   // resumable object.  The object form alone cost S4 0.39 -> 0.50 ms and this tier 4.3 -> 4.85 ms (its state no longer stays in
   // registers), and with refilling the lanes fall out of step, every closest-hit call then runs for a part of the wave, and the frame took 5.8 ms
@@ -536,8 +547,10 @@ __global__ void __launch_bounds__(64, LB) k_ss_frame_flat(DRenderArgs A, int sta
   else if ((CLS & (CLS_CSG | CLS_MESH)) && __builtin_amdgcn_ballot_w64(T.err != 0) && (threadIdx.x & 63) == 0) atomicOr(&A.counters->error, 1u);
 }
 #if GLOME_IN_PART(7)
-__global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_ss_frame_generic(DRenderArgs A) {
-  GenericTier T{A.S, A.lights, A.nlights, Cnt()};
+__global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_ss_frame_generic(DRenderArgs) {
+  const DRenderArgs& A = kernel_args<DRenderArgs>();
+  Cnt cnt; unsigned int err = 0; uint32_t vm[kVmWords];
+  GenericTier T{A.S, A.lights, A.nlights, cnt, err, vm};
   ss_frame_loop(A, T);
   if (A.want_counters) flush_counters(A.counters, T.cnt, T.err);
   else if (__builtin_amdgcn_ballot_w64(T.err != 0) && (threadIdx.x & 63) == 0) atomicOr(&A.counters->error, 1u);
@@ -589,19 +602,24 @@ __global__ void __launch_bounds__(64) k_shadow_batch_flat(DScene S, size_t n, Ra
   if (T.err) atomicOr(&c->error, 1u);
 }
 #if GLOME_IN_PART(8)
-__global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_rayint_batch_generic(DScene S, size_t n, RayStream R, HitStream H, DCounters* c) {
-  GenericTier T{S, nullptr, 0, Cnt()};
+__global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_rayint_batch_generic(DScene, size_t n, RayStream R, HitStream H, DCounters* c) {
+  const DScene& S = kernel_args<DScene>();
+  Cnt cnt; unsigned int err = 0; uint32_t vm[kVmWords];
+  GenericTier T{S, nullptr, 0, cnt, err, vm};
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     store_hit(H, i, T.closest(load_ray(R, i), R.tmax[i]), (int)S.tex_bits);
   if (T.err) atomicOr(&c->error, 1u);
 }
-__global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_shadow_batch_generic(DScene S, size_t n, RayStream R, uint8_t* occ, DCounters* c) {
-  GenericTier T{S, nullptr, 0, Cnt()};
+__global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_shadow_batch_generic(DScene, size_t n, RayStream R, uint8_t* occ, DCounters* c) {
+  const DScene& S = kernel_args<DScene>();
+  Cnt cnt; unsigned int err = 0; uint32_t vm[kVmWords];
+  GenericTier T{S, nullptr, 0, cnt, err, vm};
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     occ[i] = T.occluded(load_ray(R, i), R.tmax[i]) ? 1 : 0;
   if (T.err) atomicOr(&c->error, 1u);
 }
-__global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_inside_batch(DScene S, size_t n, const float* px, const float* py, const float* pz, uint8_t* in, DCounters* c) {
+__global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_inside_batch(DScene, size_t n, const float* px, const float* py, const float* pz, uint8_t* in, DCounters* c) {
+  const DScene& S = kernel_args<DScene>();
   unsigned int err = 0;
   uint32_t vm[kVmWords];
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)

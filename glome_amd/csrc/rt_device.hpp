@@ -62,8 +62,17 @@ GD float vcomp(V3 a, uint32_t ax) { return ax == 0 ? a.x : (ax == 1 ? a.y : a.z)
 
 struct Ray { V3 o, d; };
 
+// A load from one of the scene's pools.  On the device the pointer is named as global memory: where the compiler cannot see that
+// itself (the generic tier's kernels keep DScene in memory for their out-of-line interpreter calls, so a pool's base comes back
+// from a load) it would emit flat_load -- an aperture check per access, both wait counters, no reordering against the frame stack.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T> GD const T __attribute__((address_space(1)))* as_global(const T* p) { return (const T __attribute__((address_space(1)))*)(uintptr_t)p; }
+GD F4 ld4(const F4* p, uint32_t i) { return as_global(p)[i]; }
+GD U4 ldu4(const U4* p, uint32_t i) { return as_global(p)[i]; }
+#else
 GD F4 ld4(const F4* p, uint32_t i) { return p[i]; }
 GD U4 ldu4(const U4* p, uint32_t i) { return p[i]; }
+#endif
 
 // ------------------------------------------------------------------ wave-level helpers
 // The packet traversal below keeps its control flow uniform across the 64 lanes of a wave: votes decide where the wave
