@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--time-every", type=int, default=1, help="HIP-event pair on every k-th launch of the timed region (roofline kernel time)")
     ap.add_argument("--host-build", action="store_true", help="build the BIH with the host builder (glome_sb_bih) instead of on the GPU")
     ap.add_argument("--force-dist", action="store_true", help="one GPU, but through the multi-GPU pipeline with a one-rank RCCL group (rehearsal)")
-    ap.add_argument("--group", type=int, default=0, help="frames per launch (and per RCCL gather); default by rank count and run length (up to 4 on one or two GPUs, 8 on more)")
+    ap.add_argument("--group", type=int, default=0, help="frames per launch (and per RCCL gather); default by rank count and run length (up to 16)")
     ap.add_argument("--product", default="packed", choices=["packed", "rgbad"],
                     help="what a frame is: GlomeView's framebuffer of packed 0x00RRGGBB pixels (blitTile; 4 B/pixel cross xGMI) "
                          "or the float (r,g,b,a,depth) tuples (20 B/pixel)")
@@ -134,9 +134,11 @@ def main():
             # the adaptive sampler: a batch of eight frames lets it work in large regions (fewer, fuller sample packets)
             args.group = (8 if args.steps >= 16 else 1) if world == 1 else 1
         elif world == 1:
-            # (tools/short_run_sweep.sh, profiles/r02_short_run_sweep.log: a 20-step run takes 0.206 ms per step with four frames per
-            # launch against 0.253 with one -- a launch cannot be shorter than its slowest work items, whatever it carries)
-            args.group = 4 if args.steps >= 8 else 1
+            # A launch cannot be shorter than its slowest work items (about 0.33 ms on S3), whatever it carries: the more frames share
+            # it the better, up to the 16 a launch may carry, and a short run is best cut into two launches that are in flight
+            # together (tools/short_run_sweep.sh, profiles/r03_short_run_sweep.log: 20 steps take 0.202 ms per step as 5 x 4 frames
+            # and 0.188 as 2 x 10; 200 steps 0.1725 at 8 frames per launch and 0.162 at 16)
+            args.group = 1 if args.steps < 8 else min(16, max(4, (args.steps + 1) // 2))
         elif world == 2:
             args.group = 1 if args.steps < 8 else (4 if args.steps < 64 else 8)
         elif world <= 4:

@@ -20,6 +20,8 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $root/$out/prof --output-f
 cd $root
 cp $(find $out/prof -name "*kernel_stats.csv" | head -1) $out/bench_S3_kernel_stats.csv 2>/dev/null
 rm -rf $out/prof
+# 3b. grouping of short and long runs (what bench.py's default group sizes rest on)
+STEPS="20 200" LANES="4" GROUPS_="1 4 8 10 16" bash tools/short_run_sweep.sh > /dev/null 2>&1; cp gpurun_out/short_run_sweep.log $out/short_run_sweep.log
 # 4. every configuration
 bash tools/run_configs.sh > $out/configs.log 2>&1
 mkdir -p $out/configs; cp gpurun_out/configs/*.json $out/configs/
