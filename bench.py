@@ -298,15 +298,15 @@ def main():
             sal = (cn["SQ_INSTS_SALU"] + cn["SQ_INSTS_SMEM"] + cn["SQ_INSTS_BRANCH"]) * sc_
             allin = sal + (cn["SQ_INSTS_VALU"] + cn.get("SQ_INSTS_LDS", 0.0) + cn.get("SQ_INSTS_VMEM_RD", 0.0) + cn.get("SQ_INSTS_VMEM_WR", 0.0)) * sc_
             # issue peaks measured on this GPU (tools/probe/valu_rate.hip, profiles/r03_valu_rate.txt): a SIMD issues 0.236 scalar
-            # instructions per cycle, 0.24 vector instructions with a scalar operand (0.32-0.40 with vector operands only), and
-            # 0.43 instructions of all kinds; x 4 SIMDs per CU
+            # instructions per cycle, 0.32-0.40 vector instructions on vector operands (0.24 with a scalar operand, 0.19-0.23 packed),
+            # and 0.43 instructions of all kinds in the probe's best mix; x 4 SIMDs per CU
             ceil = {
                 "hbm": {"achieved": round(hbm_bytes / kernel_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_bytes / kernel_s / 1e9 / HBM_PEAK_GBS, 4),
                         "note": "fabric-side bytes (FETCH_SIZE x 2 + WRITE_SIZE); Infinity-Cache hits included, so true HBM traffic is at most this"},
                 "l2": {"achieved": round(l2_bytes / kernel_s / 1e9, 1), "peak": 34500.0, "unit": "GB/s", "frac": round(l2_bytes / kernel_s / 1e9 / 34500.0, 4)},
                 "scalar_issue": {"achieved": round(sal / (cus * cyc), 4), "peak": 0.95, "unit": "scalar-type (SALU + SMEM + branch) instructions per cycle per CU", "frac": round(sal / (cus * cyc) / 0.95, 4)},
-                "valu_issue": {"achieved": round(cn["SQ_INSTS_VALU"] * sc_ / (cus * cyc), 4), "peak": 0.96, "unit": "wave64 vector instructions per cycle per CU (measured rate of one with a scalar operand)",
-                               "frac": round(cn["SQ_INSTS_VALU"] * sc_ / (cus * cyc) / 0.96, 4)},
+                "valu_issue": {"achieved": round(cn["SQ_INSTS_VALU"] * sc_ / (cus * cyc), 4), "peak": 1.6, "unit": "wave64 vector instructions per cycle per CU (the best rate the probe measured: VOP2 on vector operands; one with a scalar operand issues at 0.96, a packed one at 0.75-0.9)",
+                               "frac": round(cn["SQ_INSTS_VALU"] * sc_ / (cus * cyc) / 1.6, 4)},
                 "issue_all": {"achieved": round(allin / (cus * cyc), 4), "peak": 1.72, "unit": "instructions of all kinds per cycle per CU", "frac": round(allin / (cus * cyc) / 1.72, 4)},
             }
             top = max(ceil, key=lambda k: ceil[k]["frac"])

@@ -34,9 +34,14 @@ def period(world, rank, pct, group=8, lanes=4):
         best = min(best, (time.perf_counter() - t0) / K * 1e3)
     sc.lib.glome_ctx_use_slot(ctx.h, None, 0)
     return best, sf.plan.sizes
-for world, pcts in ((8, (100, 80, 70, 60, 50, 40)), (4, (100, 90, 80, 70, 60)), (2, (100, 95, 90, 85, 80))):
+import os
+GROUP, LANES = int(os.environ.get("GROUP", "8")), int(os.environ.get("LANES", "4"))  # (bench.py at 8 ranks, long runs: 16 frames per launch on 3 lanes)
+WORLDS = [int(x) for x in os.environ.get("WORLDS", "8 4 2").split()]
+for world, pcts in ((8, (100, 80, 70, 60, 50, 40, 30)), (4, (100, 90, 80, 70, 60, 50)), (2, (100, 95, 90, 85, 80, 75))):
+    if world not in WORLDS:
+        continue
     for pct in pcts:
-        r0, sizes = period(world, 0, pct)
-        r1, _ = period(world, 1, pct)
-        print(json.dumps({"world": world, "rank0_share_pct": pct, "rank0_ms_per_frame": round(r0, 4), "rank1_ms_per_frame": round(r1, 4),
+        r0, sizes = period(world, 0, pct, GROUP, LANES)
+        r1, _ = period(world, 1, pct, GROUP, LANES)
+        print(json.dumps({"world": world, "frames_per_launch": GROUP, "lanes": LANES, "rank0_share_pct": pct, "rank0_ms_per_frame": round(r0, 4), "rank1_ms_per_frame": round(r1, 4),
                           "pixels_rank0": sizes[0], "pixels_rank1": sizes[1]}), flush=True)
