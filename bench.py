@@ -131,8 +131,10 @@ def main():
         if args.product != "packed":
             args.group = 1
         elif args.mode != 0:
-            # the adaptive sampler: a batch of eight frames lets it work in large regions (fewer, fuller sample packets)
-            args.group = (8 if args.steps >= 16 else 1) if world == 1 else 1
+            # the adaptive sampler: a batch of eight or more frames lets it work in large regions (fewer, fuller sample packets),
+            # and a tile's five dependent passes are one wave's work at a time -- the more tiles a launch holds the more waves are busy
+            # (S3: 0.276 / 0.251 / 0.242 ms per frame with 8 / 12 / 16 frames per launch; profiles/r03_probes/adaptive_frames_per_launch.txt)
+            args.group = (16 if args.steps >= 32 else (8 if args.steps >= 16 else 1)) if world == 1 else 1
         elif world == 1:
             # A launch cannot be shorter than its slowest work items (about 0.33 ms on S3), whatever it carries: the more frames share
             # it the better, up to the 16 a launch may carry, and a short run is best cut into two launches that are in flight
