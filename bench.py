@@ -126,8 +126,7 @@ def main():
 
     if args.group <= 0:
         # frames per launch (and per gather).  Deep batches pay a fill / drain of about one launch per run, so short runs get
-        # shallower ones; the break-even points are measured (tools/short_run_groups.py, profiles/r01_l_short_run_groups.log):
-        # at 8 ranks a 20-step run takes 0.091 ms per step with one frame per launch and 0.052 with four.
+        # shallower ones; the break-even points are measured (below)
         if args.product != "packed":
             args.group = 1
         elif args.mode != 0:
@@ -141,16 +140,14 @@ def main():
             # together (tools/short_run_sweep.sh, profiles/r03_short_run_sweep.log: 20 steps take 0.202 ms per step as 5 x 4 frames
             # and 0.188 as 2 x 10; 200 steps 0.1725 at 8 frames per launch and 0.162 at 16)
             args.group = 1 if args.steps < 8 else min(16, max(4, (args.steps + 1) // 2))
-        elif world == 2:
-            args.group = 1 if args.steps < 8 else (4 if args.steps < 64 else 8)
-        elif world <= 4:
-            args.group = 2 if args.steps < 16 else (8 if args.steps < 128 else 16)
         else:
-            # (a rank's shard of a frame is a small launch: sixteen frames per launch halve what its fixed part costs per frame --
-            # one-GPU rehearsal of rank 0's pipeline at 8 ranks, tools/shard_timing.py: 0.038 / 0.030 / 0.027 ms per frame with
-            # 4 / 8 / 16 frames per launch, profiles/r03_shard_timing.log)
-            args.group = 4 if args.steps < 40 else (8 if args.steps < 128 else 16)
-            if args.group == 16 and args.lanes == 4:
+            # several ranks (tools/short_run_groups.py, profiles/r03_short_run_groups.log: rank 0's side of a short run by frames per
+            # launch, one-GPU rehearsal).  A rank's shard of a frame is a small launch whose fixed part -- it cannot be shorter than
+            # its slowest work items -- is shared by the frames it carries: at 8 ranks a 20-step run takes 0.078 / 0.043 / 0.039 ms per
+            # step with 1 / 4 / 8 frames per launch, a 100-step run 0.039 / 0.031 / 0.027 with 4 / 8 / 16 (tools/shard_timing.py,
+            # profiles/r03_b_shard_timing.log: 0.040 / 0.038 / 0.027 sustained)
+            args.group = (1 if world == 2 else 4) if args.steps < 8 else (4 if args.steps < 16 else (8 if args.steps < 40 else 16))
+            if world >= 8 and args.group == 16 and args.lanes == 4:
                 args.lanes = 3
     sf = dist.ShardedFrame(scene, P, rank, world, device, lanes=args.lanes, product=args.product, group=args.group, force_pipeline=args.force_dist)
 

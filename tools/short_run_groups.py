@@ -20,7 +20,7 @@ class _Done:
 for world in (8, 4, 2):
     for K, W in ((5, 2), (10, 3), (20, 5), (50, 5), (100, 10)):
         row = {}
-        for G in (1, 2, 4, 8):
+        for G in (1, 4, 8, 10, 16):
             best = None
             for rep in range(3):
                 sf = dist.ShardedFrame(sc, P, 0, world, dev, lanes=4, product="packed", group=G)
