@@ -102,9 +102,10 @@ struct GenericTier {
   Cnt& cnt;
   unsigned int& err;
   uint32_t* vm;  // the interpreter's frames: one word stack of kVmWords per lane for the whole kernel (scratch)
+  LaneStack pk;  // the wave's LDS stack for packet walks of sphere BIHs inside the interpreter (cap 0: the scene has none)
   // `root`: the record the trace runs over -- the scene's, or the frame / scene of a Warp material
-  __device__ __forceinline__ HitG closest(const Ray& r, float tmax, uint32_t root) { return vm_closest<true>(S, cnt, err, vm, r, tmax, root); }
-  __device__ __forceinline__ bool occluded(const Ray& r, float d, uint32_t root) { return vm_occluded<true>(S, cnt, err, vm, r, d, root); }
+  __device__ __forceinline__ HitG closest(const Ray& r, float tmax, uint32_t root) { return vm_closest<true>(S, cnt, err, vm, pk.cap > 0 ? &pk : (LaneStack*)nullptr, r, tmax, root); }
+  __device__ __forceinline__ bool occluded(const Ray& r, float d, uint32_t root) { return vm_occluded<true>(S, cnt, err, vm, pk.cap > 0 ? &pk : (LaneStack*)nullptr, r, d, root); }
   __device__ __forceinline__ HitG closest(const Ray& r, float tmax) { return closest(r, tmax, S.root_rec); }
   __device__ __forceinline__ bool occluded(const Ray& r, float d) { return occluded(r, d, S.root_rec); }
   __device__ __forceinline__ HitG closest_wave(const Ray& r, float tmax, bool valid, uint32_t root) { return valid ? closest(r, tmax, root) : hit_miss(); }
@@ -131,6 +132,12 @@ __device__ __forceinline__ LaneStack lane_stack(uint32_t* lds, int cap, uint32_t
   return s;
 }
 static size_t flat_lds_bytes(int cap, bool two_rows = false) { return (size_t)cap * 64 * (two_rows ? 8 : 12); }
+// the generic tier's packet stack: three rows in LDS, no overflow columns (a tree deeper than `cap` keeps the per-lane walk)
+__device__ __forceinline__ LaneStack generic_packet_stack(uint32_t* lds, int cap) {
+  LaneStack s = lane_stack<false>(lds, cap, nullptr, 0);
+  s.ovf = nullptr; s.dump = nullptr;
+  return s;
+}
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned int v) {
   unsigned long long s = v;
@@ -357,8 +364,9 @@ __global__ void __launch_bounds__(64, LB) k_render_flat(DRenderArgs A, int stack
 #if GLOME_IN_PART(6)
 __global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_render_generic(DRenderArgs) {
   const DRenderArgs& A = kernel_args<DRenderArgs>();
+  extern __shared__ uint32_t lds[];
   Cnt cnt; unsigned int err = 0; uint32_t vm[kVmWords];
-  GenericTier T{A.S, A.lights, A.nlights, cnt, err, vm};
+  GenericTier T{A.S, A.lights, A.nlights, cnt, err, vm, generic_packet_stack(lds, (int)A.S.pk_generic_cap)};
   // (Tried in round 3 and dropped: refilling a lane with the next pixel as soon as its trace is through, with shade_vm as a
   // resumable object.  The object form alone cost S4 0.39 -> 0.50 ms and this tier 4.3 -> 4.85 ms (its state no longer stays in
   // registers), and with refilling the lanes fall out of step, every closest-hit call then runs for a part of the wave, and the frame took 5.8 ms
@@ -549,8 +557,9 @@ __global__ void __launch_bounds__(64, LB) k_ss_frame_flat(DRenderArgs A, int sta
 #if GLOME_IN_PART(7)
 __global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_ss_frame_generic(DRenderArgs) {
   const DRenderArgs& A = kernel_args<DRenderArgs>();
+  extern __shared__ uint32_t lds[];
   Cnt cnt; unsigned int err = 0; uint32_t vm[kVmWords];
-  GenericTier T{A.S, A.lights, A.nlights, cnt, err, vm};
+  GenericTier T{A.S, A.lights, A.nlights, cnt, err, vm, generic_packet_stack(lds, (int)A.S.pk_generic_cap)};
   ss_frame_loop(A, T);
   if (A.want_counters) flush_counters(A.counters, T.cnt, T.err);
   else if (__builtin_amdgcn_ballot_w64(T.err != 0) && (threadIdx.x & 63) == 0) atomicOr(&A.counters->error, 1u);
@@ -605,7 +614,8 @@ __global__ void __launch_bounds__(64) k_shadow_batch_flat(DScene S, size_t n, Ra
 __global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_rayint_batch_generic(DScene, size_t n, RayStream R, HitStream H, DCounters* c) {
   const DScene& S = kernel_args<DScene>();
   Cnt cnt; unsigned int err = 0; uint32_t vm[kVmWords];
-  GenericTier T{S, nullptr, 0, cnt, err, vm};
+  LaneStack nopk{}; nopk.cap = 0; nopk.ovf_cap = 0;  // (the ray-batch seams walk lane by lane)
+  GenericTier T{S, nullptr, 0, cnt, err, vm, nopk};
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     store_hit(H, i, T.closest(load_ray(R, i), R.tmax[i]), (int)S.tex_bits);
   if (T.err) atomicOr(&c->error, 1u);
@@ -613,7 +623,8 @@ __global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_rayint_batch_generic(D
 __global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_shadow_batch_generic(DScene, size_t n, RayStream R, uint8_t* occ, DCounters* c) {
   const DScene& S = kernel_args<DScene>();
   Cnt cnt; unsigned int err = 0; uint32_t vm[kVmWords];
-  GenericTier T{S, nullptr, 0, cnt, err, vm};
+  LaneStack nopk{}; nopk.cap = 0; nopk.ovf_cap = 0;  // (the ray-batch seams walk lane by lane)
+  GenericTier T{S, nullptr, 0, cnt, err, vm, nopk};
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     occ[i] = T.occluded(load_ray(R, i), R.tmax[i]) ? 1 : 0;
   if (T.err) atomicOr(&c->error, 1u);
@@ -747,10 +758,10 @@ void launch_shadow_batch_flat(const FlatLaunch& L, DScene S, size_t n, RayStream
 bool launch_ss_flat_p9(int key, const FlatLaunch& L, const DRenderArgs& A) { GLOME_SS_FLAT_P9(GLOME_TRY_SS_FLAT) return false; }
 #endif
 #if GLOME_IN_PART(6)
-void launch_render_generic(int grid, hipStream_t st, const DRenderArgs& A) { hipLaunchKernelGGL(k_render_generic, dim3(grid), dim3(64), 0, st, A); }
+void launch_render_generic(int grid, hipStream_t st, const DRenderArgs& A) { hipLaunchKernelGGL(k_render_generic, dim3(grid), dim3(64), flat_lds_bytes((int)A.S.pk_generic_cap), st, A); }
 #endif
 #if GLOME_IN_PART(7)
-void launch_ss_generic(int grid, hipStream_t st, const DRenderArgs& A) { hipLaunchKernelGGL(k_ss_frame_generic, dim3(grid), dim3(64), 0, st, A); }
+void launch_ss_generic(int grid, hipStream_t st, const DRenderArgs& A) { hipLaunchKernelGGL(k_ss_frame_generic, dim3(grid), dim3(64), flat_lds_bytes((int)A.S.pk_generic_cap), st, A); }
 #endif
 #if GLOME_IN_PART(8)
 void launch_rayint_batch_generic(int grid, hipStream_t st, DScene S, size_t n, RayStream R, HitStream H, DCounters* c) { hipLaunchKernelGGL(k_rayint_batch_generic, dim3(grid), dim3(64), 0, st, S, n, R, H, c); }
@@ -1063,6 +1074,9 @@ glome_scene* glome_scene_commit(glome_ctx* ctx, glome_sb* sb, int32_t root) {
   if (rc) { glome_scene_release(s); return nullptr; }
   D.n_entries = F.tier == 0 ? (uint32_t)F.entries.size() : 0;
   D.root_rec = F.root_rec; D.tier = F.tier; D.n_mats = (uint32_t)sb_graph(sb).mats.size(); D.tex_bits = F.tex_bits;
+  // the generic tier's kernels carry an LDS stack of up to kGenericPacketStack entries per lane for packet walks of sphere BIHs (15 KB
+  // a wave at 20: eight waves per CU fit); a deeper tree of spheres keeps the per-lane walk
+  D.pk_generic_cap = (F.tier != 0 && F.max_sphere_bih_depth > 0) ? (uint32_t)std::min(kGenericPacketStack, std::max(4, F.max_sphere_bih_depth)) : 0u;
   glome_scene_info& I = s->info;
   I.tier = (int32_t)F.tier; I.nesting_depth = F.nesting_depth;
   I.n_records = (int64_t)F.recs.size(); I.n_bih_nodes = (int64_t)F.bihnodes.size(); I.n_mesh_nodes = (int64_t)F.meshnodes.size() / 4;

@@ -22,15 +22,19 @@ namespace glome {
 
 constexpr int kHitWords = kVmHitWords;  // (kVmWords frame words per ray, scratch: rt_types.h; running out raises the context's error flag)
 #ifndef GLOME_VM_BIH_STEPS
-#define GLOME_VM_BIH_STEPS 8
+#define GLOME_VM_BIH_STEPS 32
 #endif
+#ifndef GLOME_PK_MIN_LANES
+#define GLOME_PK_MIN_LANES 64
+#endif
+constexpr int kPkMinLanes = GLOME_PK_MIN_LANES;  // lanes that must wait for a packet walk before one is made while other lanes are still on their way
 constexpr int kBihStepsPerPass = GLOME_VM_BIH_STEPS;  // BIH steps a lane may take in one pass of the loop
 
 enum : uint32_t {
   VT_DONE = 0, VT_LIST_R, VT_LIST_S, VT_INST_R, VT_INST_S, VT_BOUND_R, VT_BOUND_S, VT_IB_R, VT_IB_S,
   VT_DIFF_B, VT_DIFF_A, VT_DIFF_AB, VT_ISECT_HS, VT_ISECT_S1, VT_ISECT_S2, VT_BIH_R, VT_BIH_S, VT_S_OF_R
 };
-enum : int { ST_CALL_R = 0, ST_CALL_S, ST_RET, ST_BIH, ST_BIH_ITEM, ST_DIFF, ST_ISECT, ST_ENTER_CSG, ST_LIST_R, ST_LIST_S };
+enum : int { ST_CALL_R = 0, ST_CALL_S, ST_RET, ST_BIH, ST_BIH_ITEM, ST_DIFF, ST_ISECT, ST_ENTER_CSG, ST_LIST_R, ST_LIST_S, ST_PK_R, ST_PK_S };
 
 GD void vm_st_hit(uint32_t* m, int i, const HitG& h) {
   m[i] = h.hit ? 1u : 0u; m[i + 1] = as_u(h.t);
@@ -393,13 +397,21 @@ GDN TexStack vm_meta(const DScene& S, unsigned int& err, uint32_t* m, int base, 
 //            10 the leaf's tmax, 11 traversal entries, [12.. best hit (rayint only)], then the entries (node, near, far)
 constexpr int kBihFixedS = kVmBihFixedS, kBihFixedR = kVmBihFixedR, kDiffFixed = kVmDiffFixed, kIsectWords = kVmIsectWords;
 
-template <bool C>
-GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, int st, U4 rec, Ray r, float d, bool exact, HitG& rh, bool& rb) {
+// `pk`: the wave's packet stack (LDS rows, rt_device.hpp LaneStack) or null.  With one, a rayint / shadow call whose callee is a
+// BIH of plain spheres (BC_SPHERE: GlomeView's default scene spends three fifths of its frame in the 9,261-sphere lattice,
+// which a carving Difference walks again after every advance) is not walked lane by lane over frames: the lane waits in ST_PK_R /
+// ST_PK_S, and once per pass all lanes that wait for the same tree are walked as ONE packet by the flat tier's wave-wide walk
+// (bih_tri_wave: wave-uniform node references, scalar loads, per-lane intervals) -- same hit, same tie order, same counters as
+// the per-lane walk (tests: every traversal agrees ray for ray).  A ray that is not unit length keeps the per-lane walk (the
+// ordered early-out is exact for unit rays only).
+template <bool C, class PK>
+GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, PK* pk, int st, U4 rec, Ray r, float d, bool exact, HitG& rh, bool& rb) {
   int sp = 1, fb = 0;
   m[0] = VT_DONE;
   TexStack tex = 0;
   rh = hit_miss(); rb = false;
   uint32_t ref = 0; float nearv = 0, farv = 0, bt = 0;  // the BIH walk's registers (live between ST_BIH steps only)
+  uint32_t pk_hdr = 0;  // the tree a lane in ST_PK_R / ST_PK_S waits for
 #define VM_NEED(n) if (sp + (n) > kVmWords) { err = 1; rh = hit_miss(); rb = false; return; }
 #define VM_PUSH(tag, n) { VM_NEED(n); m[sp] = (uint32_t)(tag) | ((uint32_t)fb << 8); fb = sp; sp += (n); }
 #define VM_POP() { sp = fb; fb = (int)(m[fb] >> 8); }
@@ -541,6 +553,7 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, int st
         }
         case R_BIH: {  // rayint_bih, Bih.hs:332-368
           F4 h0 = ld4(S.bihhdr, 3 * rec.y), h1 = ld4(S.bihhdr, 3 * rec.y + 1);
+          if (pk != nullptr && !exact && as_u(h1.w) == BC_SPHERE && (int)as_u(ld4(S.bihhdr, 3 * rec.y + 2).w) <= pk->total_cap()) { pk_hdr = rec.y; st = ST_PK_R; break; }
           bbclip_ub(r, v3(h0), v3(h1), nearv, farv);
           farv = gminf(d, farv);  // `traverse root near (fmin d far)`, Bih.hs:368
           ref = as_u(h0.w);
@@ -611,6 +624,7 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, int st
         }
         case R_BIH: {  // shadow_bih, Bih.hs:510-544
           F4 h0 = ld4(S.bihhdr, 3 * rec.y), h1 = ld4(S.bihhdr, 3 * rec.y + 1);
+          if (pk != nullptr && as_u(h1.w) == BC_SPHERE && (int)as_u(ld4(S.bihhdr, 3 * rec.y + 2).w) <= pk->total_cap()) { pk_hdr = rec.y; st = ST_PK_S; break; }
           bbclip_ub(r, v3(h0), v3(h1), nearv, farv);
           farv = gminf(d, farv);
           ref = as_u(h0.w);
@@ -625,6 +639,30 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, int st
         default: break;  // Mesh: `shadow s r d = False` (Mesh.hs:210); Void
       }
     } while (0);
+    // the packet service: every lane of the wave that is still in this loop comes by here once per pass
+    if (pk != nullptr) {
+      const bool want = st == ST_PK_R || st == ST_PK_S;
+      LaneMask todo = wave_ballot(want);
+      // a walk costs the same for one lane as for sixty-four: while fewer than kPkMinLanes wait and other lanes can still go on
+      // (and may join them), the waiting ones wait.  (Measured on GlomeView's default scene, 1 / 8 / 16 / 32 / 64: 4.10 / 3.98 / 3.96
+      // / 3.94 / 3.91 ms per frame, a frame alone 15.7 / 14.2 / 13.5 / 13.7 / 13.6: profiles/r03_probes/generic_tier_packet_service_ab.txt)
+      if (wave_count(want) < kPkMinLanes && wave_any(!want)) todo = 0;
+      while (todo != 0) {  // one walk per (tree, kind of call) among the waiting lanes
+        const uint32_t h = uni(first_lane_value(todo, pk_hdr));
+        const int kind = (int)uni(first_lane_value(todo, (uint32_t)st));
+        const bool mine = want && pk_hdr == h && st == kind;
+        todo &= ~wave_ballot(mine);
+        float pbt = kNoBest;
+        uint32_t prec = CAND_NONE;
+        if (kind == ST_PK_R) {
+          bih_tri_wave<1, C, 1>(S, h, r, d, mine, *pk, cnt, pbt, prec);
+          if (mine) { rh = prec != CAND_NONE ? vm_prim_hit<false>(S, cnt, ldu4(S.recs, prec), r, kInf * 8.0f, tex) : hit_miss(); st = ST_RET; }
+        } else {
+          const bool occ = bih_tri_wave<2, C, 1>(S, h, r, d, mine, *pk, cnt, pbt, prec);
+          if (mine) { rb = occ; st = ST_RET; }
+        }
+      }
+    }
     if (st == ST_RET) do {
       switch (m[fb] & 0xffu) {
         case VT_DONE: return;
@@ -900,16 +938,16 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, int st
 #undef VM_CALL_R_INLINE
 }
 
-template <bool C> GD HitG vm_closest(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, const Ray& r, float tmax, uint32_t root) {
+template <bool C, class PK> GD HitG vm_closest(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, PK* pk, const Ray& r, float tmax, uint32_t root) {
   HitG h; bool b;
   // a ray that is not unit length (Refract's transmitted ray, Shader.hs:141): BIHs are walked exactly as the reference
   // walks them (rt_device.hpp bih_traverse: the ordered early-out's pruning is exact only for unit rays)
-  vm_run<C>(S, cnt, err, m, ST_CALL_R, ldu4(S.recs, root), r, tmax, !unit_length(r.d), h, b);
+  vm_run<C>(S, cnt, err, m, pk, ST_CALL_R, ldu4(S.recs, root), r, tmax, !unit_length(r.d), h, b);
   return h;
 }
-template <bool C> GD bool vm_occluded(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, const Ray& r, float d, uint32_t root) {
+template <bool C, class PK> GD bool vm_occluded(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, PK* pk, const Ray& r, float d, uint32_t root) {
   HitG h; bool b;
-  vm_run<C>(S, cnt, err, m, ST_CALL_S, ldu4(S.recs, root), r, d, false, h, b);
+  vm_run<C>(S, cnt, err, m, pk, ST_CALL_S, ldu4(S.recs, root), r, d, false, h, b);
   return b;
 }
 

@@ -52,6 +52,7 @@ constexpr int kMaxTexDepth = 8;   // with 8-bit ids; 64 / tex_bits in general
 constexpr int kMaxLights = 16;
 constexpr int kFlatStack = 32;     // deepest BIH / Mesh tree the flat tier traverses (stack entries per lane: LDS part + global overflow columns)
 constexpr int kFlatStackMesh = 64; // ... the Mesh PACKET walk may hold two entries per tree level (rt_device.hpp mesh_closest_wave)
+constexpr int kGenericPacketStack = 20;  // LDS entries per lane of the generic tier's packet stack (rt_generic.hpp, vm_run's packet service)
 constexpr int kGenericStack = 32;  // scratch traversal-stack entries per BIH/Mesh level in the generic tier
 // the generic tier's frame stack (rt_generic.hpp): words per ray, and the frame sizes the host's commit-time estimate shares
 constexpr int kVmWords = 768, kVmHitWords = 17, kVmListR = 7 + kVmHitWords, kVmInstR = 10, kVmBoundR = 5, kVmIbR = 4, kVmDiffFixed = 10 + kVmHitWords,
@@ -99,6 +100,8 @@ struct DScene {
   uint32_t tier;
   uint32_t n_mats;
   uint32_t tex_bits;  // 8 or 16: bits per id of a TexStack in this scene
+  uint32_t pk_generic_cap;  // generic tier: entries of the per-wave LDS stack its kernels carry for packet walks of sphere BIHs
+                            // (rt_generic.hpp, the packet service of vm_run); 0 = the scene has none
 };
 
 struct DCamera { float pos[3], fwd[3], up[3], right[3]; };

@@ -266,4 +266,5 @@ CONFIGS = {
     "S5mesh": dict(make=lambda: s3(708, as_mesh=True), width=3840, height=2160, maxdepth=1),  # BASELINE configs[4] as written: a 1M-triangle Mesh
     "TS": dict(make=lambda: testscene(10), width=720, height=480, maxdepth=3),  # GlomeView's default scene at its default window (Glome.hs:112-113)
     "TSnooak": dict(make=lambda: testscene(10, with_oak=False), width=720, height=480, maxdepth=3),  # the same without the oak: what rounds 1-2 timed as TS
+    "TSnolattice": dict(make=lambda: testscene(0, with_oak=False), width=720, height=480, maxdepth=3),  # (probe: what the 21^3-sphere lattice costs)
 }

@@ -34,23 +34,6 @@ template <bool FAITHFUL, bool COUNT, bool FULL_> struct HostFlatTier {
   HitG closest_wave(const Ray& r, float tmax, bool valid, uint32_t = 0) { HitG ch; Cand c = closest_flat<FAITHFUL, COUNT, CLS_EVERY, true>(S, r, tmax, stk, cnt, valid, &ch, &err); return valid ? finalize_flat<CLS_EVERY>(S, r, c, &ch) : hit_miss(); }
   bool occluded_wave(const Ray& r, float d, bool valid) { return occluded_flat<COUNT, CLS_EVERY, true>(S, r, d, stk, cnt, valid, &err); }
 };
-struct HostGenericTier {
-  static constexpr bool FULL = true;
-  static constexpr bool WARP = true;
-  const DScene& S;
-  const DLight* lights;
-  int nlights;
-  Cnt cnt;
-  unsigned int err = 0;
-  uint32_t vm[kVmWords];
-  HitG closest(const Ray& r, float tmax, uint32_t root) { return vm_closest<true>(S, cnt, err, vm, r, tmax, root); }
-  bool occluded(const Ray& r, float d, uint32_t root) { return vm_occluded<true>(S, cnt, err, vm, r, d, root); }
-  HitG closest(const Ray& r, float tmax) { return closest(r, tmax, S.root_rec); }
-  bool occluded(const Ray& r, float d) { return occluded(r, d, S.root_rec); }
-  HitG closest_wave(const Ray& r, float tmax, bool valid, uint32_t root) { return valid ? closest(r, tmax, root) : hit_miss(); }
-  bool occluded_wave(const Ray& r, float d, bool valid) { return valid && occluded(r, d); }
-};
-
 struct HostStack {
   // a deliberately small "LDS" part so the overflow columns are exercised by the CPU suite too
   static constexpr int LDS_PART = 6;
@@ -62,6 +45,26 @@ struct HostStack {
     return s;
   }
 };
+struct HostGenericTier {
+  static constexpr bool FULL = true;
+  static constexpr bool WARP = true;
+  const DScene& S;
+  const DLight* lights;
+  int nlights;
+  Cnt cnt;
+  unsigned int err = 0;
+  uint32_t vm[kVmWords];
+  HostStack pkmem;
+  LaneStack pk;  // the packet stack of vm_run's packet service (cap 0: none); packets(): after construction
+  void packets() { pk = pkmem.lane((int)S.pk_generic_cap); if (S.pk_generic_cap == 0) { pk.cap = 0; pk.ovf_cap = 0; } }
+  HitG closest(const Ray& r, float tmax, uint32_t root) { return vm_closest<true>(S, cnt, err, vm, pk.cap > 0 ? &pk : (LaneStack*)nullptr, r, tmax, root); }
+  bool occluded(const Ray& r, float d, uint32_t root) { return vm_occluded<true>(S, cnt, err, vm, pk.cap > 0 ? &pk : (LaneStack*)nullptr, r, d, root); }
+  HitG closest(const Ray& r, float tmax) { return closest(r, tmax, S.root_rec); }
+  bool occluded(const Ray& r, float d) { return occluded(r, d, S.root_rec); }
+  HitG closest_wave(const Ray& r, float tmax, bool valid, uint32_t root) { return valid ? closest(r, tmax, root) : hit_miss(); }
+  bool occluded_wave(const Ray& r, float d, bool valid) { return valid && occluded(r, d); }
+};
+
 
 // the product's launch rule (glome_device.hip launch_render): a flat-tier frame of a scene with a Refract material, traced
 // deeper than the primary ray, is traversed as the reference traverses (its transmitted rays are not unit length)
@@ -84,6 +87,7 @@ void* hostsim_commit(glome_sb* sb, int root, char* errbuf, int cap) {
   D.bihnodes = F.bihnodes.data(); D.pknodes = F.pknodes.data(); D.pknodes_bytes = (uint32_t)(F.pknodes.size() * sizeof(F4)); D.meshhdr = F.meshhdr.data(); D.meshnodes = F.meshnodes.data(); D.mtris = F.mtris.data();
   D.mtrimeta = F.mtrimeta.data(); D.mats = F.mats.data(); D.wlights = F.wlights.data(); D.matkids = F.matkids.data(); D.entries = F.entries.data();
   D.n_entries = F.tier == 0 ? (uint32_t)F.entries.size() : 0; D.root_rec = F.root_rec; D.tier = F.tier; D.n_mats = (uint32_t)sb_graph(sb).mats.size(); D.tex_bits = F.tex_bits;
+  D.pk_generic_cap = (F.tier != 0 && F.max_sphere_bih_depth > 0) ? (uint32_t)std::min(kGenericPacketStack, std::max(4, F.max_sphere_bih_depth)) : 0u;
   return s;
 }
 void hostsim_free(void* s) { delete (SimScene*)s; }
@@ -110,7 +114,7 @@ int hostsim_rayint(void* sv, int tier, int analysis, size_t n, const float* ox, 
       else if (!unit_length(r.d)) { HostFlatTier<true, false, false> T{s->D, nullptr, 0, hs.lane(kFlatStack), Cnt()}; h = T.closest(r, tmax[i]); }  // (k_rayint_batch_flat's rule for a caller's non-unit ray)
       else { HostFlatTier<false, false, false> T{s->D, nullptr, 0, hs.lane(kFlatStack), Cnt()}; h = (analysis & 2) ? T.closest_wave(r, tmax[i], true) : T.closest(r, tmax[i]); }
     } else {
-      HostGenericTier T{s->D, nullptr, 0, Cnt()};
+      HostGenericTier T{s->D, nullptr, 0, Cnt()}; T.packets();
       h = T.closest(r, tmax[i]);
       err |= T.err; total.bih += T.cnt.bih; total.prim += T.cnt.prim; total.mesh += T.cnt.mesh;
     }
@@ -132,7 +136,7 @@ int hostsim_shadow(void* sv, int tier, size_t n, const float* ox, const float* o
   for (size_t i = 0; i < n; i++) {
     Ray r; r.o = v3(ox[i], oy[i], oz[i]); r.d = v3(dx[i], dy[i], dz[i]);
     if (tier == 0) { HostFlatTier<false, false, false> T{s->D, nullptr, 0, hs.lane(kFlatStack), Cnt()}; occ[i] = T.occluded(r, tmax[i]); }
-    else { HostGenericTier T{s->D, nullptr, 0, Cnt()}; occ[i] = T.occluded(r, tmax[i]); err |= T.err; }
+    else { HostGenericTier T{s->D, nullptr, 0, Cnt()}; T.packets(); occ[i] = T.occluded(r, tmax[i]); err |= T.err; }
   }
   return err ? -2 : 0;
 }
@@ -163,7 +167,7 @@ int hostsim_render(void* sv, int tier, const float* cam, const float* lights, in
       HitG h; CA c;
       if (tier == 0 && exact) { HostFlatTier<true, false, true> T{s->D, L, nl, hs.lane(kFlatStack), Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, true, &h); total.shadow += T.cnt.shadow; total.secondary += T.cnt.secondary; }
       else if (tier == 0) { HostFlatTier<false, false, true> T{s->D, L, nl, hs.lane(kFlatStack), Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, true, &h); total.shadow += T.cnt.shadow; total.secondary += T.cnt.secondary; }
-      else { HostGenericTier T{s->D, L, nl, Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, true, &h); err |= T.err; total.shadow += T.cnt.shadow; total.secondary += T.cnt.secondary; }
+      else { HostGenericTier T{s->D, L, nl, Cnt()}; T.packets(); c = trace_primary(T, ray, kInf, maxdepth, true, &h); err |= T.err; total.shadow += T.cnt.shadow; total.secondary += T.cnt.secondary; }
       float* o = out5 + ((size_t)py * width + px) * 5;
       o[0] = c.r; o[1] = c.g; o[2] = c.b; o[3] = c.a; o[4] = h.hit ? h.t : kInf;
     }
@@ -222,7 +226,7 @@ int hostsim_render_subsample(void* sv, int tier, const float* cam, const float* 
     nprim++;
     if (tier == 0 && exact) { HostFlatTier<true, false, true> T{s->D, L, nl, hs.lane(kFlatStack), Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, true, &h); nshadow += T.cnt.shadow; nsec += T.cnt.secondary; }
     else if (tier == 0) { HostFlatTier<false, false, true> T{s->D, L, nl, hs.lane(kFlatStack), Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, true, &h); nshadow += T.cnt.shadow; nsec += T.cnt.secondary; }
-    else { HostGenericTier T{s->D, L, nl, Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, true, &h); err |= T.err; nshadow += T.cnt.shadow; nsec += T.cnt.secondary; }
+    else { HostGenericTier T{s->D, L, nl, Cnt()}; T.packets(); c = trace_primary(T, ray, kInf, maxdepth, true, &h); err |= T.err; nshadow += T.cnt.shadow; nsec += T.cnt.secondary; }
     return tc(c.r, c.g, c.b, c.a, h.hit ? h.t : kInf);
   };
   for (int xt = 0; xt < width;) {
