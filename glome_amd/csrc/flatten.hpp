@@ -22,7 +22,7 @@ struct FlatScene {
   uint32_t root_rec = 0;
   uint32_t tier = 1;
   int nesting_depth = 0, max_bih_depth = 0, max_mesh_depth = 0;
-  int max_sphere_bih_depth = 0;  // deepest BIH whose items are all plain spheres (0: none)
+  int max_sphere_bih_depth = 0;  // deepest BIH whose items are all plain spheres or all plain triangles (0: none)
   uint32_t tex_bits = 16;   // bits per id of a TexStack (rt_types.h): 8 when the scene has at most 254 materials
   int64_t n_other_prims = 0;
   std::string why_generic;  // why the flat tier was not chosen
@@ -523,7 +523,7 @@ class Flattener {
     const uint32_t pkroot = (pk && !T.nodes.empty() && !T.nodes[0].leaf) ? (((base + slot[0]) << 4) | (uint32_t)T.nodes[0].axis) : 0u;
     // (w: the tree's depth -- the generic tier walks a sphere-class tree as a packet when its per-wave stack holds it)
     F.bihhdr[3 * hdr + 2] = F4{as_float_bits(delta), as_float_bits(pkroot), as_float_bits(pk ? 1u : 0u), as_float_bits((uint32_t)T.depth)};
-    if (cls == BC_SPHERE) F.max_sphere_bih_depth = std::max(F.max_sphere_bih_depth, T.depth);
+    if (cls == BC_SPHERE || cls == BC_TRI) F.max_sphere_bih_depth = std::max(F.max_sphere_bih_depth, T.depth);
     return U4{R_BIH, hdr, 0, (uint32_t)n.uid};
   }
 

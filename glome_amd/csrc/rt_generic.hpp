@@ -398,7 +398,7 @@ GDN TexStack vm_meta(const DScene& S, unsigned int& err, uint32_t* m, int base, 
 constexpr int kBihFixedS = kVmBihFixedS, kBihFixedR = kVmBihFixedR, kDiffFixed = kVmDiffFixed, kIsectWords = kVmIsectWords;
 
 // `pk`: the wave's packet stack (LDS rows, rt_device.hpp LaneStack) or null.  With one, a rayint / shadow call whose callee is a
-// BIH of plain spheres (BC_SPHERE: GlomeView's default scene spends three fifths of its frame in the 9,261-sphere lattice,
+// BIH of plain spheres or plain triangles (BC_SPHERE, BC_TRI: GlomeView's default scene spends three fifths of its frame in the 9,261-sphere lattice,
 // which a carving Difference walks again after every advance) is not walked lane by lane over frames: the lane waits in ST_PK_R /
 // ST_PK_S, and once per pass all lanes that wait for the same tree are walked as ONE packet by the flat tier's wave-wide walk
 // (bih_tri_wave: wave-uniform node references, scalar loads, per-lane intervals) -- same hit, same tie order, same counters as
@@ -553,7 +553,7 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, PK* pk
         }
         case R_BIH: {  // rayint_bih, Bih.hs:332-368
           F4 h0 = ld4(S.bihhdr, 3 * rec.y), h1 = ld4(S.bihhdr, 3 * rec.y + 1);
-          if (pk != nullptr && !exact && as_u(h1.w) == BC_SPHERE && (int)as_u(ld4(S.bihhdr, 3 * rec.y + 2).w) <= pk->total_cap()) { pk_hdr = rec.y; st = ST_PK_R; break; }
+          if (pk != nullptr && !exact && (as_u(h1.w) == BC_SPHERE || as_u(h1.w) == BC_TRI) && (int)as_u(ld4(S.bihhdr, 3 * rec.y + 2).w) <= pk->total_cap()) { pk_hdr = rec.y; st = ST_PK_R; break; }
           bbclip_ub(r, v3(h0), v3(h1), nearv, farv);
           farv = gminf(d, farv);  // `traverse root near (fmin d far)`, Bih.hs:368
           ref = as_u(h0.w);
@@ -624,7 +624,7 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, PK* pk
         }
         case R_BIH: {  // shadow_bih, Bih.hs:510-544
           F4 h0 = ld4(S.bihhdr, 3 * rec.y), h1 = ld4(S.bihhdr, 3 * rec.y + 1);
-          if (pk != nullptr && as_u(h1.w) == BC_SPHERE && (int)as_u(ld4(S.bihhdr, 3 * rec.y + 2).w) <= pk->total_cap()) { pk_hdr = rec.y; st = ST_PK_S; break; }
+          if (pk != nullptr && (as_u(h1.w) == BC_SPHERE || as_u(h1.w) == BC_TRI) && (int)as_u(ld4(S.bihhdr, 3 * rec.y + 2).w) <= pk->total_cap()) { pk_hdr = rec.y; st = ST_PK_S; break; }
           bbclip_ub(r, v3(h0), v3(h1), nearv, farv);
           farv = gminf(d, farv);
           ref = as_u(h0.w);
@@ -654,11 +654,13 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, PK* pk
         todo &= ~wave_ballot(mine);
         float pbt = kNoBest;
         uint32_t prec = CAND_NONE;
+        const bool tris = uni(as_u(ld4u(S.bihhdr, 3 * h + 1).w)) == BC_TRI;  // (the tree's leaf class: triangles or spheres)
         if (kind == ST_PK_R) {
-          bih_tri_wave<1, C, 1>(S, h, r, d, mine, *pk, cnt, pbt, prec);
+          if (tris) bih_tri_wave<1, C, 0>(S, h, r, d, mine, *pk, cnt, pbt, prec);
+          else bih_tri_wave<1, C, 1>(S, h, r, d, mine, *pk, cnt, pbt, prec);
           if (mine) { rh = prec != CAND_NONE ? vm_prim_hit<false>(S, cnt, ldu4(S.recs, prec), r, kInf * 8.0f, tex) : hit_miss(); st = ST_RET; }
         } else {
-          const bool occ = bih_tri_wave<2, C, 1>(S, h, r, d, mine, *pk, cnt, pbt, prec);
+          const bool occ = tris ? bih_tri_wave<2, C, 0>(S, h, r, d, mine, *pk, cnt, pbt, prec) : bih_tri_wave<2, C, 1>(S, h, r, d, mine, *pk, cnt, pbt, prec);
           if (mine) { rb = occ; st = ST_RET; }
         }
       }

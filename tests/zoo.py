@@ -215,7 +215,29 @@ def veils(extra_materials=0):
     return _finish(sd, sd.group([pl, a, grp]))
 
 
-ALL = {"flat_mixed": flat_mixed, "quadrics": quadrics, "csg": csg, "nested": nested, "mesh": mesh_scene, "materials": materials, "textures": textures, "veils": veils}
+def instanced_terrain():
+    """One triangle BIH (a 20x20-cell heightfield) used three times -- as it is, rotated and squashed by a non-uniform scale,
+    and carved by a sphere -- beside a rotated lattice of spheres carved like GlomeView's, a mirror and a refracting sphere:
+    the generic tier walks triangle and sphere BIHs inside its interpreter as packets (rt_generic.hpp, vm_run's packet
+    service), for primary, shadow and reflected rays; the refracted ones are not unit length and keep the per-lane walk."""
+    sd = SceneDesc()
+    m = scenes.materials(sd)
+    sand, moss = scenes.matte(sd, (0.8, 0.6, 0.4)), scenes.matte(sd, (0.3, 0.6, 0.3))
+    ids = sd.triangles_bulk(scenes.heightfield_triangles(20) * np.array([0.3, 0.6, 0.3] * 3))
+    terrain = sd.bih(ids)
+    t0 = sd.tex(terrain, sand)
+    t1 = sd.tex(sd.transform(terrain, [api.rotate((0, 1, 0), api.deg(35)), api.scale((0.6, 1.8, 0.9)), api.translate((5.5, 0.4, -1.0))]), moss)
+    t2 = sd.tex(sd.difference(sd.transform(terrain, [api.translate((-6.5, 0.2, 0.5))]), sd.sphere((-6.5, 0.6, 0.5), 1.6)), m["shiny_red"])
+    lattice = sd.bih([sd.sphere((float(x), float(y), float(z)), 0.28) for x in range(-3, 4) for y in range(-3, 4) for z in range(-3, 4)])
+    hollow = sd.tex(sd.difference(sd.transform(lattice, [api.rotate((0, 0, 1), api.deg(23)), api.rotate((1, 0, 0), api.deg(43)), api.scale((0.45, 0.45, 0.45)), api.translate((0.5, 3.2, -2.5))]),
+                                  sd.sphere((0.5, 3.2, -2.5), 1.3)), scenes.matte(sd, (0.9, 0.8, 0.2)))
+    mirror = sd.tex(sd.sphere((2.2, 1.4, 2.2), 0.9), m["mirror"])
+    glass = sd.tex(sd.sphere((-2.0, 1.3, 3.0), 0.8), sd.material_refract(0.3, 0.8, 1.4))
+    sd.set_camera((1.0, 5.5, 11.0), (0.0, 1.0, 0.0), (0, 1, 0), 50)
+    return _finish(sd, sd.group([sd.bih([t0, t1, t2, hollow]), mirror, glass]))
+
+
+ALL = {"flat_mixed": flat_mixed, "quadrics": quadrics, "csg": csg, "nested": nested, "mesh": mesh_scene, "materials": materials, "textures": textures, "veils": veils, "instanced_terrain": instanced_terrain}
 
 
 def soup(n=2500, seed=5, spheres=False, floor=True):
