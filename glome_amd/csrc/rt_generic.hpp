@@ -116,6 +116,66 @@ template <bool C> GD HitG vm_prim_hit(const DScene& S, Cnt& cnt, const U4& rec, 
   return h;
 }
 
+// A callee that is an Instance of a primitive (under Tex wrappers on either side of it) is answered in place too: rayint_instance /
+// shadow_instance (Solid.hs:388-403, 464-471) around the primitive's test -- the same arithmetic in the same order as the
+// VT_INST_R / VT_INST_S frames, without the frame and the passes through the loop.  The oak of GlomeView's default scene is a bih
+// of 2,047 such items.  false: the callee is something else (nothing was computed).
+template <bool C> GD bool vm_inst_prim_hit(const DScene& S, Cnt& cnt, U4 rec, TexStack tex, const Ray& ray, float d, HitG& h) {
+  for (;;) {
+    if (rec.x & RF_NOVIS) { h = hit_miss(); return true; }
+    if ((rec.x & RF_KINDMASK) != R_TEX) break;
+    tex = tex_push(tex, rec.z, (int)S.tex_bits);
+    rec = ldu4(S.recs, rec.y);
+  }
+  if ((rec.x & RF_KINDMASK) != R_INSTANCE) return false;
+  U4 c = ldu4(S.recs, rec.y);
+  bool novis = false;
+  for (;;) {
+    if (c.x & RF_NOVIS) { novis = true; break; }
+    if ((c.x & RF_KINDMASK) != R_TEX) break;
+    tex = tex_push(tex, c.z, (int)S.tex_bits);
+    c = ldu4(S.recs, c.y);
+  }
+  const uint32_t kind = c.x & RF_KINDMASK;
+  if (!novis && !(kind >= R_SPHERE && kind <= R_CONE)) return false;
+  h = hit_miss();
+  if (novis) return true;
+  const Xf6 x = load_xf(S, rec.z);
+  const V3 newdir = mat_vec(x.i0, x.i1, x.i2, ray.d), neworig = mat_point(x.i0, x.i1, x.i2, ray.o);
+  const float lenscale = sqrtf(vdot(newdir, newdir)), invlenscale = 1.0f / lenscale;
+  Ray r; r.o = neworig; r.d = newdir * invlenscale;
+  h = vm_prim_hit<C>(S, cnt, c, r, d * lenscale, tex);
+  if (h.hit) {
+    h.t = h.t * invlenscale;
+    h.p = mat_point(x.f0, x.f1, x.f2, h.p);
+    h.n = vnorm(mat_tvec(x.i0, x.i1, x.i2, h.n));
+  }
+  return true;
+}
+// 0 = not an Instance of a primitive, 1 = it casts no shadow on this ray, 2 = it does
+template <bool C> GD int vm_inst_prim_shadow(const DScene& S, Cnt& cnt, U4 rec, const Ray& ray, float d) {
+  for (;;) {
+    if (rec.x & RF_NOSHADOW) return 1;
+    if ((rec.x & RF_KINDMASK) != R_TEX) break;
+    rec = ldu4(S.recs, rec.y);
+  }
+  if ((rec.x & RF_KINDMASK) != R_INSTANCE) return 0;
+  U4 c = ldu4(S.recs, rec.y);
+  for (;;) {
+    if (c.x & RF_NOSHADOW) return 1;
+    if ((c.x & RF_KINDMASK) != R_TEX) break;
+    c = ldu4(S.recs, c.y);
+  }
+  const uint32_t kind = c.x & RF_KINDMASK;
+  if (!(kind >= R_SPHERE && kind <= R_CONE)) return 0;
+  const Xf6 x = load_xf(S, rec.z);
+  const V3 newdir = mat_vec(x.i0, x.i1, x.i2, ray.d), neworig = mat_point(x.i0, x.i1, x.i2, ray.o);
+  const float lenscale = sqrtf(vdot(newdir, newdir)), invlenscale = 1.0f / lenscale;
+  Ray r; r.o = neworig; r.d = newdir * invlenscale;
+  if (C) cnt.prim++;
+  return prim_shadow(S, kind, c.y, r, d * lenscale) ? 2 : 1;
+}
+
 // `inside s p` (Solid.hs:138-254) over the same word stack, from word `base` up: a run-to-completion loop (the callers are
 // the CSG nodes and Bound, in the middle of a rayint step).  A composite is an OR (List, InnerBound, the leaves of a BIH), an
 // AND (Intersection, Bound, Difference = a && not b) or an Instance (the point moves into its frame).
@@ -435,7 +495,12 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, PK* pk
           U4 it = ldu4(S.recs, cur); cur++; left--;
           const int what = vm_resolve_s(S, it);
           if (what == 1) continue;
-          if (what == 2) { m[fb + 8] = cur; m[fb + 9] = left; rec = it; d = dd; st = ST_CALL_S; called = true; break; }
+          if (what == 2) {
+            const int ip = vm_inst_prim_shadow<C>(S, cnt, it, r, dd);  // an Instance of a primitive: in place
+            if (ip == 2) { rb = true; VM_POP(); st = ST_RET; called = true; break; }
+            if (ip == 1) continue;
+            m[fb + 8] = cur; m[fb + 9] = left; rec = it; d = dd; st = ST_CALL_S; called = true; break;
+          }
           if (C) cnt.prim++;
           if (prim_shadow(S, it.x & RF_KINDMASK, it.y, r, dd)) { rb = true; VM_POP(); st = ST_RET; called = true; break; }
         }
@@ -449,7 +514,14 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, PK* pk
           TexStack t = ftex;
           const int what = vm_resolve_r(S, it, t);
           if (what == 1) continue;
-          if (what == 2) { m[fb + 8] = cur; m[fb + 9] = left; rec = it; tex = ftex; d = tmax; st = ST_CALL_R; called = true; break; }
+          if (what == 2) {
+            HitG h;
+            if (vm_inst_prim_hit<C>(S, cnt, it, ftex, r, tmax, h)) {  // an Instance of a primitive: in place, `rayint s r far` (the node's own far)
+              if (h.hit && (!besthit || !(bestt < h.t))) { vm_st_hit(m, fb + 12, h); besthit = true; bestt = h.t; }
+              continue;
+            }
+            m[fb + 8] = cur; m[fb + 9] = left; rec = it; tex = ftex; d = tmax; st = ST_CALL_R; called = true; break;
+          }
           // a plain primitive other than a quadric answers the same for every tmax beyond its hit: it may be tested against
           // the best so far (the lattice of GlomeView's default scene is 9261 such spheres); a cylinder or a cone sees the
           // node's own `far` (rt_device.hpp bih_traverse, CLAMP)
@@ -842,6 +914,11 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, PK* pk
         const int what = vm_resolve_r(S, c, t);
         if (what == 1) continue;
         if (what == 2) {
+          HitG hi;
+          if (vm_inst_prim_hit<C>(S, cnt, c, ltex, r, ld, hi)) {  // an Instance of a primitive: in place
+            if (hi.hit && (!best.hit || !(best.t < hi.t))) { best = hi; dirty = true; }
+            continue;
+          }
           if (dirty) vm_st_hit(m, fb + 7, best);
           m[fb + 3] = k + 1; rec = c; tex = ltex; d = ld; st = ST_CALL_R; called = true;
           break;
@@ -861,7 +938,12 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, PK* pk
         U4 c = ldu4(S.recs, first + k);
         const int what = vm_resolve_s(S, c);
         if (what == 1) continue;
-        if (what == 2) { m[fb + 3] = k + 1; rec = c; d = ld; st = ST_CALL_S; called = true; break; }
+        if (what == 2) {
+          const int ip = vm_inst_prim_shadow<C>(S, cnt, c, r, ld);  // an Instance of a primitive: in place
+          if (ip == 2) { rb = true; break; }
+          if (ip == 1) continue;
+          m[fb + 3] = k + 1; rec = c; d = ld; st = ST_CALL_S; called = true; break;
+        }
         if (C) cnt.prim++;
         if (prim_shadow(S, c.x & RF_KINDMASK, c.y, r, ld)) { rb = true; break; }
       }
