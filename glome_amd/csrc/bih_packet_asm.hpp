@@ -4,12 +4,13 @@
 // (Bih.hs:332-368, 510-544) once for its 64 rays.  This file is the same walk written out, one instance per octant (the
 // direction signs of a packet are fixed for the whole walk: no direction test, no operand swap) and per mode.
 //
-// What bounds it (round 3; DESIGN.md section 4.6 has the measurements): a walk of the flagship frame is 92 branch steps, 17
-// leaf visits and 25 pops, and the kernel that runs them is bound by the SIMD's SCALAR ISSUE PORT -- scalar ALU, branch and
-// scalar-memory instructions go out at one per ~4.2 cycles per SIMD (tools/probe/valu_rate.hip), the round-2 walk issued 2,470
-// of them per work item, and that port was 75-80 % busy.  What did NOT move the frame time: two more waves per SIMD (3 %), a
-// fifth fewer vector instructions (packed pair tests: 0 %), the next node's fetch taken out of the dependent chain (prefetch:
-// 9 % at one wave per SIMD, 0 % at six).  So this walk is written for the FEWEST SCALAR-TYPE INSTRUCTIONS:
+// What bounds it (round 3; DESIGN.md section 4.1a has the measurements): a walk of the flagship frame is 92 branch steps, 17 leaf
+// visits and 25 pops, about 4,700 instructions, and the frame time follows the INSTRUCTION COUNT one to one -- 736 more per work
+// item cost 6.5 % whether they are scalar, branch or vector instructions, while taking the next node's fetch out of the dependent
+// chain is worth 1.5 % at six waves per SIMD (9 % at one).  A SIMD issues 0.24 scalar instructions per cycle, 0.24 vector
+// instructions with a scalar operand (what a node's planes and a triangle's words are), 0.19-0.23 packed ones and 0.43 of all
+// kinds (tools/probe/valu_rate.hip); the kernel runs at 0.73 of that last figure (0.85 on the 1M-triangle tree).  So this walk is
+// written for the FEWEST INSTRUCTIONS per step, scalar-type ones first (they were the busier port in round 2's walk):
 //
 //   lanes        the set of lanes whose interval reaches the current node lives in EXEC, not in a scalar pair: a vote is a
 //                v_cmp into VCC or a v_cmpx (which narrows EXEC itself) followed by s_cbranch_vccz / s_cbranch_execz -- no

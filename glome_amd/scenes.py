@@ -2,6 +2,8 @@
 (GlomeView/TestScene.hs:17-19 lights, :138 cust_cam, :201-245 materials).  Every generator uses only IEEE-exact
 + - * / and integer hashing, evaluated in double and rounded to fp32 by SceneDesc.
 """
+import os
+
 import numpy as np
 
 from . import api
@@ -195,7 +197,7 @@ def oak(sd, age, seed=42):
     return sd.tag(sd.tex(sd.bih_tolist(sd.flatten_transform(tree(year, _Draws(seed)))), matte(sd, (0.8, 0.5, 0.4))), "tree")
 
 
-def testscene(lattice_n=10, with_oak=True):
+def testscene(lattice_n=10, with_oak=True, skip=()):
     """GlomeView's own default scene, `geom''` of TestScene.hs:183-197 with TestScene's lights, camera and textures, every
     item of it (the `oak`'s random draws come from a stated generator, not GHC's: see _Draws): the chessboard of 64 textured boxes carved by a sphere (a Difference whose first operand is a
     transformed group), the dodecahedron and the transformed icosahedron (Intersections of a sphere with 12 / 20 planes)
@@ -241,6 +243,8 @@ def testscene(lattice_n=10, with_oak=True):
     if with_oak:
         items.append(sd.transform(oak(sd, 11.4, 42), [api.scale((2, 2, 2)), api.translate((2, -1, -8))]))                 # :190
     items += [hollow, door, glass]
+    if skip:  # (measurement only, tools/probe/ts_parts.sh: the scene without some of its items, by position in the list above)
+        items = [it for k, it in enumerate(items) if k not in skip]
     sd.set_root(sd.bih(items))
     _common(sd, 2)
     if with_oak:
@@ -266,5 +270,7 @@ CONFIGS = {
     "S5mesh": dict(make=lambda: s3(708, as_mesh=True), width=3840, height=2160, maxdepth=1),  # BASELINE configs[4] as written: a 1M-triangle Mesh
     "TS": dict(make=lambda: testscene(10), width=720, height=480, maxdepth=3),  # GlomeView's default scene at its default window (Glome.hs:112-113)
     "TSnooak": dict(make=lambda: testscene(10, with_oak=False), width=720, height=480, maxdepth=3),  # the same without the oak: what rounds 1-2 timed as TS
-    "TSnolattice": dict(make=lambda: testscene(0, with_oak=False), width=720, height=480, maxdepth=3),  # (probe: what the 21^3-sphere lattice costs)
+    # (probe: GlomeView's default scene without the items whose positions GLOME_TS_SKIP lists -- 0 board, 1 dodecahedron, 2 icosahedron,
+    # 3 cone, 4 oak, 5 lattice, 6 door, 7 glass sphere)
+    "TSparts": dict(make=lambda: testscene(10, skip=tuple(int(x) for x in os.environ.get("GLOME_TS_SKIP", "").split(",") if x)), width=720, height=480, maxdepth=3),
 }
