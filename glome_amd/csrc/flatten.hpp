@@ -374,6 +374,11 @@ class Flattener {
         std::vector<U4> kids;
         for (int k : n.kids) kids.push_back(emit(k));
         r.x = (n.kind == K_LIST) ? R_LIST : R_ISECT;
+        if (n.kind == K_LIST && !kids.empty()) {
+          bool prims = true;
+          for (const U4& kr : kids) { const uint32_t kk = kr.x & RF_KINDMASK; prims = prims && kk >= R_SPHERE && kk <= R_CONE; }
+          if (prims) r.x |= RF_PRIMLIST;
+        }
         r.y = (uint32_t)F.recs.size(); r.z = (uint32_t)kids.size();
         F.recs.insert(F.recs.end(), kids.begin(), kids.end());
         break;

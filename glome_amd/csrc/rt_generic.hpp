@@ -137,14 +137,23 @@ template <bool C> GD bool vm_inst_prim_hit(const DScene& S, Cnt& cnt, U4 rec, Te
     c = ldu4(S.recs, c.y);
   }
   const uint32_t kind = c.x & RF_KINDMASK;
-  if (!novis && !(kind >= R_SPHERE && kind <= R_CONE)) return false;
+  const bool primlist = kind == R_LIST && (c.x & RF_PRIMLIST);  // a group of primitives (the chessboard of GlomeView's default scene: 64 boxes)
+  if (!novis && !primlist && !(kind >= R_SPHERE && kind <= R_CONE)) return false;
   h = hit_miss();
   if (novis) return true;
   const Xf6 x = load_xf(S, rec.z);
   const V3 newdir = mat_vec(x.i0, x.i1, x.i2, ray.d), neworig = mat_point(x.i0, x.i1, x.i2, ray.o);
   const float lenscale = sqrtf(vdot(newdir, newdir)), invlenscale = 1.0f / lenscale;
   Ray r; r.o = neworig; r.d = newdir * invlenscale;
-  h = vm_prim_hit<C>(S, cnt, c, r, d * lenscale, tex);
+  if (primlist) {  // foldl' nearest RayMiss, every item with the same d (Solid.hs:327, Q9: ties -> the later item)
+    const float dl = d * lenscale;
+    for (uint32_t k = 0; k < c.z; k++) {
+      const U4 cc = ldu4(S.recs, c.y + k);
+      if (cc.x & RF_NOVIS) continue;
+      const HitG hk = vm_prim_hit<C>(S, cnt, cc, r, dl, tex);
+      if (hk.hit && (!h.hit || !(h.t < hk.t))) h = hk;
+    }
+  } else h = vm_prim_hit<C>(S, cnt, c, r, d * lenscale, tex);
   if (h.hit) {
     h.t = h.t * invlenscale;
     h.p = mat_point(x.f0, x.f1, x.f2, h.p);
@@ -167,11 +176,22 @@ template <bool C> GD int vm_inst_prim_shadow(const DScene& S, Cnt& cnt, U4 rec, 
     c = ldu4(S.recs, c.y);
   }
   const uint32_t kind = c.x & RF_KINDMASK;
-  if (!(kind >= R_SPHERE && kind <= R_CONE)) return 0;
+  const bool primlist = kind == R_LIST && (c.x & RF_PRIMLIST);
+  if (!primlist && !(kind >= R_SPHERE && kind <= R_CONE)) return 0;
   const Xf6 x = load_xf(S, rec.z);
   const V3 newdir = mat_vec(x.i0, x.i1, x.i2, ray.d), neworig = mat_point(x.i0, x.i1, x.i2, ray.o);
   const float lenscale = sqrtf(vdot(newdir, newdir)), invlenscale = 1.0f / lenscale;
   Ray r; r.o = neworig; r.d = newdir * invlenscale;
+  if (primlist) {  // foldl' (||) False (Solid.hs:330)
+    const float dl = d * lenscale;
+    for (uint32_t k = 0; k < c.z; k++) {
+      const U4 cc = ldu4(S.recs, c.y + k);
+      if (cc.x & RF_NOSHADOW) continue;
+      if (C) cnt.prim++;
+      if (prim_shadow(S, cc.x & RF_KINDMASK, cc.y, r, dl)) return 2;
+    }
+    return 1;
+  }
   if (C) cnt.prim++;
   return prim_shadow(S, kind, c.y, r, d * lenscale) ? 2 : 1;
 }
@@ -479,7 +499,8 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, PK* pk
 #define VM_TEX(i) ((TexStack)m[fb + (i)] | ((TexStack)m[fb + (i) + 1] << 32))
 // a rayint call issued before ST_RET in the pass: a primitive callee answers at once and the caller's frame goes on in this pass
 #define VM_CALL_R_INLINE() { const int what_ = vm_resolve_r(S, rec, tex); \
-    if (what_ == 2) st = ST_CALL_R; else { rh = what_ == 0 ? vm_prim_hit<C>(S, cnt, rec, r, d, tex) : hit_miss(); st = ST_RET; } }
+    if (what_ == 2) { if (vm_inst_prim_hit<C>(S, cnt, rec, tex, r, d, rh)) st = ST_RET; else st = ST_CALL_R; } \
+    else { rh = what_ == 0 ? vm_prim_hit<C>(S, cnt, rec, r, d, tex) : hit_miss(); st = ST_RET; } }
 #define VM_SET_TEX(i, t) { m[fb + (i)] = (uint32_t)(t); m[fb + (i) + 1] = (uint32_t)((t) >> 32); }
   for (;;) {
     // One pass runs the states in an order that lets the common chains finish inside it: leaf item -> call of a primitive ->
