@@ -317,7 +317,8 @@ def main():
                              "scalar_cache_hit": round(cn["SQC_DCACHE_HITS"] / (cn["SQC_DCACHE_HITS"] + cn["SQC_DCACHE_MISSES"]), 4) if cn.get("SQC_DCACHE_HITS") else None,
                              "lane_utilisation": round(cn["SQ_THREAD_CYCLES_VALU"] / (cn["SQ_ACTIVE_INST_VALU"] * 64.0), 4) if cn.get("SQ_THREAD_CYCLES_VALU") and cn.get("SQ_ACTIVE_INST_VALU") else None,
                              "pmc_kernel_ms": pm.get("kernel_ms"),
-                             "reading": "no pipe is near its ceiling: the waves wait (wave_wait_frac) -- a latency-bound walk; see DESIGN.md 4.6",
+                             "reading": ("issue-bound: the kernel issues at %.2f of the best instruction mix measured on this GPU, and its frame time follows its instruction count (DESIGN.md 4.1a)" % ceil[top]["frac"]) if (top == "issue_all" and ceil[top]["frac"] >= 0.6)
+                                        else "no pipe is near its ceiling: the waves wait (wave_wait_frac) -- latency-bound; see DESIGN.md 4.6 / 4.4a",
                              "note": "counters per launch from the committed rocprofv3 --pmc passes of this launch shape; duration measured live (HIP events); cycles = duration x the clock the counter passes measured"})
         except StopIteration:
             pass
