@@ -374,7 +374,7 @@ class Flattener {
         std::vector<U4> kids;
         for (int k : n.kids) kids.push_back(emit(k));
         r.x = (n.kind == K_LIST) ? R_LIST : R_ISECT;
-        if (n.kind == K_LIST && !kids.empty()) {
+        if (!kids.empty()) {  // (a list or an Intersection of primitives: the generic tier answers those in place)
           bool prims = true;
           for (const U4& kr : kids) { const uint32_t kk = kr.x & RF_KINDMASK; prims = prims && kk >= R_SPHERE && kk <= R_CONE; }
           if (prims) r.x |= RF_PRIMLIST;

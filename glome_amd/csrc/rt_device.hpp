@@ -1090,7 +1090,7 @@ template <bool C> GD HitG leaf_rayint(const DScene& S, Cnt& cnt, U4 rec, const R
   if (C) cnt.prim++;
   float t; V3 n;
   if (!prim_test<true>(S, rec.x & RF_KINDMASK, rec.y, r, d, t, n)) return h;
-  h.hit = true; h.t = t; h.n = n; h.p = vscaleadd(r.o, r.d, t);
+  h.hit = true; h.t = t; h.n = n; h.p = vscaleadd(r.o, r.d, t); h.lo = r.o; h.ld = r.d;  // (lo / ld: riray, read by Warp materials -- generic tier only)
   h.tex = tex_cat(own_stack_rayint(rec.z, (int)S.tex_bits), tex, (int)S.tex_bits); h.uid = rec.w;
   return h;
 }

@@ -562,6 +562,11 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, PK* pk
         m[fb + 5] = as_u(r.o.x); m[fb + 6] = as_u(r.o.y); m[fb + 7] = as_u(r.o.z);
         m[fb + 8] = as_u(d); m[fb + 9] = 0;
         st = ST_DIFF;
+      } else if (rec.x & RF_PRIMLIST) {
+        // an Intersection of primitives (the dodecahedron and the icosahedron of GlomeView's default scene: a sphere and 12 / 20
+        // planes): rayint_intersection as the flat tier's CSG class runs it (csg_isect: the same loop over its own small frames)
+        rh = csg_isect<C>(S, cnt, err, rec, r, d, tex);
+        st = ST_RET;
       } else {  // rayint_intersection, Csg.hs:68-90 (Q14)
         VM_PUSH(VT_ISECT_HS, kIsectWords);
         m[fb + 1] = rec.y; m[fb + 2] = rec.z; m[fb + 3] = 0; VM_SET_TEX(4, tex);

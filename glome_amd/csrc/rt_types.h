@@ -38,7 +38,8 @@ enum RecKind : uint32_t {
 constexpr uint32_t RF_KINDMASK = 0xffu;
 constexpr uint32_t RF_NOVIS = 1u << 8;     // OnlyShadow: rayint misses (Tex.hs:89)
 constexpr uint32_t RF_NOSHADOW = 1u << 9;  // NoShadow: shadow is False (Tex.hs:81)
-constexpr uint32_t RF_PRIMLIST = 1u << 10; // on a list record: every child's record is a primitive's (the generic tier answers an Instance of such a list in place)
+constexpr uint32_t RF_PRIMLIST = 1u << 10; // on a list / Intersection record: every child's record is a primitive's (the generic tier answers an Instance
+                                           // of such a list, and such an Intersection, in place)
 
 enum BihLeafClass : uint32_t { BC_GENERIC = 0, BC_TRI = 1, BC_SPHERE = 2, BC_SIMPLE = 3, BC_CSG = 4 /* primitives and CSG over primitives */ };
 constexpr uint32_t MESH_BRANCH = 0xffffffffu;  // count value marking "ref is a branch node"
