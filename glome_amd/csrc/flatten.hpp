@@ -393,6 +393,10 @@ class Flattener {
       case K_DIFF: case K_BOUND: case K_INNERBOUND: {
         U4 a = emit(n.a), b = emit(n.b);
         r.x = n.kind == K_DIFF ? R_DIFF : (n.kind == K_BOUND ? R_BOUND : R_INNERBOUND);
+        if (n.kind == K_DIFF) {  // (a Difference of two primitives: answered in place by the generic tier)
+          const uint32_t ka = a.x & RF_KINDMASK, kb = b.x & RF_KINDMASK;
+          if (ka >= R_SPHERE && ka <= R_CONE && kb >= R_SPHERE && kb <= R_CONE) r.x |= RF_PRIMLIST;
+        }
         r.y = slot(a); r.z = slot(b);
         break;
       }

@@ -556,7 +556,10 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, PK* pk
       if (!called) { ref = 0xffffffffu; st = ST_BIH; }
     } while (0);
     if (st == ST_ENTER_CSG) do {
-      if ((rec.x & RF_KINDMASK) == R_DIFF) {  // rayint_difference, Csg.hs:33-54 (Q13)
+      if ((rec.x & RF_KINDMASK) == R_DIFF && (rec.x & RF_PRIMLIST)) {  // a Difference of two primitives: the flat tier's loop (csg_diff), in place
+        rh = csg_diff<C>(S, cnt, err, rec, r, d, tex);
+        st = ST_RET;
+      } else if ((rec.x & RF_KINDMASK) == R_DIFF) {  // rayint_difference, Csg.hs:33-54 (Q13)
         VM_PUSH(VT_DIFF_B, kDiffFixed);
         m[fb + 1] = rec.y; m[fb + 2] = rec.z; VM_SET_TEX(3, tex);
         m[fb + 5] = as_u(r.o.x); m[fb + 6] = as_u(r.o.y); m[fb + 7] = as_u(r.o.z);
