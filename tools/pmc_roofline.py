@@ -62,8 +62,12 @@ def main():
             counters[c] = sum(v) / n_units
         if "GRBM_GUI_ACTIVE" in cs:
             clock = (sum(cs["GRBM_GUI_ACTIVE"]) / n_units) / 8.0 / (ms * 1e-3) / 1e9
+    note = None
+    if clock is not None and not (1.0 < clock < 2.6):  # (the GPU's top clock is 2.4 GHz: a pass that reads more counted something else as well)
+        note = "GRBM_GUI_ACTIVE of this pass gives %.2f GHz: discarded, bench.py uses its default clock" % clock
+        clock = None
     res = {"scene": scene, "mode": mode, "kernel": sorted(names), "frames_per_launch": group, "launches_per_pass": max(len(t) // per_unit for t in times.values()) if times else 0,
-           "kernel_ms": round(sum(kernel_ms) / max(1, len(kernel_ms)), 4), "kernel_ms_per_pass": [round(x, 4) for x in kernel_ms], "clock_ghz": round(clock, 4) if clock else None,
+           "kernel_ms": round(sum(kernel_ms) / max(1, len(kernel_ms)), 4), "kernel_ms_per_pass": [round(x, 4) for x in kernel_ms], "clock_ghz": round(clock, 4) if clock else None, **({"clock_note": note} if note else {}),
            "counters": {k: round(v, 1) for k, v in sorted(counters.items())},
            "source_sha16": source_sha16(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),
            "how": "tools/pmc_roofline.sh: one rocprofv3 --kernel-trace --pmc pass per counter group over tools/pmc_run.py (lanes 1: one launch in flight); means per launch of the dominant kernel"}
