@@ -47,7 +47,11 @@ for world in (() if os.environ.get("SHARD_PIPE_ONLY") else (1, 2, 4, 8)):
 class _Done:
     def wait(self):
         return True
-for world, lanes, group in ((8, 4, 16), (8, 2, 16), (8, 3, 16), (4, 4, 16), (2, 4, 16), (8, 4, 8), (8, 4, 4), (4, 4, 4), (4, 4, 8), (2, 4, 8), (2, 4, 4), (1, 4, 1), (1, 4, 2), (1, 2, 4)):
+import os
+_cfgs = ((8, 4, 16), (8, 2, 16), (8, 3, 16), (4, 4, 16), (2, 4, 16), (8, 4, 8), (8, 4, 4), (4, 4, 4), (4, 4, 8), (2, 4, 8), (2, 4, 4), (1, 4, 1), (1, 4, 2), (1, 2, 4))
+if os.environ.get("SHARD_TIMING_CONFIGS"):  # "world,lanes,group;..."
+    _cfgs = tuple(tuple(int(x) for x in c.split(",")) for c in os.environ["SHARD_TIMING_CONFIGS"].split(";"))
+for world, lanes, group in _cfgs:
     sf = dist.ShardedFrame(sc, P, 0, world, dev, lanes=lanes, product="packed", group=group)
     def fake(payload, gathered, async_op=False):
         gathered[0].copy_(payload)
