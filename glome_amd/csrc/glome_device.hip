@@ -1290,6 +1290,10 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
       // more than shared compaction.  One block per region for a frame alone (GlomeView's default scene: 68.5 -> 37.0 ms), two
       // blocks in passes 3-5 of a batch (12.1 -> 9.1 ms per frame; tools/probe/ts_variants.sh with GLOME_DEBUG_SS_REGIONS)
       if (s->dev.tier != 0) { rw = (nframes >= 3 && pass >= 3) ? 2 : 1; rh = 1; }
+      // ... and once the interpreter's rays had become three times cheaper (round 3) a launch of twelve or more frames wants larger
+      // regions in the later passes: 5.8 -> 5.1 ms per frame with 1x1, 2x1, 2x2, 2x2, 3x3 blocks (a launch of eight alone: 7.1 -> 10.2,
+      // so those keep the rule above; profiles/r03_probes/generic_tier_sampler_regions.txt)
+      if (s->dev.tier != 0 && nframes >= 12) { static const int8_t W[6] = {0, 1, 2, 2, 2, 3}, H[6] = {0, 1, 1, 2, 2, 3}; rw = W[pass]; rh = H[pass]; }
       A.ss_rw[pass] = (int8_t)rw; A.ss_rh[pass] = (int8_t)rh;
     }
     if (const char* e = getenv("GLOME_DEBUG_SS_REGIONS")) {  // "1x5,3x5,5x5,5x5,5x5"

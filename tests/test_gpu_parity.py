@@ -676,7 +676,7 @@ def test_reference_default_scene_with_the_full_lattice(gpu_ctx):
     sc.release()
 
 
-@pytest.mark.parametrize("nframes,which", [(3, "S3"), (8, "S3"), (16, "S3"), (3, "testscene")])
+@pytest.mark.parametrize("nframes,which", [(3, "S3"), (8, "S3"), (16, "S3"), (3, "testscene"), (12, "testscene")])
 def test_adaptive_sampler_frame_batches_equal_the_frames_rendered_alone(gpu_ctx, nframes, which):
     """renderTileSubsample over several views in ONE launch (glome_render_packed_batch_dev, mode 1): the sampler then works in
     larger regions per work item (3 frames: medium, 8: a whole tile per pass) -- other packets, the same pixels.  Every frame
