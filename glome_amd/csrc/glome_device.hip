@@ -1077,6 +1077,7 @@ glome_scene* glome_scene_commit(glome_ctx* ctx, glome_sb* sb, int32_t root) {
   // the generic tier's kernels carry an LDS stack of up to kGenericPacketStack entries per lane for packet walks of sphere BIHs (15 KB
   // a wave at 20: eight waves per CU fit); a deeper tree of spheres keeps the per-lane walk
   D.pk_generic_cap = (F.tier != 0 && F.max_sphere_bih_depth > 0) ? (uint32_t)std::min(kGenericPacketStack, std::max(4, F.max_sphere_bih_depth)) : 0u;
+  if (getenv("GLOME_DEBUG_NO_GENERIC_PACKETS")) D.pk_generic_cap = 0;  // (debug switch: every BIH inside the interpreter walked lane by lane -- the test that holds the packet service against it)
   glome_scene_info& I = s->info;
   I.tier = (int32_t)F.tier; I.nesting_depth = F.nesting_depth;
   I.n_records = (int64_t)F.recs.size(); I.n_bih_nodes = (int64_t)F.bihnodes.size(); I.n_mesh_nodes = (int64_t)F.meshnodes.size() / 4;

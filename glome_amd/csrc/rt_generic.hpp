@@ -481,8 +481,8 @@ constexpr int kBihFixedS = kVmBihFixedS, kBihFixedR = kVmBihFixedR, kDiffFixed =
 // BIH of plain spheres or plain triangles (BC_SPHERE, BC_TRI: GlomeView's default scene spends three fifths of its frame in the 9,261-sphere lattice,
 // which a carving Difference walks again after every advance) is not walked lane by lane over frames: the lane waits in ST_PK_R /
 // ST_PK_S, and once per pass all lanes that wait for the same tree are walked as ONE packet by the flat tier's wave-wide walk
-// (bih_tri_wave: wave-uniform node references, scalar loads, per-lane intervals) -- same hit, same tie order, same counters as
-// the per-lane walk (tests: every traversal agrees ray for ray).  A ray that is not unit length keeps the per-lane walk (the
+// (bih_tri_wave: wave-uniform node references, scalar loads, per-lane intervals) -- same hit and same tie order as the per-lane
+// walk: frames are bit-identical with the service switched off (GLOME_DEBUG_NO_GENERIC_PACKETS, GPU test), node counters 2 % apart.  A ray that is not unit length keeps the per-lane walk (the
 // ordered early-out is exact for unit rays only).
 template <bool C, class PK>
 GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, PK* pk, int st, U4 rec, Ray r, float d, bool exact, HitG& rh, bool& rb) {
