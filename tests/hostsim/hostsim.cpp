@@ -5,6 +5,7 @@
 #include <cstring>
 #include <set>
 
+#include <cstdlib>
 #include "host_shim.hpp"  // first: GD / GHD, the one-lane wave, LaneStack -- then the device headers compile for the host
 #include "../../glome_amd/csrc/capi_shared.hpp"
 #include "../../glome_amd/csrc/flatten.hpp"
@@ -88,6 +89,7 @@ void* hostsim_commit(glome_sb* sb, int root, char* errbuf, int cap) {
   D.mtrimeta = F.mtrimeta.data(); D.mats = F.mats.data(); D.wlights = F.wlights.data(); D.matkids = F.matkids.data(); D.entries = F.entries.data();
   D.n_entries = F.tier == 0 ? (uint32_t)F.entries.size() : 0; D.root_rec = F.root_rec; D.tier = F.tier; D.n_mats = (uint32_t)sb_graph(sb).mats.size(); D.tex_bits = F.tex_bits;
   D.pk_generic_cap = (F.tier != 0 && F.max_sphere_bih_depth > 0) ? (uint32_t)std::min(kGenericPacketStack, std::max(4, F.max_sphere_bih_depth)) : 0u;
+  if (getenv("GLOME_DEBUG_NO_GENERIC_PACKETS")) D.pk_generic_cap = 0;  // (the product's switch, glome_device.hip glome_scene_commit)
   return s;
 }
 void hostsim_free(void* s) { delete (SimScene*)s; }

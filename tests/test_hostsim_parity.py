@@ -207,6 +207,33 @@ def test_more_nested_textures_than_the_stack_holds_are_refused(built):
         HostSim(b, nm[five])
 
 
+@pytest.mark.parametrize("name", ["nested", "instanced_terrain", "testscene"])
+def test_generic_tier_packet_service_equals_the_per_lane_walk(built, name):
+    """The packet service of the generic tier's interpreter (sphere / triangle BIHs walked wave-wide, rt_generic.hpp vm_run) against
+    the same scene committed with GLOME_DEBUG_NO_GENERIC_PACKETS, where every BIH is walked over frames: frames, ray counts and the
+    ray-batch seams bit-identical (host build: one lane per wave; the GPU test of the same name runs 64)."""
+    import os
+    sd = zoo.testscene(2) if name == "testscene" else zoo.ALL[name]()
+    cam, lights = product_camera_lights(sd)
+    ro, rd = random_rays(4000, 5, center=(0, 1.5, 0), radius=13, spread=7)
+    out = []
+    for off in (False, True):
+        if off:
+            os.environ["GLOME_DEBUG_NO_GENERIC_PACKETS"] = "1"
+        try:
+            b = api.Builder()
+            nm, _ = sd.replay(b)
+            hs = HostSim(b, nm[sd.root])
+        finally:
+            os.environ.pop("GLOME_DEBUG_NO_GENERIC_PACKETS", None)
+        img, cnt = hs.render(cam, lights, 96, 64, 3)
+        sub, cnts = hs.render_subsample(cam, lights, 96, 64, 3)
+        r = hs.rayint(ro, rd)
+        out.append((img, [int(x) for x in cnt[:3]], sub, [int(x) for x in cnts[:3]], r["t"], r["prim"], r["tex"]))
+    for a_, b_ in zip(*out):
+        assert np.array_equal(np.asarray(a_), np.asarray(b_))
+
+
 @pytest.mark.parametrize("extra", [0, 300])
 def test_texture_stacks_of_eight(built, extra):
     """zoo.veils: eight Tex levels above a sphere, a Difference, BIH items and a mesh triangle (8-bit ids), and the same scene
