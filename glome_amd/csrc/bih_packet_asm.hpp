@@ -8,9 +8,10 @@
 // visits and 25 pops, about 4,700 instructions, and the frame time follows the INSTRUCTION COUNT one to one -- 736 more per work
 // item cost 6.5 % whether they are scalar, branch or vector instructions, while taking the next node's fetch out of the dependent
 // chain is worth 1.5 % at six waves per SIMD (9 % at one).  A SIMD issues 0.24 scalar instructions per cycle, 0.24 vector
-// instructions with a scalar operand (what a node's planes and a triangle's words are), 0.19-0.23 packed ones and 0.43 of all
-// kinds (tools/probe/valu_rate.hip); the kernel runs at 0.73 of that last figure (0.85 on the 1M-triangle tree).  So this walk is
-// written for the FEWEST INSTRUCTIONS per step, scalar-type ones first (they were the busier port in round 2's walk):
+// instructions with a scalar operand (what a node's planes and a triangle's words are), 0.19-0.23 packed ones
+// (tools/probe/valu_rate.hip); the kernel keeps the scalar port 0.57 busy (0.70 on the 1M-triangle tree), the vector port less, and
+// its waves wait for 57 % of their cycles: six waves per SIMD that each execute their own stream serially.  So this walk is
+// written for the FEWEST INSTRUCTIONS per step, scalar-type ones first (the busier port):
 //
 //   lanes        the set of lanes whose interval reaches the current node lives in EXEC, not in a scalar pair: a vote is a
 //                v_cmp into VCC or a v_cmpx (which narrows EXEC itself) followed by s_cbranch_vccz / s_cbranch_execz -- no

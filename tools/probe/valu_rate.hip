@@ -25,6 +25,9 @@ __global__ void __launch_bounds__(64) k(float* out, int iters, float sv) {
     if (KIND == 11) { R8(asm volatile("v_mul_f32 %0, s20, %0\n v_mul_f32 %1, s20, %1\n v_mul_f32 %2, s20, %2\n v_mul_f32 %3, s20, %3\n v_mul_f32 %4, s20, %4\n v_mul_f32 %5, s20, %5\n v_mul_f32 %6, s20, %6\n v_mul_f32 %7, s20, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) :: "s20");) }
     if (KIND == 12) { R8(asm volatile("v_mul_f32 %0, %8, %0\n v_mul_f32 %1, %8, %1\n v_mul_f32 %2, %8, %2\n v_mul_f32 %3, %8, %3\n v_mul_f32 %4, %8, %4\n v_mul_f32 %5, %8, %5\n v_mul_f32 %6, %8, %6\n v_mul_f32 %7, %8, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));) }
     if (KIND == 13) { R8(asm volatile("v_mov_b32 %0, s20\n v_mov_b32 %1, s20\n v_mov_b32 %2, s20\n v_mov_b32 %3, s20\n v_mov_b32 %4, s20\n v_mov_b32 %5, s20\n v_mov_b32 %6, s20\n v_mov_b32 %7, s20" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) :: "s20");) }
+    if (KIND == 14) { R8(asm volatile("v_mul_f32 %0, %8, %0\n s_add_u32 s20, s20, 1\n v_mul_f32 %1, %8, %1\n s_add_u32 s21, s21, 1\n v_mul_f32 %2, %8, %2\n s_add_u32 s20, s20, 1\n v_mul_f32 %3, %8, %3\n s_add_u32 s21, s21, 1\n v_mul_f32 %4, %8, %4\n s_add_u32 s20, s20, 1\n v_mul_f32 %5, %8, %5\n s_add_u32 s21, s21, 1\n v_mul_f32 %6, %8, %6\n s_add_u32 s20, s20, 1\n v_mul_f32 %7, %8, %7\n s_add_u32 s21, s21, 1" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "s20", "s21", "scc");) }
+    if (KIND == 15) { R8(asm volatile("v_mul_f32 %0, %8, %0\n v_mul_f32 %1, %8, %1\n s_add_u32 s20, s20, 1\n v_mul_f32 %2, %8, %2\n v_mul_f32 %3, %8, %3\n s_add_u32 s21, s21, 1\n v_mul_f32 %4, %8, %4\n v_mul_f32 %5, %8, %5\n s_add_u32 s20, s20, 1\n v_mul_f32 %6, %8, %6\n v_mul_f32 %7, %8, %7\n s_add_u32 s21, s21, 1" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "s20", "s21", "scc");) }
+    if (KIND == 16) { R8(asm volatile("v_mul_f32 %0, %8, %0\n s_add_u32 s20, s20, 1\n s_add_u32 s21, s21, 1\n v_mul_f32 %1, %8, %1\n s_add_u32 s22, s22, 1\n s_add_u32 s23, s23, 1\n v_mul_f32 %2, %8, %2\n s_add_u32 s20, s20, 1\n s_add_u32 s21, s21, 1\n v_mul_f32 %3, %8, %3\n s_add_u32 s22, s22, 1\n s_add_u32 s23, s23, 1" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "s20", "s21", "s22", "s23", "scc");) }
     if (KIND == 7) { R8(asm volatile("v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n v_fma_f32 %1, %1, %2, %3\n v_fma_f32 %1, %1, %2, %3\n v_fma_f32 %1, %1, %2, %3" : "+v"(a0), "+v"(a1) : "v"(b), "v"(c));) }
   }
   out[blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
@@ -34,9 +37,9 @@ int main() {
   const int cus = pr.multiProcessorCount, iters = 2000;
   float* out; CK(hipMalloc(&out, (size_t)cus * 32 * 64 * 4));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  const char* names[] = {"v_fma_f32 (vgpr)", "v_pk_fma_f32", "v_fma_f32 (sgpr operand)", "v_cmp_lt_f32 -> vcc", "v_fma + s_add alternating (counted: both)", "s_add_u32", "v_pk_mul / v_pk_add", "v_fma_f32 dependent chains of 4", "v_pk_fma_f32 (sgpr pair operand)", "v_pk_fma_f32 (sgpr pair + op_sel broadcast)", "v_pk_mul_f32 (vgpr, op_sel broadcast)", "v_mul_f32 VOP2 (sgpr operand)", "v_mul_f32 VOP2 (vgpr)", "v_mov_b32 v, s"};
+  const char* names[] = {"v_fma_f32 (vgpr)", "v_pk_fma_f32", "v_fma_f32 (sgpr operand)", "v_cmp_lt_f32 -> vcc", "v_fma + s_add alternating (counted: both)", "s_add_u32", "v_pk_mul / v_pk_add", "v_fma_f32 dependent chains of 4", "v_pk_fma_f32 (sgpr pair operand)", "v_pk_fma_f32 (sgpr pair + op_sel broadcast)", "v_pk_mul_f32 (vgpr, op_sel broadcast)", "v_mul_f32 VOP2 (sgpr operand)", "v_mul_f32 VOP2 (vgpr)", "v_mov_b32 v, s", "v_mul VOP2 (vgpr) + s_add alternating (both)", "2 v_mul (vgpr) : 1 s_add (all)", "1 v_mul (vgpr) : 2 s_add (all)"};
   printf("# instructions per cycle per SIMD at an assumed 2.4 GHz (64 instr per loop body, %d iterations; kind 1/6: one instruction = 2 results per lane)\n", iters);
-  for (int kind = 0; kind < 14; kind++)
+  for (int kind = 0; kind < 17; kind++)
     for (int wps : {1, 6, 8}) {
       float ms = 0;
       for (int rep = 0; rep < 2; rep++) {
@@ -56,12 +59,15 @@ int main() {
           case 10: hipLaunchKernelGGL(k<10>, g, b, 0, 0, out, iters, 1.0001f); break;
           case 11: hipLaunchKernelGGL(k<11>, g, b, 0, 0, out, iters, 1.0001f); break;
           case 12: hipLaunchKernelGGL(k<12>, g, b, 0, 0, out, iters, 1.0001f); break;
-          default: hipLaunchKernelGGL(k<13>, g, b, 0, 0, out, iters, 1.0001f); break;
+          case 13: hipLaunchKernelGGL(k<13>, g, b, 0, 0, out, iters, 1.0001f); break;
+          case 14: hipLaunchKernelGGL(k<14>, g, b, 0, 0, out, iters, 1.0001f); break;
+          case 15: hipLaunchKernelGGL(k<15>, g, b, 0, 0, out, iters, 1.0001f); break;
+          default: hipLaunchKernelGGL(k<16>, g, b, 0, 0, out, iters, 1.0001f); break;
         }
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1));
       }
-      const double n = (kind == 4 ? 128.0 : 64.0) * iters * wps;  // instructions per SIMD
+      const double n = (kind == 4 || kind == 14 ? 128.0 : (kind == 15 || kind == 16 ? 96.0 : 64.0)) * iters * wps;  // instructions per SIMD
       printf("%-44s waves/SIMD %d  %8.3f ms  %.3f instr/cycle/SIMD\n", names[kind], wps, ms, n / (ms * 1e-3 * 2.4e9));
       fflush(stdout);
     }
