@@ -145,7 +145,7 @@ def main():
             # launch, one-GPU rehearsal).  A rank's shard of a frame is a small launch whose fixed part -- it cannot be shorter than
             # its slowest work items -- is shared by the frames it carries: at 8 ranks a 20-step run takes 0.078 / 0.043 / 0.039 ms per
             # step with 1 / 4 / 8 frames per launch, a 100-step run 0.039 / 0.031 / 0.027 with 4 / 8 / 16 (tools/shard_timing.py,
-            # profiles/r03_g_shard_timing.log: 0.040 / 0.038 / 0.027 sustained)
+            # profiles/r03_h_shard_timing.log: 0.040 / 0.038 / 0.027 sustained)
             args.group = (1 if world == 2 else 4) if args.steps < 8 else (4 if args.steps < 16 else (8 if args.steps < 40 else 16))
             if world >= 8 and args.group == 16 and args.lanes == 4:
                 args.lanes = 3
