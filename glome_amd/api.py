@@ -178,6 +178,7 @@ class Builder:
         return self._chk(self.lib.glome_sb_transform(self.h, int(node), arr.ctypes.data_as(L.c_dp), arr.shape[0]), "glome_sb_transform")
 
     def difference(self, a, b): return self._chk(self.lib.glome_sb_difference(self.h, int(a), int(b)), "glome_sb_difference")
+    def difference_retexture(self, a, b): return self._chk(self.lib.glome_sb_difference_retexture(self.h, int(a), int(b)), "glome_sb_difference_retexture")
 
     def mesh(self, verts, norms, tris, mats):
         v = np.ascontiguousarray(np.asarray(verts, dtype=np.float64).reshape(-1, 3))

@@ -94,6 +94,7 @@ int32_t glome_sb_transform(glome_sb* sb, int32_t id, const double* xfms, int n) 
   });
 }
 int32_t glome_sb_difference(glome_sb* sb, int32_t a, int32_t b) { return guard(sb, [&] { return sb->graph.difference(a, b); }); }
+int32_t glome_sb_difference_retexture(glome_sb* sb, int32_t a, int32_t b) { return guard(sb, [&] { return sb->graph.difference(a, b, true); }); }
 int32_t glome_sb_intersection(glome_sb* sb, const int32_t* ids, int n) { return guard(sb, [&] { return sb->graph.intersection(ids_of(ids, n)); }); }
 int32_t glome_sb_bih(glome_sb* sb, const int32_t* ids, int n) { return guard(sb, [&] { return sb->graph.bih(ids_of(ids, n)); }); }
 int32_t glome_sb_mesh(glome_sb* sb, const double* verts, int nv, const double* norms, int nn, const int32_t* tris, int nt, const int32_t* mats, int nm) {

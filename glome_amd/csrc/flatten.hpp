@@ -396,6 +396,7 @@ class Flattener {
         if (n.kind == K_DIFF) {  // (a Difference of two primitives: answered in place by the generic tier)
           const uint32_t ka = a.x & RF_KINDMASK, kb = b.x & RF_KINDMASK;
           if (ka >= R_SPHERE && ka <= R_CONE && kb >= R_SPHERE && kb <= R_CONE) r.x |= RF_PRIMLIST;
+          if (n.retex) r.x |= RF_RETEX;
         }
         r.y = slot(a); r.z = slot(b);
         break;

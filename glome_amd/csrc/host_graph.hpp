@@ -166,6 +166,7 @@ struct Node {
   std::vector<int> kids;
   int a = -1, b = -1; // children of binary composites / wrappers
   int mat = -1;       // K_TEX
+  bool retex = false; // K_DIFF: Difference a b False (difference_retexture, Csg.hs:29-30)
   Xf xf = xf_ident(); // K_INSTANCE
   std::shared_ptr<BihTree> bih;
   std::shared_ptr<MeshData> mesh;
@@ -346,7 +347,7 @@ struct Graph {
   int flatten_transform_item(int id) { return make_list(flatten_transform(id)); }  // Solid.hs:273
   int tolist_node(int id) { std::vector<int> out; tolist(id, out); return make_list(out); }
 
-  int difference(int a, int b) { at(a); at(b); Node n; n.kind = K_DIFF; n.a = a; n.b = b; return add(n); }  // Csg.hs:26-27
+  int difference(int a, int b, bool retexture = false) { at(a); at(b); Node n; n.kind = K_DIFF; n.a = a; n.b = b; n.retex = retexture; return add(n); }  // Csg.hs:26-30
   int intersection(const std::vector<int>& ids) { for (int i : ids) at(i); Node n; n.kind = K_ISECT; n.kids = ids; return add(n); }  // Csg.hs:64-65
   int wrap(int kind, int id, int mat = -1) {
     at(id);

@@ -1121,7 +1121,7 @@ template <bool C> GD HitG csg_diff(const DScene& S, Cnt& cnt, unsigned int& err,
       if (!hb.hit) break;
       if (leaf_inside(S, ra, hb.p) && !leaf_inside(S, rb, vscaleadd(hb.p, r.d, kDel))) {
         hb.n = vneg(hb.n);
-        hb.tex = leaf_meta(S, ra);  // `difference` = Difference a b True: textures of A at the carved point
+        if (!(rec.x & RF_RETEX)) hb.tex = leaf_meta(S, ra);  // `difference` = Difference a b True: textures of A at the carved point; difference_retexture keeps B's (Csg.hs:42-43)
         res = hb;
         break;
       }

@@ -563,7 +563,7 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, PK* pk
         VM_PUSH(VT_DIFF_B, kDiffFixed);
         m[fb + 1] = rec.y; m[fb + 2] = rec.z; VM_SET_TEX(3, tex);
         m[fb + 5] = as_u(r.o.x); m[fb + 6] = as_u(r.o.y); m[fb + 7] = as_u(r.o.z);
-        m[fb + 8] = as_u(d); m[fb + 9] = 0;
+        m[fb + 8] = as_u(d); m[fb + 9] = (rec.x & RF_RETEX) ? 0x80000000u : 0u;  // advances so far; bit 31: Difference a b False (keep B's textures)
         st = ST_DIFF;
       } else if (rec.x & RF_PRIMLIST) {
         // an Intersection of primitives (the dodecahedron and the icosahedron of GlomeView's default scene: a sphere and 12 / 20
@@ -831,7 +831,7 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, PK* pk
               if (vm_inside(S, err, m, sp, ra, rh.p) && !vm_inside(S, err, m, sp, rbrec, vscaleadd(rh.p, r.d, kDel))) {
                 res = rh;
                 res.n = vneg(rh.n);
-                res.tex = vm_meta(S, err, m, sp, ra, rh.p);  // `difference` = Difference a b True: textures of A at the carved point
+                if (!(m[fb + 9] >> 31)) res.tex = vm_meta(S, err, m, sp, ra, rh.p);  // `difference` = Difference a b True: textures of A at the carved point (difference_retexture: B's, Csg.hs:42-43)
               } else { finish = false; adv = rh.t; }
             }
           } else {
@@ -851,13 +851,13 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, PK* pk
               else { finish = false; adv = rh.t; }
             }
           }
-          uint32_t na = m[fb + 9];
+          const uint32_t na = m[fb + 9] & 0x7fffffffu;
           if (!finish) {
             // (the reference advances as often as it takes; here as long as the frame memory lasts -- the commit-time estimate
             // allows kCsgMaxAdvance per Difference, the flat tier's fixed cap)
             VM_NEED(1);
             const float a = adv + kDel;
-            m[sp++] = as_u(a); m[fb + 9] = na + 1;
+            m[sp++] = as_u(a); m[fb + 9] = m[fb + 9] + 1u;
             r.o = vscaleadd(r.o, r.d, a);  // ray_move
             m[fb + 8] = as_u(as_f(m[fb + 8]) - a);
             st = ST_DIFF;

@@ -41,6 +41,9 @@ constexpr uint32_t RF_NOSHADOW = 1u << 9;  // NoShadow: shadow is False (Tex.hs:
 constexpr uint32_t RF_PRIMLIST = 1u << 10; // on a list / Intersection record: every child's record is a primitive's (the generic tier answers an Instance
                                            // of such a list, and such an Intersection, in place)
 
+constexpr uint32_t RF_RETEX = 1u << 11;    // on a Difference record: `Difference a b False` (difference_retexture, Csg.hs:29-30, 42-43): a carved surface keeps
+                                           // the textures B's hit came with instead of taking A's at the point
+
 enum BihLeafClass : uint32_t { BC_GENERIC = 0, BC_TRI = 1, BC_SPHERE = 2, BC_SIMPLE = 3, BC_CSG = 4 /* primitives and CSG over primitives */ };
 constexpr uint32_t MESH_BRANCH = 0xffffffffu;  // count value marking "ref is a branch node"
 

@@ -125,7 +125,7 @@ struct ShowWriter {
       case K_CONE: o += "Cone "; arg(p[0]); o += ' '; arg(p[1]); o += ' '; arg(p[2]); o += ' '; arg(p[3]); break;
       case K_LIST: items(n.kids); break;  // instance Solid [SolidItem t m]: the list's own Show
       case K_INSTANCE: o += "Instance "; item(n.a); o += " (Xfm "; matrix(n.xf.f); o += ' '; matrix(n.xf.i); o += ')'; break;
-      case K_DIFF: o += "Difference "; item(n.a); o += ' '; item(n.b); o += " True"; break;  // `difference`, Csg.hs:26-27
+      case K_DIFF: o += "Difference "; item(n.a); o += ' '; item(n.b); o += n.retex ? " False" : " True"; break;  // `difference` / `difference_retexture`, Csg.hs:26-30
       case K_ISECT: o += "Intersection "; items(n.kids); break;
       case K_BOUND: o += "Bound "; item(n.a); o += ' '; item(n.b); break;
       case K_INNERBOUND: o += "InnerBound "; item(n.a); o += ' '; item(n.b); break;
@@ -297,9 +297,8 @@ struct ShowReader {
     if (c == "Difference") {
       int a = item(), b = item();
       std::string flag = name();
-      if (flag == "False") fail("Difference _ _ False (difference_retexture, Csg.hs:29-30) is not supported");
-      if (flag != "True") fail("expected True or False");
-      return G.difference(a, b);
+      if (flag != "True" && flag != "False") fail("expected True or False");
+      return G.difference(a, b, flag == "False");  // False: difference_retexture (Csg.hs:29-30)
     }
     if (c == "Intersection") return G.intersection(items());
     if (c == "Bound") { int a = item(), b = item(); return G.bound_object(a, b, false); }

@@ -12,7 +12,7 @@ def r32(x):
 
 
 NODE_OPS = {"sphere", "triangle", "trianglenorm", "box", "plane", "plane_offset", "disc", "cylinder", "cone", "group",
-            "transform", "difference", "intersection", "bih", "mesh", "tex", "tag", "noshadow", "onlyshadow", "bound_object",
+            "transform", "difference", "difference_retexture", "intersection", "bih", "mesh", "tex", "tag", "noshadow", "onlyshadow", "bound_object",
             "innerbound", "flatten_transform", "tolist", "triangles_bulk"}
 MAT_OPS = {"material_surface", "material_reflect", "material_refract", "material_layers", "material_blend", "material_blend_fn", "material_warp"}
 
@@ -53,6 +53,7 @@ class SceneDesc:
     def group(self, ids): return self._node("group", list(ids))
     def transform(self, node, xfms): return self._node("transform", node, [np.asarray(x, dtype=np.float64) for x in xfms])
     def difference(self, a, b): return self._node("difference", a, b)
+    def difference_retexture(self, a, b): return self._node("difference_retexture", a, b)  # Csg.hs:29-30
     def intersection(self, ids): return self._node("intersection", list(ids))
     def bih(self, ids): return self._node("bih", list(ids))
     def mesh(self, verts, norms, tris, mats):
@@ -125,7 +126,7 @@ class SceneDesc:
                 nmap.append(getattr(backend, name)([N(i) for i in args[0]]))
             elif name == "transform":
                 nmap.append(backend.transform(N(args[0]), args[1]))
-            elif name in ("difference", "bound_object", "innerbound"):
+            elif name in ("difference", "difference_retexture", "bound_object", "innerbound"):
                 nmap.append(getattr(backend, name)(N(args[0]), N(args[1])))
             elif name == "tex":
                 nmap.append(backend.tex(N(args[0]), mmap[args[1]]))

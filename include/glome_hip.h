@@ -98,6 +98,7 @@ int32_t glome_sb_cone(glome_sb*, const double p1[3], double r1, const double p2[
 int32_t glome_sb_group(glome_sb*, const int32_t* ids, int n);                                    /* Solid.hs:293-296 */
 int32_t glome_sb_transform(glome_sb*, int32_t id, const double* xfms /* n*24 */, int n);         /* Solid.hs:184,235 */
 int32_t glome_sb_difference(glome_sb*, int32_t a, int32_t b);                                    /* Csg.hs:26-27 */
+int32_t glome_sb_difference_retexture(glome_sb*, int32_t a, int32_t b);                          /* Csg.hs:29-30: `Difference a b False` -- the surface hollowed out by b keeps b's textures (Csg.hs:42-43) */
 int32_t glome_sb_intersection(glome_sb*, const int32_t* ids, int n);                             /* Csg.hs:64-65 */
 int32_t glome_sb_bih(glome_sb*, const int32_t* ids, int n);                                      /* Bih.hs:309-324 */
 /* tris: 8 ints per triangle = a b c na nb nc tex tag (-1 = none), Mesh.hs:27-29; mats = the mesh's texture vector */
@@ -131,7 +132,7 @@ int32_t glome_sb_load_nff(glome_sb*, const char* text, double cam_from_at_up_ang
  * TestScene.hs -- into the builder, Bih and Mesh trees exactly as printed, and returns the root.  Materials are closures
  * on the Haskell side and print as "Texture": the k-th `Tex` of the text (reading order) gets tex_materials[k], the
  * rest default_material (-1: fail); *n_tex = how many the text holds.  Tags and mesh vertex normals are not printed by
- * the reference and do not survive (a mesh with normals is refused); `Difference _ _ False` is refused. */
+ * the reference and do not survive (a mesh with normals is refused); `Difference _ _ False` reads as glome_sb_difference_retexture. */
 long glome_sb_show(glome_sb*, int32_t id, char* buf, long cap);
 /* the material ids of the `Tex` constructors of that text, in reading order (what the text itself cannot carry): returns
  * their number, writes at most cap of them */

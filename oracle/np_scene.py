@@ -539,12 +539,13 @@ def rayint_advance(s, o, d, dist, texs, adv):  # Solid.hs:85-91
 
 
 class Difference(Solid):  # Csg.hs
-    def __init__(self, a, b): self.a, self.b = a, b
+    def __init__(self, a, b, useatex=True): self.a, self.b, self.useatex = a, b, useatex  # False: difference_retexture (:29-30)
     def rayint(self, o, d, dist, texs):  # :33-54 (Q13), recursive like the reference
         if self.b.inside(o):
             hb = self.b.rayint(o, d, dist, texs)
             if hb is None: return None
             if self.a.inside(hb[1]) and not self.b.inside(vscaleadd(hb[1], d, DELTA)):
+                if not self.useatex: return (hb[0], hb[1], vinvert(hb[2])) + hb[3:]  # `RayHit bd bp (vinvert bn) ray uvw bt btags` (:43)
                 return (hb[0], hb[1], vinvert(hb[2]), self.a.get_metainfo(hb[1]), hb[4], hb[5])  # useatex: textures of A at the point
             return rayint_advance(self, o, d, dist, texs, hb[0])
         ha = self.a.rayint(o, d, dist, texs)
@@ -779,6 +780,7 @@ class Scene:
         xs = self.nodes[i].tolist()
         return self._add(Bih(xs) if xs else Void())
     def difference(self, a, b): return self._add(Difference(self.nodes[a], self.nodes[b]))
+    def difference_retexture(self, a, b): return self._add(Difference(self.nodes[a], self.nodes[b], False))
     def intersection(self, ids): return self._add(Intersection([self.nodes[i] for i in ids]))
     def transform(self, node, xfms): return self._add(self.nodes[node].transform(compose(xfms)))
     def tex(self, node, mat): return self._add(Tex(self.nodes[node], mat))

@@ -25,7 +25,7 @@ struct IOracle {
   virtual int cone(const double* p1, double r1, const double* p2, double r2) = 0;
   virtual int group(const int* ids, int n) = 0;
   virtual int transform(int id, const double* xfms, int n) = 0;
-  virtual int difference(int a, int b) = 0;
+  virtual int difference(int a, int b, bool useatex = true) = 0;
   virtual int intersection(const int* ids, int n) = 0;
   virtual int bih(const int* ids, int n) = 0;
   virtual int mesh(const double* verts, int nv, const double* norms, int nn, const int* tris, int nt, const int* mats, int nm) = 0;
@@ -150,9 +150,9 @@ template <class R> struct Impl : IOracle {
     SP<R> s = get(id)->transform(xs, nextid());
     return add(s, false);
   }
-  int difference(int a, int b) override {  // Csg.hs:26-27
+  int difference(int a, int b, bool useatex) override {  // Csg.hs:26-30
     auto d = std::make_shared<Difference<R>>();
-    d->sa = get(a); d->sb = get(b); d->useatex = true;
+    d->sa = get(a); d->sb = get(b); d->useatex = useatex;
     return add(d);
   }
   int intersection(const int* ids, int n) override {  // Csg.hs:64-65
@@ -336,6 +336,7 @@ int glo_cone(void* h, const double* p1, double r1, const double* p2, double r2) 
 int glo_group(void* h, const int* ids, int n) { return guard(h, [&](IOracle* o) { return o->group(ids, n); }); }
 int glo_transform(void* h, int id, const double* xfms, int n) { return guard(h, [&](IOracle* o) { return o->transform(id, xfms, n); }); }
 int glo_difference(void* h, int a, int b) { return guard(h, [&](IOracle* o) { return o->difference(a, b); }); }
+int glo_difference_retexture(void* h, int a, int b) { return guard(h, [&](IOracle* o) { return o->difference(a, b, false); }); }  // Csg.hs:29-30
 int glo_intersection(void* h, const int* ids, int n) { return guard(h, [&](IOracle* o) { return o->intersection(ids, n); }); }
 int glo_bih(void* h, const int* ids, int n) { return guard(h, [&](IOracle* o) { return o->bih(ids, n); }); }
 int glo_mesh(void* h, const double* verts, int nv, const double* norms, int nn, const int* tris, int nt, const int* mats, int nm) {

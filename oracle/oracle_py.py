@@ -106,6 +106,7 @@ class Oracle:
         return self._chk(self.L.glo_transform(self.h, C.c_int(int(node)), _dp(arr), C.c_int(arr.shape[0])), "glo_transform")
 
     def difference(self, a, b): return self._chk(self.L.glo_difference(self.h, C.c_int(int(a)), C.c_int(int(b))), "glo_difference")
+    def difference_retexture(self, a, b): return self._chk(self.L.glo_difference_retexture(self.h, C.c_int(int(a)), C.c_int(int(b))), "glo_difference_retexture")
 
     def mesh(self, verts, norms, tris, mats):
         v = np.ascontiguousarray(np.asarray(verts, dtype=np.float64).reshape(-1, 3))

@@ -141,7 +141,7 @@ def _frames(sd, w, h, maxdepth):
 
 
 _FRAMES = [("S1", 48, 32, 1), ("S3small", 40, 24, 1), ("S3mesh_small", 40, 24, 1), ("S4", 48, 27, 3), ("csg", 40, 30, 3), ("flat_mixed", 40, 30, 3),
-           ("materials", 40, 30, 3), ("mesh", 40, 30, 3), ("mirror_terrain", 40, 30, 3), ("nested", 40, 30, 3), ("portal", 56, 42, 3), ("quadrics", 40, 30, 3),
+           ("materials", 40, 30, 3), ("mesh", 40, 30, 3), ("mirror_terrain", 40, 30, 3), ("nested", 40, 30, 3), ("portal", 56, 42, 3), ("quadrics", 40, 30, 3), ("retexture", 48, 30, 3),
            ("testscene", 64, 48, 3), ("textures", 40, 30, 3)]
 
 

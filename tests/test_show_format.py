@@ -79,7 +79,98 @@ def test_hand_written_literal_loads_and_traces_like_the_oracle(built):
     assert np.allclose(got["t"][hit], want["t"][hit], rtol=2e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("name", ["flat_mixed", "quadrics", "csg", "nested", "materials", "textures", "soup"])
+# Conformance vectors for `show geom` (Glome.hs:431), typed by hand from GHC's rules -- NOT produced by glome_sb_show:
+#   * a derived Show instance prints `Con a b ..` with every argument at precedence 11, so an argument that is itself an
+#     application, or a negative number, stands in parentheses (Haskell 2010 report 11.4; showSignedFloat parenthesises x < 0 and
+#     -0.0 above precedence 6); record syntax prints `Con {f = v, ..}` with the fields at precedence 0 (no parentheses inside),
+#     and the record as a whole is parenthesised as an argument (Bbox, Vec.hs:646; Bih, Bih.hs:52);
+#   * showFloat: fixed notation for 0.1 <= x < 10^7, otherwise d.ddde<n> with the shortest digits that read back;
+#   * SolidItem, Tag and Texture have hand-written `show` (Solid.hs:277-278, Tex.hs:50-51, Solid.hs:101-102): "SI " ++ show s,
+#     "<Tag " ++ show s ++ ">", "Texture" -- never parenthesised, whatever the context (the class default showsPrec ignores the
+#     precedence);
+#   * a list prints as [a,b,c], no spaces, elements at precedence 0 (showList).
+# Each row: what the constructors build, and the text GHC prints for it.  Checked three ways: the writer prints exactly this, the
+# reader takes it and prints it back, and the reader's scene is the constructors' scene (same primitive count, bound, rays).
+_CONFORMANCE = [
+    # negative doubles and negative zero as constructor arguments; `plane_offset pt off = Plane pt off` (Plane.hs:24-25)
+    (lambda b, m: b.plane_offset((0.0, 1.0, -0.0), -0.5), "SI Plane (Vec 0.0 1.0 (-0.0)) (-0.5)"),
+    # the switch between fixed and exponent notation at 0.1 and 10^7; `sphere c r = Sphere c r (1.0/r)` (Sphere.hs:15-17)
+    (lambda b, m: b.sphere((1.0e-2, 1.0e7, 9999999.0), 0.1), "SI Sphere (Vec 1.0e-2 1.0e7 9999999.0) 0.1 10.0"),
+    (lambda b, m: b.sphere((0.099, 12345678.0, -1234567.5), 4.0), "SI Sphere (Vec 9.9e-2 1.2345678e7 (-1234567.5)) 4.0 0.25"),
+    # SI inside derived constructors: no parentheses around an item, `Texture` for the closure
+    (lambda b, m: b.tex(b.noshadow(b.onlyshadow(b.sphere((0, 0, 0), 1))), m), "SI Tex SI NoShadow SI OnlyShadow SI Sphere (Vec 0.0 0.0 0.0) 1.0 1.0 Texture"),
+    (lambda b, m: b.tag(b.tag(b.sphere((0, 0, 0), 1))), "SI <Tag SI <Tag SI Sphere (Vec 0.0 0.0 0.0) 1.0 1.0>>"),
+    # lists: Intersection [SolidItem] (Csg.hs:15), a group inside it (the list instance's own Show, Solid.hs:326)
+    (lambda b, m: b.intersection([b.sphere((0, 0, 0), 2), b.plane_offset((1, 0, 0), 1.0), b.group([b.sphere((0, 0, 0), 1), b.sphere((1, 0, 0), 1)])]),
+     "SI Intersection [SI Sphere (Vec 0.0 0.0 0.0) 2.0 0.5,SI Plane (Vec 1.0 0.0 0.0) 1.0,SI [SI Sphere (Vec 0.0 0.0 0.0) 1.0 1.0,SI Sphere (Vec 1.0 0.0 0.0) 1.0 1.0]]"),
+    # `group []` = Void, `group [x]` = x (Solid.hs:293-296)
+    (lambda b, m: b.group([]), "SI Void"),
+    (lambda b, m: b.group([b.sphere((0, 0, 0), 1)]), "SI Sphere (Vec 0.0 0.0 0.0) 1.0 1.0"),
+    # a record as an argument: parenthesised as a whole, fields bare
+    (lambda b, m: b.bound_object(b.sphere((0, 0, 0), 2), b.box((-1, -1, -1), (1, 1, 1))),
+     "SI Bound SI Sphere (Vec 0.0 0.0 0.0) 2.0 0.5 SI Box (Bbox {p1 = Vec (-1.0) (-1.0) (-1.0), p2 = Vec 1.0 1.0 1.0})"),
+    (lambda b, m: b.innerbound(b.sphere((0, 0, 0), 2), b.box((-1, -1, -1), (1, 1, 1))),
+     "SI InnerBound SI Sphere (Vec 0.0 0.0 0.0) 2.0 0.5 SI Box (Bbox {p1 = Vec (-1.0) (-1.0) (-1.0), p2 = Vec 1.0 1.0 1.0})"),
+    # Instance (Solid.hs:386) with Xfm = forward and inverse Matrix (Vec.hs:407-414): scale (2,1,1) then translate (-2,3,0)
+    (lambda b, m: b.transform(b.sphere((0, 0, 0), 1), [api.scale((2, 1, 1)), api.translate((-2, 3, 0))]),
+     "SI Instance SI Sphere (Vec 0.0 0.0 0.0) 1.0 1.0 (Xfm (Matrix 2.0 0.0 0.0 (-2.0) 0.0 1.0 0.0 3.0 0.0 0.0 1.0 0.0) (Matrix 0.5 0.0 0.0 1.0 0.0 1.0 0.0 (-3.0) 0.0 0.0 1.0 0.0))"),
+    # Bih {bihbb, bihroot} (Bih.hs:51-57): three objects or fewer stay one leaf (Bih.hs:222)
+    (lambda b, m: b.bih([b.sphere((0, 0, 0), 0.5), b.sphere((1, 0, 0), 0.5)]),
+     "SI Bih {bihbb = Bbox {p1 = Vec (-0.5) (-0.5) (-0.5), p2 = Vec 1.5 0.5 0.5}, bihroot = BihLeaf [SI Sphere (Vec 0.0 0.0 0.0) 0.5 2.0,SI Sphere (Vec 1.0 0.0 0.0) 0.5 2.0]}"),
+    # ... four split once along x: planes lmax + delta = 1.5001, rmin - delta = 9.4999 (Bih.hs:262-266), nested nodes parenthesised
+    (lambda b, m: b.bih([b.sphere((0, 0, 0), 0.5), b.sphere((1, 0, 0), 0.5), b.sphere((10, 0, 0), 0.5), b.sphere((11, 0, 0), 0.5)]),
+     "SI Bih {bihbb = Bbox {p1 = Vec (-0.5) (-0.5) (-0.5), p2 = Vec 11.5 0.5 0.5}, bihroot = BihBranch 1.5001 9.4999 0 "
+     "(BihLeaf [SI Sphere (Vec 0.0 0.0 0.0) 0.5 2.0,SI Sphere (Vec 1.0 0.0 0.0) 0.5 2.0]) (BihLeaf [SI Sphere (Vec 10.0 0.0 0.0) 0.5 2.0,SI Sphere (Vec 11.0 0.0 0.0) 0.5 2.0])}"),
+    # Difference a b Bool (Csg.hs:14): `difference` True, `difference_retexture` False (Csg.hs:26-30)
+    (lambda b, m: b.difference(b.sphere((0, 0, 0), 1), b.sphere((1, 0, 0), 1)), "SI Difference SI Sphere (Vec 0.0 0.0 0.0) 1.0 1.0 SI Sphere (Vec 1.0 0.0 0.0) 1.0 1.0 True"),
+    (lambda b, m: b.difference_retexture(b.sphere((0, 0, 0), 1), b.sphere((1, 0, 0), 1)), "SI Difference SI Sphere (Vec 0.0 0.0 0.0) 1.0 1.0 SI Sphere (Vec 1.0 0.0 0.0) 1.0 1.0 False"),
+    (lambda b, m: b.triangle((0, 0, 0), (1, 0, 0), (0, 1, 0)), "SI Triangle (Vec 0.0 0.0 0.0) (Vec 1.0 0.0 0.0) (Vec 0.0 1.0 0.0)"),
+    # `disc pos norm r = Disc pos norm (r*r)` (Cone.hs:29-31): the normal as given, the radius squared
+    (lambda b, m: b.disc((0, 1, 0), (0, 0, 2), 0.5), "SI Disc (Vec 0.0 1.0 0.0) (Vec 0.0 0.0 2.0) 0.25"),
+    # `cylinder` / `cone` = the canonical z-axis solid inside a transform (Cone.hs:40-67): Cylinder r 0 len; Cone r1 0 len (r1*len/(r1-r2))
+    (lambda b, m: b.cylinder((0, 0, 0), (0, 0, 2), 0.5),
+     "SI Instance SI Cylinder 0.5 0.0 2.0 (Xfm (Matrix 0.0 (-1.0) 0.0 0.0 1.0 0.0 0.0 0.0 0.0 0.0 1.0 0.0) (Matrix 0.0 1.0 0.0 0.0 (-1.0) 0.0 0.0 0.0 0.0 0.0 1.0 0.0))"),
+    (lambda b, m: b.cone((0, 0, 0), 1.0, (0, 0, 2), 0.5),
+     "SI Instance SI Cone 1.0 0.0 2.0 4.0 (Xfm (Matrix 0.0 (-1.0) 0.0 0.0 1.0 0.0 0.0 0.0 0.0 0.0 1.0 0.0) (Matrix 0.0 1.0 0.0 0.0 (-1.0) 0.0 0.0 0.0 0.0 0.0 1.0 0.0))"),
+    # showFloat's names for the non-finite values; a negative one is parenthesised like any negative number
+    (lambda b, m: b.plane_offset((0, 1, 0), float("-inf")), "SI Plane (Vec 0.0 1.0 0.0) (-Infinity)"),
+]
+
+
+@pytest.mark.parametrize("k", range(len(_CONFORMANCE)))
+def test_show_conformance_vectors(built, k):
+    make, literal = _CONFORMANCE[k]
+    b = api.Builder()
+    m = b.material_surface((1, 0, 0), 1, 0.2, 0.8, 0, 0)
+    made = make(b, m)
+    assert b.show(made) == literal                       # the writer against the rule
+    root, ntex = b.load_show(literal, [m] * literal.count("Texture"))
+    assert ntex == literal.count("Texture")
+    assert b.show(root) == literal                       # the reader takes it, and loses nothing
+    assert showfmt.parse(literal)[0] == "SI"             # (and so does the independent reader)
+    assert b.primcount(root) == b.primcount(made)
+    if "Infinity" in literal or "Void" in literal:
+        return
+    assert np.array_equal(b.bound(root), b.bound(made))
+    ro, rd = random_rays(300, 17 + k, center=(0.5, 0.5, 0.5), radius=6, spread=3)
+    g1, g2 = HostSim(b, made).rayint(ro, rd), HostSim(b, root).rayint(ro, rd)
+    for key in ("t", "n", "tex"):
+        assert np.array_equal(g1[key], g2[key]), key
+
+
+def test_reader_takes_text_the_writer_never_prints(built):
+    # text a GHC dump can contain that glome_sb_show itself never produces: branch planes and boxes that no builder call made
+    # (the reader must take the tree as written, not rebuild it), and a leaf with more than three items
+    text = ("SI Bih {bihbb = Bbox {p1 = Vec (-1.0) (-1.0) (-1.0), p2 = Vec 4.0 1.0 1.0}, bihroot = BihBranch 0.75 2.25 0 "
+            "(BihLeaf [SI Sphere (Vec 0.0 0.0 0.0) 0.75 1.3333333333333333]) "
+            "(BihBranch 0.5 (-0.5) 1 (BihLeaf [SI Sphere (Vec 3.0 0.0 0.0) 0.5 2.0,SI Sphere (Vec 3.0 0.25 0.0) 0.5 2.0,SI Sphere (Vec 3.0 (-0.25) 0.0) 0.5 2.0,SI Sphere (Vec 3.0 0.0 0.25) 0.5 2.0]) (BihLeaf []))}")
+    b = api.Builder()
+    root, ntex = b.load_show(text, [])
+    assert ntex == 0 and b.show(root) == text and b.primcount(root)[0] == 5
+    tree = showfmt.parse(text)
+    assert tree[1][0] == "Bih" and tree[1][2][0] == "BihBranch" and tree[1][2][3] == 0 and tree[1][2][5][3] == 1
+
+@pytest.mark.parametrize("name", ["flat_mixed", "quadrics", "csg", "nested", "materials", "textures", "soup", "retexture"])
 def test_round_trip_is_the_same_scene(built, name):
     sd = zoo.soup(300) if name == "soup" else getattr(zoo, name)()
     b, root, _ = _build(sd)
@@ -199,7 +290,7 @@ def test_reader_errors(built):
     b = api.Builder()
     m = b.material_reflect(0.5)
     for text, what in [("SI Sphere (Vec 0.0 0.0 0.0) 1.0", "number"), ("SI Torus 1.0 2.0", "unknown solid"), ("SI Void SI Void", "after the scene"),
-                       ("SI Difference SI Void SI Void False", "difference_retexture"), ("SI Tex SI Void Texture", "no material"),
+                       ("SI Difference SI Void SI Void Maybe", "True or False"), ("SI Tex SI Void Texture", "no material"),
                        ("SI Bih {bihbb = Bbox {p1 = Vec 0.0 0.0 0.0, p2 = Vec 1.0 1.0 1.0}, bihroot = BihBranch 0.5 0.5 3 (BihLeaf []) (BihLeaf [])}", "axis"),
                        ("Sphere (Vec 0.0 0.0 0.0) 1.0 1.0", "expected SI"), ("SI [SI Void,", "expected SI")]:
         with pytest.raises(api.GlomeError, match=what):

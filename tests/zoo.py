@@ -322,6 +322,37 @@ def portal():
 ALL["portal"] = portal
 
 
+def retexture():
+    """`difference_retexture` = `Difference a b False` (Csg.hs:29-30): the surface hollowed out by b is rendered with b's
+    textures -- the stack b's own rayint returned, `bt` (Csg.hs:43) -- where `difference` takes a's at the point (Csg.hs:39-42).
+    Every tier that answers a Difference: the flat tier's CSG class (two primitives, bare and inside an Instance), the generic
+    tier in place (two primitives below a composite) and over frames (a group carved by a bih of spheres), each beside the same
+    solid built with `difference`; and one under an outer Tex, whose id b's stack ends with."""
+    sd = SceneDesc()
+    m = scenes.materials(sd)
+    gold, teal, pink = sd.material_surface((0.9, 0.7, 0.2), 1, 0.2, 0.8, 0.4, 10), scenes.matte(sd, (0.1, 0.7, 0.7)), scenes.matte(sd, (1, 0.4, 0.7))
+
+    def carved(mk, at, outer=None):
+        x, z = at
+        a = sd.tex(sd.box((x - 1, 0.03, z - 1), (x + 1, 2, z + 1)), gold)  # (clear of the floor: coplanar faces tie differently in fp32)
+        b = sd.tex(sd.sphere((x + 0.6, 2.0, z + 0.9), 1.0), m["shiny_red"])
+        d = mk(a, b)
+        return sd.tex(d, outer) if outer is not None else d
+    flat = [carved(sd.difference_retexture, (-4.5, 2)), carved(sd.difference, (-1.5, 2)), carved(sd.difference_retexture, (1.5, 2), outer=teal)]
+    inst = sd.transform(carved(sd.difference_retexture, (0, 0)), [api.rotate((0, 1, 0), api.deg(35)), api.scale((1.0, 1.3, 0.8)), api.translate((4.8, 0, 1.5))])
+    # generic tier: the first operand a composite, the second a bih of textured spheres
+    def blocks(): return sd.tex(sd.group([sd.box((float(i) - 3.0, 0.03, -4.0), (float(i) - 2.1, 1.8, -3.0)) for i in range(6)]), pink)
+    def bites(): return sd.bih([sd.tex(sd.sphere((float(i) - 2.55, 1.8, -3.2), 0.55), m["shiny_white"] if i % 2 else teal) for i in range(6)])
+    gen = sd.difference_retexture(blocks(), bites())
+    gen_plain = sd.transform(sd.difference(blocks(), bites()), [api.translate((0, 0, -2.5))])
+    inplace = sd.group([sd.difference_retexture(sd.tex(sd.sphere((-6.0, 1.25, -1.0), 1.2), gold), sd.tex(sd.box((-6.0, 1.0, -1.0), (-4.0, 3.0, 1.0)), m["shiny_red"])), sd.sphere((-6.0, 3.2, -1.0), 0.4)])
+    pl = sd.tex(sd.plane((0, 0, 0), (0, 1, 0)), scenes.matte(sd, (0, 0.8, 0.3)))
+    return _finish(sd, sd.group([pl, sd.bih(flat + [inst, gen, gen_plain, inplace])]))
+
+
+ALL["retexture"] = retexture
+
+
 testscene = scenes.testscene  # GlomeView's default scene (TestScene.hs:183-197), in glome_amd/scenes.py so bench.py can time it
 
 
