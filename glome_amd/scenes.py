@@ -255,7 +255,8 @@ def testscene(lattice_n=10, with_oak=True, skip=()):
         # (and a twig-end sphere is 0.1-0.2 across, ten transforms deep, 12 units from the eye: 2e-4 of hit distance is 3e-3 of its normal)
         # The adaptive sampler decides per pixel by a contrast threshold: twigs a pixel wide put many contrasts near it, and one flipped
         # decision moves a pixel and the neighbours blended from it (measured on the GPU at 260x195: 1.4 % of the pixels beyond 1e-4)
-        sd.subsample_outlier_max, sd.rel_outlier_max = 2.5e-2, 2.5e-2
+        # (the wide bounds are bounds against the fp64 checker ALONE; that these pixels are rounding is asked by parity.away_beyond_rounding, in both suites)
+        sd.subsample_outlier_max, sd.rel_outlier_max = 2.0e-2, 2.0e-2  # (measured on the GPU: 1.36e-2)
         sd.same_prim_min, sd.pixel_outlier_max, sd.pixel_mean_max, sd.normal_atol = 0.95, 6e-3, 4e-4, 2e-2  # (measured on the GPU at 720x480: 4.2e-3, 2.8e-4)
     return sd
 

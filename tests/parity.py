@@ -101,3 +101,35 @@ def check_subsample_image(img, counts, sd, w, h, maxdepth):
     assert c["mean"] <= max(1e-4, getattr(sd, "pixel_mean_max", 0.0)), c
     assert abs(int(counts[0]) - rc["rays_primary"]) <= max(8, rc["rays_primary"] // 500), (counts, rc)
     return c, rc
+
+
+
+def away_beyond_rounding(img, sd, w, h, maxdepth, mode=0, tol=1e-4, jitters=8, seed=1):
+    """Rounding separated from logic INSIDE the suite.  A frame of a scene with ill-conditioned pixels -- the oak's twig-end
+    spheres, 0.1 across and 12 away, whose `rayint_sphere` (Sphere.hs:20-41) cancels six digits; coincident cone ends at its joints;
+    contrasts a hair from the adaptive sampler's thresholds -- differs from the fp64 oracle in more pixels than the strict gates
+    allow.  Whether such a pixel is ROUNDING is asked of the oracle itself, computing in fp32: its frame, and the frames it gives
+    with the eye moved by an ulp (`jitters` of them), mark every pixel where a correct fp32 evaluation of the reference's own
+    formulas lands beyond `tol` of the fp64 frame -- the rounding-sensitive set.  (One fp32 frame does not do: which way a
+    sensitive pixel falls is a coin toss per implementation, so the device and one fp32 oracle disagree on half of them.)
+    A pixel of `img` beyond `tol` of the fp64 frame OUTSIDE that set is a difference in what was computed.  Returns the fractions."""
+    def err(a, b):
+        return (np.abs(a[..., :4].astype(np.float64) - b[..., :4]) / np.maximum(1.0, np.abs(b[..., :4]))).max(-1)
+    o64, _, _ = oracle_for(sd)
+    o32, _, _ = oracle_for(sd, use_float=True)
+    r64, _, _ = o64.render(w, h, mode=mode, maxdepth=maxdepth, want_packed=False)
+    away = err(img, r64) > tol
+    cam, _ = product_camera_lights(sd)
+    rng = np.random.default_rng(seed)
+    sens = np.zeros_like(away)
+    for k in range(jitters):
+        pos = np.array(list(cam.pos), np.float64)
+        if k:
+            pos = pos * (1 + rng.uniform(-1, 1, 3) * 2.0 ** -22)  # an ulp or two of the fp32 eye position
+        o32.set_camera_vectors(list(pos), list(cam.fwd), list(cam.up), list(cam.right))
+        r32, _, _ = o32.render(w, h, mode=mode, maxdepth=maxdepth, want_packed=False)
+        sens |= err(r32, r64) > tol
+    lv = {"away_fp64": float(away.mean()), "rounding_sensitive": float(sens.mean()), "away_outside_sensitive": float((away & ~sens).mean()),
+          "away_inside_sensitive_share": float((away & sens).sum() / max(1, away.sum())), "mode": mode, "w": w, "h": h, "jitters": jitters}
+    _log("beyond_rounding", sd, lv)
+    return lv

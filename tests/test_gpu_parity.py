@@ -1116,3 +1116,65 @@ def test_axis_aligned_camera_reproduces_the_centre_column(gpu_ctx):
             if mode == 0:
                 assert (ref[:, 96, 3] > 0).sum() == (0 if kind in ("box", "bih") else (ref[:, 95, 3] > 0).sum())
         sc.release()
+
+
+def test_default_scene_at_the_reference_window_beyond_rounding(gpu_ctx):
+    """GlomeView's default scene WITH the oak at GlomeView's own 720x480 (Glome.hs:112-113), both render modes.  The scene
+    states wide bounds against the fp64 oracle (scenes.testscene); what this test adds is the gate that says those pixels are
+    ROUNDING (parity.away_beyond_rounding): outside the set of pixels where the oracle itself, computing in fp32 with the eye
+    an ulp off, leaves the fp64 frame, the GPU may differ from the fp64 oracle on 5e-4 of the pixels like any other scene."""
+    sd = zoo.testscene(10)
+    b, nm, sc = commit(gpu_ctx, sd)
+    cam, lights = product_camera_lights(sd)
+    for mode in (0, 1):
+        img, _, st = sc.render(cam, lights, api.render_params(width=720, height=480, maxdepth=3, mode=mode), want_packed=False)
+        lv = parity.away_beyond_rounding(img, sd, 720, 480, 3, mode=mode)
+        assert lv["away_outside_sensitive"] <= (5e-4 if mode == 0 else 1.5e-3), lv
+        assert lv["away_inside_sensitive_share"] >= 0.75, lv  # (a random 2-3 % of the frame would hold 2-3 % of them)
+        assert lv["away_fp64"] <= (sd.pixel_outlier_max if mode == 0 else sd.subsample_outlier_max), lv
+    sc.release()
+
+
+def test_oak_alone_where_its_twigs_are_not_sub_pixel(gpu_ctx):
+    """The oak of TestScene.hs:68-110 by itself over a floor, the camera close enough that a twig is several pixels wide: the
+    strict gates of every other scene hold for hit / miss and depth, and the pixels that differ from the fp64 oracle lie where the
+    fp32 oracle's do."""
+    from glome_amd.scene import SceneDesc
+    sd = SceneDesc()
+    pl = sd.tex(sd.plane((0, 0, 0), (0, 1, 0)), scenes.matte(sd, (0, 0.8, 0.3)))
+    sd.set_root(sd.group([pl, sd.transform(scenes.oak(sd, 8.4, 42), [api.translate((0, 0.01, 0))])]))
+    for pos, col in scenes.LIGHTS[:2]:
+        sd.add_light(pos, col)
+    sd.set_camera((1.5, 3.2, 6.5), (0, 2.6, 0), (0, 1, 0), 45)
+    b, nm, sc = commit(gpu_ctx, sd)
+    cam, lights = product_camera_lights(sd)
+    img, _, st = sc.render(cam, lights, api.render_params(width=480, height=360, maxdepth=2), want_packed=False)
+    o, om, _ = oracle_for(sd)
+    ref, _, rc = o.render(480, 360, maxdepth=2, want_packed=False)
+    hit_g, hit_r = img[..., 4] < 1e6, ref[..., 4] < 1e6
+    both = hit_g & hit_r
+    assert np.mean(hit_g != hit_r) <= 3e-4
+    assert np.mean(np.abs(img[..., 4][both] - ref[..., 4][both]) / np.maximum(1, ref[..., 4][both]) > 1e-4) <= 5e-4
+    lv = parity.away_beyond_rounding(img, sd, 480, 360, 2)
+    assert lv["away_outside_sensitive"] <= 5e-4, lv
+    sc.release()
+
+
+def test_closure_fallback_host_shading_over_the_batch_seams(gpu_ctx):
+    """tests/test_hostsim_parity.py's contract check through the real C ABI: a host that keeps trace / mpreshade / mpostshade for
+    its closure textures and calls glome_rayint_batch / glome_shadow_batch reproduces glome_render's frames and ray counts."""
+    from test_hostsim_parity import _closure_fallback_checks
+    made = []
+
+    def make_backend(sd):
+        b, nm, sc = commit(gpu_ctx, sd)
+        made.append(sc)
+        _, mm = sd.replay(api.Builder())  # (material ids are assigned in call order: the same in every builder)
+        return sc, mm
+
+    def render_ref(sc, cam, lights, w, h, md):
+        img, _, st = sc.render(cam, lights, api.render_params(width=w, height=h, maxdepth=md), want_packed=False)
+        return img, [st["rays_primary"], st["rays_shadow"], st["rays_secondary"]]
+    _closure_fallback_checks(make_backend, render_ref)
+    for sc in made:
+        sc.release()
