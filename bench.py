@@ -37,6 +37,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# issue peaks of the scalar port per CU, measured (tools/probe/valu_rate.hip; profiles/r03_valu_rate.txt, r04_valu_rate_branches.txt)
+SCALAR_PEAK = 0.95                # s_add_u32 alone: 0.236-0.237 per cycle per SIMD
+# A branch does NOT cost the scalar port a full slot (round-4 probe, kinds 17-23 at six waves per SIMD): not-taken s_cbranch alone 0.247
+# per cycle per SIMD, taken s_branch alone 0.149, but branch : s_add mixes issue 0.27-0.33 of BOTH kinds together -- more than s_add
+# alone (0.237).  Scalar-type instructions with the kernel's share of branches (two in five) are priced against the mixes' 1.25 per CU.
+SCALAR_PEAK_WITH_BRANCHES = 1.25
 
 
 def main():
@@ -47,7 +53,10 @@ def main():
     ap.add_argument("--scene", default="S3", help="S1 S2 S3 S3mesh S4 S5 S5mesh, TS = GlomeView's own default scene, TSnooak = the same without the oak (default: the headline workload S3)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--mode", type=int, default=0, help="0 = renderTile (1 ray/pixel), 1 = renderTileSubsample (adaptive)")
-    ap.add_argument("--lanes", type=int, default=4, help="launches kept in flight per GPU (HIP streams / context slots)")
+    ap.add_argument("--lanes", type=int, default=None, help="launches kept in flight per GPU (HIP streams / context slots); default 4 (3 for 16-frame launches at 8+ ranks)")
+    ap.add_argument("--orbit", type=float, default=0.25, help="degrees the camera moves around its look-at point from one frame to the next (a triangle wave over 32 frames, "
+                                                               "so the frames in flight are different views); 0 = every frame the same view.  `value` is the orbit's; the line also "
+                                                               "carries the fixed-camera period (`fixed_camera`)")
     ap.add_argument("--time-every", type=int, default=1, help="HIP-event pair on every k-th launch of the timed region (roofline kernel time)")
     ap.add_argument("--host-build", action="store_true", help="build the BIH with the host builder (glome_sb_bih) instead of on the GPU")
     ap.add_argument("--force-dist", action="store_true", help="one GPU, but through the multi-GPU pipeline with a one-rank RCCL group (rehearsal)")
@@ -139,7 +148,9 @@ def main():
             # it the better, up to the 16 a launch may carry, and a short run is best cut into two launches that are in flight
             # together (tools/short_run_sweep.sh, profiles/r03_short_run_sweep.log: 20 steps take 0.202 ms per step as 5 x 4 frames
             # and 0.188 as 2 x 10; 200 steps 0.1725 at 8 frames per launch and 0.162 at 16)
-            args.group = 1 if args.steps < 8 else min(16, max(4, (args.steps + 1) // 2))
+            # round 4: a launch costs ~0.31 ms besides its frames even with others in flight (profiles/r04_probes/short_run_fit.txt:
+            # per launch 0.307 + 0.137 ms x frames, pipelined), so a run is cut into as few launches as possible: up to 32 frames each
+            args.group = 1 if args.steps < 4 else min(32, args.steps)
         else:
             # several ranks (tools/short_run_groups.py, profiles/r03_short_run_groups.log: rank 0's side of a short run by frames per
             # launch, one-GPU rehearsal).  A rank's shard of a frame is a small launch whose fixed part -- it cannot be shorter than
@@ -147,8 +158,10 @@ def main():
             # step with 1 / 4 / 8 frames per launch, a 100-step run 0.039 / 0.031 / 0.027 with 4 / 8 / 16 (tools/shard_timing.py,
             # profiles/r03_h_shard_timing.log: 0.040 / 0.038 / 0.027 sustained)
             args.group = (1 if world == 2 else 4) if args.steps < 8 else (4 if args.steps < 16 else (8 if args.steps < 40 else 16))
-            if world >= 8 and args.group == 16 and args.lanes == 4:
+            if world >= 8 and args.group == 16 and args.lanes is None:
                 args.lanes = 3
+    if args.lanes is None:
+        args.lanes = 4
     sf = dist.ShardedFrame(scene, P, rank, world, device, lanes=args.lanes, product=args.product, group=args.group, force_pipeline=args.force_dist)
 
     def barrier():
@@ -156,35 +169,60 @@ def main():
             tdist.barrier()
         torch.cuda.synchronize(device)
 
-    # ray count of one frame (identical every step: the scene and camera are fixed)
-    st = sf.step(cam, lights, stats=True)
-    rays_local = torch.tensor([st["rays_primary"], st["rays_shadow"], st["rays_secondary"]], dtype=torch.float64, device=device) if dist_on else None
-    if dist_on:
-        tdist.all_reduce(rays_local)
-        rays = [int(x) for x in rays_local.tolist()]
-    else:
-        rays = [st["rays_primary"], st["rays_shadow"], st["rays_secondary"]]
-    rays_per_step = sum(rays)
+    # The views: the scene's own camera, or (--orbit, the default) that camera moved around its look-at point by a fixed angle per
+    # frame -- a triangle wave over 32 frames -- so that the frames a launch carries, and the launches in flight, are different views
+    # (identical frames share every scalar-cache and L2 line: VERDICT r03).  A frame's rays are counted per view, before the timed region.
+    def orbit_view(k):
+        if not args.orbit:
+            return cam
+        pos, at, up, ang = sd.cam
+        th = np.deg2rad(args.orbit) * (k % 32 if k % 32 <= 16 else 32 - k % 32)
+        p, a = np.asarray(pos, np.float64), np.asarray(at, np.float64)
+        d = p - a
+        rot = np.array([d[0] * np.cos(th) + d[2] * np.sin(th), d[1], -d[0] * np.sin(th) + d[2] * np.cos(th)])
+        return api.camera(tuple(a + rot), at, up, ang)
+    n_views = 17 if args.orbit else 1
+    views = [orbit_view(k) for k in range(32)] if args.orbit else [cam]
+
+    def count_rays(view):
+        st = sf.step(view, lights, stats=True)
+        if dist_on:
+            t_ = torch.tensor([st["rays_primary"], st["rays_shadow"], st["rays_secondary"]], dtype=torch.float64, device=device)
+            tdist.all_reduce(t_)
+            return [int(x) for x in t_.tolist()]
+        return [st["rays_primary"], st["rays_shadow"], st["rays_secondary"]]
+    rays_of_view = [count_rays(views[k]) for k in range(n_views)]
+    rays_by_k = [rays_of_view[k % 32 if k % 32 <= 16 else 32 - k % 32] if args.orbit else rays_of_view[0] for k in range(32)]
+    rays = rays_of_view[0]
+    rays_fixed = sum(rays)
 
     sf.prime(cam, lights)  # every lane's slot / stream / kernel instance exists before the warm-up (initialisation, not steps)
-    for _ in range(args.warmup):
-        sf.step(cam, lights)
-    sf.flush()
-    barrier()
-    # every --time-every-th launch of the timed region carries a HIP-event pair on its launch stream (default: every launch)
-    ctx.lib.glome_ctx_timing_begin_sampled(ctx.h, args.steps, max(1, args.time_every))
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        sf.step(cam, lights)
-    sf.flush()  # frames are pipelined (several in flight): complete the last ones inside the timed region
-    barrier()
-    elapsed = time.perf_counter() - t_start
-    kms = np.zeros(args.steps, np.float32)
-    nk = ctx.lib.glome_ctx_timing_end(ctx.h, kms.ctypes.data_as(L.c_fp), args.steps)
-    if dist_on:
-        e = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        tdist.all_reduce(e, op=tdist.ReduceOp.MAX)
-        elapsed = float(e.item())
+
+    def timed_region(view_of_step):
+        """W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides; max over ranks"""
+        for k in range(args.warmup):
+            sf.step(view_of_step(k), lights)
+        sf.flush()
+        barrier()
+        # every --time-every-th launch of the timed region carries a HIP-event pair on its launch stream (default: every launch)
+        ctx.lib.glome_ctx_timing_begin_sampled(ctx.h, args.steps, max(1, args.time_every))
+        t_start = time.perf_counter()
+        for k in range(args.steps):
+            sf.step(view_of_step(args.warmup + k), lights)
+        sf.flush()  # frames are pipelined (several in flight): complete the last ones inside the timed region
+        barrier()
+        dt = time.perf_counter() - t_start
+        kms = np.zeros(args.steps, np.float32)
+        ctx.lib.glome_ctx_timing_end(ctx.h, kms.ctypes.data_as(L.c_fp), args.steps)
+        if dist_on:
+            e = torch.tensor([dt], dtype=torch.float64, device=device)
+            tdist.all_reduce(e, op=tdist.ReduceOp.MAX)
+            dt = float(e.item())
+        return dt
+    elapsed_fixed = timed_region(lambda k: cam) if args.orbit else None  # the same view every frame (what rounds 1-3 timed)
+    elapsed = timed_region(lambda k: views[k % 32] if args.orbit else cam)
+    last_view = views[(args.warmup + args.steps - 1) % 32] if args.orbit else cam
+    rays_timed = sum(sum(rays_by_k[(args.warmup + k) % 32]) for k in range(args.steps)) if args.orbit else rays_fixed * args.steps
 
     if rank != 0:
         if dist_on:
@@ -193,7 +231,8 @@ def main():
         return
 
     ms_per_step = elapsed / args.steps * 1e3
-    value = rays_per_step / (elapsed / args.steps) / 1e6
+    value = rays_timed / elapsed / 1e6  # the rays of the frames actually rendered in the timed region
+    rays_per_step = rays_timed / args.steps
 
     # ---- after the timed region: the last frame the job delivered (rank 0's framebuffer, reassembled from every rank's tiles)
     # against the same view rendered whole on this GPU -- the multi-GPU data path checks itself in every run
@@ -202,7 +241,7 @@ def main():
         torch.cuda.synchronize(device)
         ctx.lib.glome_ctx_use_slot(ctx.h, None, 0)
         whole = torch.zeros((H, W), dtype=torch.int32, device=device)
-        scene.render_dev(cam, lights, P, None, whole.data_ptr(), want_stats=False)
+        scene.render_dev(last_view, lights, P, None, whole.data_ptr(), want_stats=False)
         ctx.synchronize()
         frame_check = bool(torch.equal(sf.frame.reshape(H, W), whole))
 
@@ -244,6 +283,7 @@ def main():
     kernel_s = kernel_ms * 1e-3
     latency = {"single_frame_ms": round(float(np.median(one_ms)), 4), "lone_launch_ms": round(kernel_ms, 4), "lone_launch_frames": G_lone,
                "ms_per_frame_in_a_lone_launch": round(kernel_ms / G_lone, 4), "pipelined_ms_per_frame": round(ms_per_step, 4),
+               "fixed_camera_ms_per_step": round(elapsed_fixed / args.steps * 1e3, 4) if elapsed_fixed else None,
                "note": "value / ms_per_step are pipelined throughput (launches_in_flight x frames_per_launch independent frames in flight); single_frame_ms is one frame alone on an idle GPU"}
 
     # ---- SURVEY.md 8(d)'s byte model, kept as a labelled side figure ----
@@ -294,7 +334,8 @@ def main():
             cyc = kernel_s * clock_hz  # cycles of one CU over the launch
             hbm_bytes = (cn["FETCH_SIZE"] * 2.0 + cn["WRITE_SIZE"]) * 1024.0 * sc_  # KiB; gfx950 FETCH_SIZE reads half (MI355X_MICROARCH.md, HBM)
             l2_bytes = cn["TCC_REQ_sum"] * 128.0 * sc_                               # an upper bound: every request priced as a full 128-B line
-            sal = (cn["SQ_INSTS_SALU"] + cn["SQ_INSTS_SMEM"] + cn["SQ_INSTS_BRANCH"]) * sc_
+            sal_nb = (cn["SQ_INSTS_SALU"] + cn["SQ_INSTS_SMEM"]) * sc_
+            sal = sal_nb + cn["SQ_INSTS_BRANCH"] * sc_
             allin = sal + (cn["SQ_INSTS_VALU"] + cn.get("SQ_INSTS_LDS", 0.0) + cn.get("SQ_INSTS_VMEM_RD", 0.0) + cn.get("SQ_INSTS_VMEM_WR", 0.0)) * sc_
             # issue peaks measured on this GPU (tools/probe/valu_rate.hip, profiles/r03_valu_rate.txt): a SIMD issues 0.236 scalar
             # instructions per cycle, 0.32-0.40 vector instructions on vector operands (0.24 with a scalar operand, 0.19-0.23 packed),
@@ -304,15 +345,29 @@ def main():
                 "hbm": {"achieved": round(hbm_bytes / kernel_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_bytes / kernel_s / 1e9 / HBM_PEAK_GBS, 4),
                         "note": "fabric-side bytes (FETCH_SIZE x 2 + WRITE_SIZE); Infinity-Cache hits included, so true HBM traffic is at most this"},
                 "l2": {"achieved": round(l2_bytes / kernel_s / 1e9, 1), "peak": 34500.0, "unit": "GB/s", "frac": round(l2_bytes / kernel_s / 1e9 / 34500.0, 4)},
-                "scalar_issue": {"achieved": round(sal / (cus * cyc), 4), "peak": 0.95, "unit": "scalar-type (SALU + SMEM + branch) instructions per cycle per CU", "frac": round(sal / (cus * cyc) / 0.95, 4)},
+                # scalar-type issue, three ways so rounds stay comparable.  What a branch costs the scalar port is
+                # measured, not assumed (tools/probe/valu_rate.hip kinds 17-23, profiles/r04_valu_rate_branches.txt): SCALAR_PEAK_WITH_BRANCHES
+                # is the rate of the probe's branch : s_add mixes, SCALAR_PEAK that of s_add alone.
+                "scalar_issue": {"achieved": round(sal / (cus * cyc), 4), "peak": SCALAR_PEAK_WITH_BRANCHES, "unit": "scalar-type (SALU + SMEM + branch) instructions per cycle per CU",
+                                 "frac": round(sal / (cus * cyc) / SCALAR_PEAK_WITH_BRANCHES, 4)},
+                "scalar_issue_without_branches": {"achieved": round(sal_nb / (cus * cyc), 4), "peak": SCALAR_PEAK, "unit": "SALU + SMEM instructions per cycle per CU, against the measured s_add rate",
+                                                  "frac": round(sal_nb / (cus * cyc) / SCALAR_PEAK, 4)},
+                "scalar_issue_r02_definition": {"achieved": round(sal_nb / (cus * cyc), 4), "peak": 1.0, "unit": "SALU + SMEM per cycle per CU over a nominal 1.0 (round 2's definition, kept so rounds compare)",
+                                                "frac": round(sal_nb / (cus * cyc), 4)},
                 "valu_issue": {"achieved": round(cn["SQ_INSTS_VALU"] * sc_ / (cus * cyc), 4), "peak": 1.6, "unit": "wave64 vector instructions per cycle per CU (the best rate the probe measured: VOP2 on vector operands; one with a scalar operand issues at 0.96, a packed one at 0.75-0.9)",
-                               "frac": round(cn["SQ_INSTS_VALU"] * sc_ / (cus * cyc) / 1.6, 4)},
+                               "frac": round(cn["SQ_INSTS_VALU"] * sc_ / (cus * cyc) / 1.6, 4),
+                               "frac_of_guide_peak": round(cn["SQ_INSTS_VALU"] * sc_ / (cus * cyc) / 2.0, 4), "guide_peak": 2.0,
+                               "guide_peak_note": "MI355X_MICROARCH.md: 4 SIMDs x one wave64 VALU instruction per 2 cycles; this kernel's vector instructions carry scalar operands (node planes, triangle words), which the probe issues at 0.96"},
                 "issue_all": {"achieved": round(allin / (cus * cyc), 4), "peak": 2.25, "unit": "instructions of all kinds per cycle per CU (the best mix the probe measured: two vector on vector operands to one scalar)", "frac": round(allin / (cus * cyc) / 2.25, 4)},
             }
-            top = max(ceil, key=lambda k: ceil[k]["frac"])
+            top = max((k for k in ceil if k not in ("scalar_issue_without_branches", "scalar_issue_r02_definition")), key=lambda k: ceil[k]["frac"])
             wc = cn.get("SQ_WAVE_CYCLES")
             roofline.update({"bound": top, "achieved": ceil[top]["achieved"], "peak": ceil[top]["peak"], "unit": ceil[top]["unit"], "frac": ceil[top]["frac"],
                              "traffic": int(hbm_bytes), "ceilings": ceil, "clock_ghz": pm.get("clock_ghz"),
+                             "hbm_frac": ceil["hbm"]["frac"],
+                             "hbm_frac_note": "fabric-side bytes of the launch (FETCH_SIZE x 2 + WRITE_SIZE, counters) / its duration / 8 TB/s: the north star's 'fraction of the HBM roofline'; low by design -- rays live in registers and the scene in cache",
+                             "model_frac": round(model["bytes_per_launch"] / kernel_s / 1e9 / HBM_PEAK_GBS, 4),
+                             "model_frac_note": "SURVEY.md 8(d)'s algorithmic bytes (every ray charged for every node and triangle the reference's per-ray traversal fetches) / duration / 8 TB/s; ABOVE 1 because a wave fetches a node once for its 64 rays: those bytes are work done, not bytes moved",
                              "wave_wait_frac": round(cn["SQ_WAIT_ANY"] / wc, 4) if wc else None,
                              "wave_issue_stall_frac": round(cn["SQ_WAIT_INST_ANY"] / wc, 4) if wc and cn.get("SQ_WAIT_INST_ANY") else None,
                              "scalar_cache_hit": round(cn["SQC_DCACHE_HITS"] / (cn["SQC_DCACHE_HITS"] + cn["SQC_DCACHE_MISSES"]), 4) if cn.get("SQC_DCACHE_HITS") else None,
@@ -371,6 +426,8 @@ def main():
                    "width": W, "height": H, "rays_per_frame": {"primary": rays[0], "shadow": rays[1], "secondary": rays[2]},
                    "sampling": "renderTile, 1 primary ray/pixel" if args.mode == 0 else "renderTileSubsample (adaptive, 1/8..2 primary rays/pixel)", "launches_in_flight": sf.n, "frames_per_launch": sf.G, "rank0_share_pct": sf.rank0_share_pct, "frame_product": "packed 0x00RRGGBB framebuffer (trace + blitTile fused, 4 B/pixel)" if args.product == "packed" else "float (r,g,b,a,depth) per pixel, 20 B/pixel", "tiles": f"{'64x64 work' if args.mode == 0 else '65x65 reference'} tiles, round-robin over ranks; a launch renders a rank's tiles of {sf.G} frames, one RCCL gather to rank 0 per launch, overlapped with the next launch" if (world > 1 or args.force_dist) else ("65x65 reference tile map, one GPU; a whole renderTile frame is cut into 64x64 work tiles (same pixels, no leftover strips)" if args.mode == 0 else "65x65 reference tiles, one GPU"),
                    "scene_setup_s": round(setup_s, 2), "bih_build": "host" if args.host_build else "device (glome_sb_bih_dev / glome_sb_mesh_dev) for lists of 4096+ objects", "device_bytes": info["device_bytes"]},
+        "camera": ({"orbit_deg_per_frame": args.orbit, "views": 32, "note": "`value` / `ms_per_step`: the camera moves around its look-at point by this angle per frame (triangle wave over 32 frames), rays counted per view; `fixed_camera`: every frame the same view, as rounds 1-3 timed"} if args.orbit else {"orbit_deg_per_frame": 0}),
+        "fixed_camera": ({"ms_per_step": round(elapsed_fixed / args.steps * 1e3, 4), "value": round(rays_fixed * args.steps / elapsed_fixed / 1e6, 2), "unit": "Mrays/s"} if elapsed_fixed else None),
         "roofline": roofline, "latency": latency, "cpu_baseline": cpu, "frame_equals_single_gpu_render": frame_check, "rccl_ranks": world if (dist_on and not args.rehearse) else 0,
         **({"rehearsal": "ranks share one GPU, payloads gathered over gloo through the host: not a measurement"} if args.rehearse else {}),
     }

@@ -70,6 +70,7 @@ SYMBOLS = [
     ("glome_render_multi", C.c_int, [C.POINTER(vp), C.c_int, vp, vp, C.c_int, vp, vp]),
     ("glome_ctx_device_info", C.c_int, [vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("glome_ctx_debug_words", C.c_int, [vp, C.POINTER(C.c_uint64)]),
+    ("glome_ctx_debug_reset", C.c_int, [vp]),
     ("glome_xfm_translate", C.c_int, [c_dp, c_dp]),
     ("glome_xfm_scale", C.c_int, [c_dp, c_dp]),
     ("glome_xfm_rotate", C.c_int, [c_dp, C.c_double, c_dp]),

@@ -435,7 +435,7 @@ class Multi:
         return self.lib.glome_multi_transport(self.h).decode()
 
     def render(self, cams, lights, packed_ptr):
-        """cams: one glome_camera or a list of up to 16; packed_ptr: device pointer on rank 0's GPU (frames back to back)"""
+        """cams: one glome_camera or a list of up to 32; packed_ptr: device pointer on rank 0's GPU (frames back to back)"""
         cams = list(cams) if isinstance(cams, (list, tuple)) else [cams]
         ca = (L.Camera * len(cams))(*cams)
         la = (L.Light * max(1, len(lights)))(*lights)

@@ -4,7 +4,7 @@
 // Kernel catalogue
 //   k_render_flat<FAITHFUL,COUNT,FULL,CLS,LB,TWO_ROWS>
 //                                       persistent: one wave pulls 64-pixel work items (8x8 blocks of a 65x65
-//                                       reference tile, Glome.hs:371-386; up to 16 frames per launch) from a ticket
+//                                       reference tile, Glome.hs:371-386; up to 32 frames per launch) from a ticket
 //                                       queue of eight heads; the wave walks a triangle / sphere BIH once for its 64 rays
 //                                       (packet: rt_device.hpp bih_tri_wave; for triangles the hand-written walk of
 //                                       bih_packet_asm.hpp) -> shadow rays -> shade; secondary rays re-enter the same walk
@@ -283,9 +283,20 @@ __device__ __forceinline__ void render_loop(const DRenderArgs& A, TIER& T) {
 #ifdef GLOME_PROBE
     rt_last_item = __builtin_amdgcn_s_memrealtime();
 #endif
-    if (w >= A.total_waves * (uint32_t)A.nframes) continue;  // padding of the last round of chunks
-    const uint32_t frame = w / A.total_waves;  // wave-uniform
-    w -= frame * A.total_waves;
+    uint32_t frame;  // wave-uniform
+    if (A.chunks_per_frame) {
+      // chunk by chunk through all frames: the same 64x64 work tile of every view one after the other (neighbouring views walk the
+      // same part of the tree), and what a launch ends with is the last chunks of ALL its frames, not the whole of its last frame
+      const uint32_t g = w / kQueueChunk, nf = (uint32_t)A.nframes;
+      if (g >= A.chunks_per_frame * nf) continue;  // padding of the last round of chunks
+      frame = g % nf;
+      w = (g / nf) * kQueueChunk + (w % kQueueChunk);
+      if (w >= A.total_waves) continue;            // padding of a frame's last chunk
+    } else {
+      if (w >= A.total_waves * (uint32_t)A.nframes) continue;  // padding of the last round of chunks
+      frame = w / A.total_waves;
+      w -= frame * A.total_waves;
+    }
     int px = 0, py = 0;
     size_t dense_off = 0;
     bool valid;
@@ -846,6 +857,14 @@ static int get_tiles(glome_ctx* ctx, const glome_render_params* P, int first, in
   if (it == ctx->tile_cache.end()) {
     glome_ctx::TileTable tt;
     owned_tiles(P->width, P->height, blocksize, first, stride, P->rank0_share_pct, tt.host, tt.total_waves, tt.pixels);
+    if (const char* e = getenv("GLOME_DEBUG_TILE_ORDER")) {  // (experiment: the order in which a launch works through its tiles; pixels do not move)
+      const std::string how = e;
+      if (how == "bottomup") std::stable_sort(tt.host.begin(), tt.host.end(), [](const DTile& a, const DTile& b) { return a.y > b.y; });
+      else if (how == "rowmajor") std::stable_sort(tt.host.begin(), tt.host.end(), [](const DTile& a, const DTile& b) { return a.y < b.y; });
+      else if (how == "reverse") std::reverse(tt.host.begin(), tt.host.end());
+      uint32_t wb = 0;
+      for (auto& t : tt.host) { t.wave_base = wb; wb += tile_waves(t.w, t.h); }
+    }
     size_t bytes = std::max<size_t>(1, tt.host.size()) * sizeof(DTile);
     HIPCHK(ctx, hipMalloc((void**)&tt.dev, bytes));
     if (!tt.host.empty()) HIPCHK(ctx, hipMemcpy(tt.dev, tt.host.data(), tt.host.size() * sizeof(DTile), hipMemcpyHostToDevice));
@@ -991,6 +1010,14 @@ int glome_ctx_debug_words(glome_ctx* c, uint64_t* out16) {  // DCounters::dbg of
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(out16, c->slot().d_counters->dbg, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return 0;
+}
+int glome_ctx_debug_reset(glome_ctx* c) {  // (measurement builds: the timeline words of the current slot back to "nothing seen")
+  if (!c) return GLOME_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemset(c->slot().d_counters->dbg, 0, 16 * sizeof(uint64_t)));
+  for (int q : {8, 10, 12}) HIPCHK(c, hipMemset(&c->slot().d_counters->dbg[q], 0xff, sizeof(unsigned long long)));
   return 0;
 }
 int glome_ctx_device_info(glome_ctx* c, char* name, int cap, int* cu_count, int* warp_size) {
@@ -1245,7 +1272,7 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
   memset(&A, 0, sizeof(A));
   A.S = s->dev;
   memcpy(&A.cam, cam, sizeof(DCamera));
-  if (nframes < 1 || nframes > kMaxBatchFrames) { ctx->err = "a launch carries 1..16 frames"; return GLOME_E_LIMIT; }
+  if (nframes < 1 || nframes > kMaxBatchFrames) { ctx->err = "a launch carries 1..32 frames"; return GLOME_E_LIMIT; }
   if (nframes > 1 && (frame_stride <= 0 || frame_stride > 0xffffffffll)) { ctx->err = "frame batches: positive frame stride"; return GLOME_E_INVALID; }
   for (int f = 1; f < nframes; f++) memcpy(&A.more_cams[f - 1], cam + f, sizeof(DCamera));
   A.nframes = nframes; A.frame_stride = nframes > 1 ? (uint32_t)frame_stride : 0u;
@@ -1257,7 +1284,9 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
   memcpy(A.thresholds, P->thresholds, 16);
   A.tiles = tt->dev; A.tile_lut = tt->lut; A.ntiles = (int)tt->host.size(); A.total_waves = tt->total_waves;
   {  // tickets per queue head: the launch's chunks dealt round-robin over the heads, the last round padded
-    const uint32_t tickets = A.total_waves * (uint32_t)nframes, round = kQueueChunk * kQueueShards;
+    static const bool no_interleave = getenv("GLOME_DEBUG_NO_INTERLEAVE") != nullptr;  // (A/B: frame after frame, as until round 3)
+    A.chunks_per_frame = (nframes > 1 && P->mode == GLOME_MODE_TILE && !no_interleave) ? (A.total_waves + kQueueChunk - 1) / kQueueChunk : 0u;
+    const uint32_t tickets = A.chunks_per_frame ? A.chunks_per_frame * kQueueChunk * (uint32_t)nframes : A.total_waves * (uint32_t)nframes, round = kQueueChunk * kQueueShards;
     A.shard_cap = ((tickets + round - 1) / round) * kQueueChunk;
   }
   // dense 0: full frame (rgbad and / or packed); 1: dense rgbad tile payload; 2: dense packed-pixel tile payload only
@@ -1641,7 +1670,7 @@ int glome_tiles_blit_dev(glome_ctx* ctx, const glome_render_params* P, int tile_
 // ================================================================================================ several GPUs, one process
 // renderTiles' `runPar $ parMap` over tiles followed by `forM_ tiles (blitTile surf)` (Glome.hs:379-386) across the GPUs of a
 // node, for a host that drives all of them from one process (the Haskell host of INTEGRATION.md): scenes[i] is the scene
-// committed on context i, tile k of the frame belongs to rank k mod n (or to the rank rank0_share_pct's pattern gives it), a rank renders its tiles of up to 16 frames in one
+// committed on context i, tile k of the frame belongs to rank k mod n (or to the rank rank0_share_pct's pattern gives it), a rank renders its tiles of up to 32 frames in one
 // launch straight into a packed payload, the payloads travel to rank 0's GPU over xGMI, one launch there blits the frames.
 // The exchange is the path's only communication step.  Transport: RCCL send / recv in one group (librccl is opened at run
 // time, so the library carries no link-time dependency on it) when the ranks sit on distinct devices; peer copies on rank
@@ -1779,7 +1808,7 @@ const char* glome_multi_transport(const glome_multi* m) { return !m ? "" : (m->n
 
 int glome_multi_render(glome_multi* m, const glome_camera* cams, int nframes, const glome_light* lights, int nlights, uint32_t* packed_dev) {
   if (!m || !cams || !packed_dev) return GLOME_E_INVALID;
-  if (nframes < 1 || nframes > kMaxBatchFrames || (m->P.mode != GLOME_MODE_TILE && nframes != 1)) { m->err = "a call carries 1..16 frames (one in adaptive mode)"; return GLOME_E_LIMIT; }
+  if (nframes < 1 || nframes > kMaxBatchFrames || (m->P.mode != GLOME_MODE_TILE && nframes != 1)) { m->err = "a call carries 1..32 frames (one in adaptive mode)"; return GLOME_E_LIMIT; }
   const int n = m->n;
   glome_ctx* c0 = m->scenes[0]->ctx;
   const size_t slab = (size_t)kMaxBatchFrames * (size_t)m->maxp;

@@ -68,7 +68,7 @@ constexpr int kCsgFlatAdvance = 256; // ray-advance steps per CSG item of the fl
 constexpr int kIsectFrames = 40;   // explicit frames for rayint_intersection's list recursion (flat tier's CSG items)
 constexpr int kMaxTraceDepth = 8;  // maxdepth values the shading state machine has trace frames for (reference: any)
 constexpr int kMaxMatNest = 4;     // Blend / AdditiveLayers nesting it has material frames for (reference: any)
-constexpr int kMaxBatchFrames = 16;  // frames one render launch can carry
+constexpr int kMaxBatchFrames = 32;  // frames one render launch can carry (a launch costs ~0.3 ms besides its frames -- it ends with its slowest work items -- so the more the better: DESIGN.md 4.1b)
 
 constexpr int kPairWords = 20;  // a pair record: 18 floats, the leaf's remaining count, the first triangle's record index (80 bytes)
 
@@ -162,6 +162,9 @@ struct DRenderArgs {
   // frame f-1's in the queue, its pixels go frame_stride pixels further into out5 / packed
   int32_t nframes;
   uint32_t frame_stride;
+  uint32_t chunks_per_frame;  // > 0: the frames of the launch are interleaved in the queue chunk by chunk (chunk c of every frame, then chunk
+                              // c + 1 of every frame ...; a chunk = kQueueChunk items of ONE frame), chunks_per_frame = ceil(total_waves / kQueueChunk);
+                              // 0: frame after frame
   int32_t want_counters;  // 0: nobody will read the ray / work counters of this launch -- the waves skip the flush
   int32_t debug_flags;    // GLOME_PROBE builds only (glome_device.hip render_loop)
   DCamera more_cams[kMaxBatchFrames - 1];

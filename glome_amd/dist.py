@@ -193,7 +193,7 @@ class ShardedFrame:
         self.P, self.P_local = self.plan.P, self.plan.P_local
         self.h, self.w = params.height, params.width
         self.n = max(1, min(int(lanes), 8))  # the context has 8 launch slots
-        self.G = max(1, min(int(group), 16)) if self.packed else 1  # frames per launch (and per gather)
+        self.G = max(1, min(int(group), 32)) if self.packed else 1  # frames per launch (and per gather): kMaxBatchFrames
         self.streams = [torch.cuda.Stream(device=device) for _ in range(self.n)]
         dt = torch.int32 if self.packed else torch.float32
         shape = (self.G, self.h, self.w) if self.packed else (self.G, self.h, self.w, 5)

@@ -74,6 +74,7 @@ int glome_ctx_device_info(glome_ctx*, char* name, int cap, int* cu_count, int* w
 /* debugging aid, no reference counterpart: 16 words a measurement build of the library accumulates on the device (the stock
    build leaves them zero); synchronises the context's stream */
 int glome_ctx_debug_words(glome_ctx*, uint64_t* out16);
+int glome_ctx_debug_reset(glome_ctx*);  /* measurement builds (-DGLOME_PROBE): the current slot's debug words back to their start values */
 
 /* ---- transforms: Xfm = forward 3x4 (12 doubles, row major) + inverse 3x4 (12 doubles) ---- */
 int glome_xfm_translate(const double v[3], double out[24]);                          /* Vec.hs:564-567 */
@@ -280,7 +281,7 @@ int glome_render_packed_batch_dev(glome_scene*, const glome_camera* cams, int nf
  * scenes[i] = the same scene committed on context i (a context per GPU; rank 0's GPU receives the frame).  Tile k of the
  * frame -- 64x64 work tiles in renderTile mode, the 65x65 reference tiles in adaptive mode (whose pixels depend on the tile
  * map, Q21) -- belongs to rank k mod n, or to the rank the weighted pattern of glome_render_params.rank0_share_pct gives it.
- * A call renders nframes <= 16 views (one in adaptive mode): every rank renders its
+ * A call renders nframes <= 32 views (one in adaptive mode): every rank renders its
  * tiles of all of them in one launch into a packed 0x00RRGGBB payload, the payloads move to rank 0's GPU over xGMI -- RCCL
  * send / recv in one group when use_rccl != 0, librccl.so can be opened and the ranks sit on distinct devices, peer copies
  * otherwise (glome_multi_transport says which) -- and one launch there blits the frames into packed_dev (frame f at

@@ -1049,14 +1049,14 @@ def test_refused_parameters_fail_with_a_status_not_a_frame(gpu_ctx):
     b, nm, sc = commit(gpu_ctx, sd)
     cam, lights = product_camera_lights(sd)
     la = (L.Light * len(lights))(*lights)
-    buf = torch.zeros((17, 64, 64), dtype=torch.int32, device=torch.device("cuda:0"))
+    buf = torch.zeros((33, 64, 64), dtype=torch.int32, device=torch.device("cuda:0"))
     for kw in (dict(width=0), dict(height=-3), dict(maxdepth=0), dict(maxdepth=9), dict(blocksize=0), dict(tile_stride=0), dict(tile_first=-1), dict(rank0_share_pct=101)):
         P = api.render_params(**{**dict(width=64, height=64, maxdepth=1), **kw})
         rc = sc.lib.glome_render_dev(sc.h, C.byref(cam), la, len(lights), C.byref(P), None, C.c_void_p(buf.data_ptr()), None)
         assert rc in (L.E_INVALID, L.E_LIMIT) and gpu_ctx.err(), kw
     P = api.render_params(width=64, height=64, maxdepth=1)
-    cams = (L.Camera * 17)(*[cam] * 17)
-    assert sc.lib.glome_render_packed_batch_dev(sc.h, cams, 17, la, len(lights), C.byref(P), C.c_void_p(buf.data_ptr()), 64 * 64, None) == L.E_LIMIT  # 1..16 frames
+    cams = (L.Camera * 33)(*[cam] * 33)
+    assert sc.lib.glome_render_packed_batch_dev(sc.h, cams, 33, la, len(lights), C.byref(P), C.c_void_p(buf.data_ptr()), 64 * 64, None) == L.E_LIMIT  # 1..32 frames
     assert sc.lib.glome_render_packed_batch_dev(sc.h, cams, 2, la, len(lights), C.byref(P), C.c_void_p(buf.data_ptr()), 0, None) == L.E_INVALID   # frame stride
     too_many = (L.Light * 17)(*[lights[0]] * 17)  # (the light list holds 16)
     assert sc.lib.glome_render_dev(sc.h, C.byref(cam), too_many, 17, C.byref(P), None, C.c_void_p(buf.data_ptr()), None) in (L.E_INVALID, L.E_LIMIT)
@@ -1128,7 +1128,7 @@ def test_default_scene_at_the_reference_window_beyond_rounding(gpu_ctx):
     cam, lights = product_camera_lights(sd)
     for mode in (0, 1):
         img, _, st = sc.render(cam, lights, api.render_params(width=720, height=480, maxdepth=3, mode=mode), want_packed=False)
-        lv = parity.away_beyond_rounding(img, sd, 720, 480, 3, mode=mode)
+        lv = parity.away_beyond_rounding(img, sd, 720, 480, 3, mode=mode, jitters=12)  # (measured with 8: 4.9e-4 / 6.3e-4; 87 % / 95 % inside)
         assert lv["away_outside_sensitive"] <= (5e-4 if mode == 0 else 1.5e-3), lv
         assert lv["away_inside_sensitive_share"] >= 0.75, lv  # (a random 2-3 % of the frame would hold 2-3 % of them)
         assert lv["away_fp64"] <= (sd.pixel_outlier_max if mode == 0 else sd.subsample_outlier_max), lv
@@ -1175,6 +1175,42 @@ def test_closure_fallback_host_shading_over_the_batch_seams(gpu_ctx):
     def render_ref(sc, cam, lights, w, h, md):
         img, _, st = sc.render(cam, lights, api.render_params(width=w, height=h, maxdepth=md), want_packed=False)
         return img, [st["rays_primary"], st["rays_shadow"], st["rays_secondary"]]
-    _closure_fallback_checks(make_backend, render_ref)
+    _closure_fallback_checks(make_backend, render_ref, exact=False)
     for sc in made:
         sc.release()
+
+
+@pytest.mark.parametrize("nframes,w,h", [(32, 200, 120), (5, 333, 97), (32, 1920, 1080)])
+def test_renderTile_frame_batches_equal_the_frames_rendered_alone(gpu_ctx, s3_full, nframes, w, h):
+    """Up to 32 frames per launch, interleaved in the work queue chunk by chunk (chunk c of every frame, then chunk c + 1 ...;
+    glome_device.hip render_loop): every frame of a batch -- different views, frame sizes whose item counts are no multiple of a
+    chunk -- is, pixel for pixel, the frame rendered alone; through the whole-frame entry and through a rank's dense tile payload."""
+    import torch
+    sd, sc = s3_full
+    dev = torch.device("cuda:0")
+    cam, lights = product_camera_lights(sd)
+    la = (L.Light * len(lights))(*lights)
+    pos, at, up, ang = sd.cam
+    views = [api.camera((pos[0] + 0.21 * f, pos[1] + 0.05 * (f % 3), pos[2] - 0.1 * f), at, up, ang) for f in range(nframes)]
+    cams = (L.Camera * nframes)(*views)
+    P = api.render_params(width=w, height=h, maxdepth=1)
+    px = torch.zeros((nframes, h, w), dtype=torch.int32, device=dev)
+    assert sc.lib.glome_render_packed_batch_dev(sc.h, cams, nframes, la, len(lights), C.byref(P), C.c_void_p(px.data_ptr()), h * w, None) == 0, gpu_ctx.err()
+    gpu_ctx.synchronize()
+    got = px.cpu().numpy().view(np.uint32)
+    one = torch.zeros((h, w), dtype=torch.int32, device=dev)
+    for f in (range(nframes) if w < 1000 else (0, 13, 31)):
+        one.zero_()
+        sc.render_dev(views[f], lights, P, None, one.data_ptr(), want_stats=False)
+        gpu_ctx.synchronize()
+        assert np.array_equal(got[f], one.cpu().numpy().view(np.uint32)), f
+    if w < 1000:  # a rank's shard (tiles 1, 4, 7 ... of three ranks) of the same frames as a dense payload
+        Pl = api.render_params(width=w, height=h, maxdepth=1, tile_first=1, tile_stride=3, blocksize=64)
+        n = dist.payload_floats(Pl, 1, 3) // 5
+        pay = torch.zeros((nframes, n), dtype=torch.int32, device=dev)
+        assert sc.lib.glome_render_tiles_packed_batch_dev(sc.h, cams, nframes, la, len(lights), C.byref(Pl), C.c_void_p(pay.data_ptr()), n, None) == 0, gpu_ctx.err()
+        gpu_ctx.synchronize()
+        lay = dist.owned_layout(Pl, 1, 3)
+        payh = pay.cpu().numpy().view(np.uint32)
+        for f in range(nframes):
+            assert np.array_equal(payh[f], dist.pack_numpy(got[f], lay)), f

@@ -253,7 +253,7 @@ def test_texture_stacks_of_eight(built, extra):
     parity.check_image(img, [int(x) for x in cnt], sd, 160, 100, 3)
 
 
-def _closure_fallback_checks(make_backend, render_ref):
+def _closure_fallback_checks(make_backend, render_ref, exact=True):
     """The boundary's fallback for textures that are general closures: the host keeps trace / mpreshade /
     mpostshade (tests/host_shade.py, written from Trace.hs:59-82 and Shader.hs:65-118) and asks the backend for `rayint` and
     `shadow` batches only.  (1) With `t_uniform` closures its frames are the backend's own render of the scene -- pixels and ray
@@ -268,8 +268,16 @@ def _closure_fallback_checks(make_backend, render_ref):
         img, rays = host_shade.render_with_host_shading(backend, cam, sd.lights, host_shade.uniform_textures(sd, mmap), w, h, md)
         e = np.abs(img[..., :4] - ref[..., :4]) / np.maximum(1, np.abs(ref[..., :4]))
         assert (e.max(-1) > 1e-4).mean() <= 5e-4, float(e.max())  # measured 0 (max 6e-7 on the host build): the host shades in fp64 from the same fp32 hits
-        assert np.array_equal(img[..., 4].astype(np.float32), ref[..., 4])
-        assert list(rays) == list(rays_ref)
+        if exact:  # the host build makes its rays with the same IEEE operations as tests/host_shade.py
+            assert np.array_equal(img[..., 4].astype(np.float32), ref[..., 4])
+            assert list(rays) == list(rays_ref)
+        else:      # the GPU normalises a ray with its own reciprocal square root: rays, and so depths, an ulp apart
+            hit = ref[..., 4] < 1e6
+            assert np.array_equal(img[..., 4] < 1e6, hit) or np.mean((img[..., 4] < 1e6) != hit) <= 1e-4
+            both = hit & (img[..., 4] < 1e6)
+            assert np.allclose(img[..., 4][both], ref[..., 4][both], rtol=2e-5)
+            for got, want in zip(rays, rays_ref):
+                assert abs(int(got) - int(want)) <= max(8, int(want) // 1000), (rays, rays_ref)
     sd = scenes.s1(nlights=1)
     backend, mmap = make_backend(sd)
     cam, _ = product_camera_lights(sd)
