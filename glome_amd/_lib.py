@@ -90,6 +90,7 @@ SYMBOLS = [
     ("glome_sb_cone", C.c_int32, [vp, c_dp, C.c_double, c_dp, C.c_double]),
     ("glome_sb_group", C.c_int32, [vp, c_ip, C.c_int]),
     ("glome_sb_transform", C.c_int32, [vp, C.c_int32, c_dp, C.c_int]),
+    ("glome_tex_words", C.c_int, []),
     ("glome_sb_difference", C.c_int32, [vp, C.c_int32, C.c_int32]),
     ("glome_sb_difference_retexture", C.c_int32, [vp, C.c_int32, C.c_int32]),
     ("glome_sb_intersection", C.c_int32, [vp, c_ip, C.c_int]),

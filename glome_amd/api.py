@@ -378,7 +378,7 @@ class Scene:
         n, cols = self._rays(o, d, tmax)
         t = np.zeros(n, np.float32); prim = np.zeros(n, np.int32)
         nx = np.zeros(n, np.float32); ny = np.zeros(n, np.float32); nz = np.zeros(n, np.float32)
-        tex = np.zeros((n, 8), np.int32)
+        tex = np.zeros((n, self.lib.glome_tex_words()), np.int32)  # (8: GLOME_TEX_WORDS of the loaded library)
         self._chk(self.lib.glome_rayint_batch(self.h, n, *[c.ctypes.data_as(L.c_fp) for c in cols], t.ctypes.data_as(L.c_fp),
                                               prim.ctypes.data_as(L.c_ip), nx.ctypes.data_as(L.c_fp), ny.ctypes.data_as(L.c_fp),
                                               nz.ctypes.data_as(L.c_fp), tex.ctypes.data_as(L.c_ip)), "glome_rayint_batch")

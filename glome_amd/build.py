@@ -2,6 +2,7 @@
 
 glome_device.hip is compiled once per PART (-DGLOME_PART=k, see the top of that file), the parts in parallel: the kernel
 instances are what takes the time (one translation unit: 4.5 minutes; ten parts on 8 cores: about one)."""
+import hashlib
 import os
 import subprocess
 import sys
@@ -29,7 +30,13 @@ def _stale(target, sources):
 def build(force=False, verbose=True, lib=LIB, extra_flags=None, obj_dir=None, jobs=None):
     """lib / extra_flags / obj_dir: a variant build beside the in-tree one (A/B measurements through GLOME_DEBUG_LIB)."""
     extra = list(extra_flags) if extra_flags is not None else os.environ.get("GLOME_EXTRA_HIPFLAGS", "").split()
-    obj_dir = obj_dir or (OBJ if not extra else OBJ + "_" + str(abs(hash(" ".join(extra))) % 100000))
+    # a build with extra flags is a VARIANT: its objects and its library live beside the in-tree ones, named by the flags (a stable
+    # hash: the same flags find their objects again), so the in-tree library never silently holds variant objects
+    tag = hashlib.sha1(" ".join(extra).encode()).hexdigest()[:8] if extra else ""
+    obj_dir = obj_dir or (OBJ if not extra else OBJ + "_" + tag)
+    if extra and lib == LIB:
+        os.makedirs(os.path.join(HERE, "variants"), exist_ok=True)
+        lib = os.path.join(HERE, "variants", "flags_" + tag + ".so")
     os.makedirs(obj_dir, exist_ok=True)
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
     hdrs.append(os.path.join(HERE, "..", "include", "glome_hip.h"))

@@ -69,6 +69,8 @@ int glome_camera_lookat(const double pos[3], const double at[3], const double up
   return 0;
 }
 
+int glome_tex_words(void) { return GLOME_TEX_WORDS; }  // int32 words per ray of glome_rayint_batch's texture-stack output
+
 glome_sb* glome_sb_new(void) { return new glome_sb(); }
 void glome_sb_free(glome_sb* sb) { delete sb; }
 const char* glome_sb_last_error(const glome_sb* sb) { return sb ? sb->err.c_str() : "null builder"; }

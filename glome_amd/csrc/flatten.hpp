@@ -335,7 +335,13 @@ class Flattener {
   bool csg_core(int id) const {
     const Node& c = G.at(peel(id).id);
     if (c.kind == K_DIFF) return prim_under_wrappers(c.a) && prim_under_wrappers(c.b);
-    if (c.kind == K_ISECT) { for (int k : c.kids) if (!prim_under_wrappers(k)) return false; return true; }
+    if (c.kind == K_ISECT) {
+      // (csg_isect's frames: one per list position it may nest through, and a few for advances before they fold in place; a longer
+      // Intersection is the generic tier's, whose frames are sized per scene)
+      if ((int)c.kids.size() + 8 > kIsectFrames) return false;
+      for (int k : c.kids) if (!prim_under_wrappers(k)) return false;
+      return true;
+    }
     return false;
   }
   bool csg_simple(int id) const {
@@ -377,7 +383,7 @@ class Flattener {
         if (!kids.empty()) {  // (a list or an Intersection of primitives: the generic tier answers those in place)
           bool prims = true;
           for (const U4& kr : kids) { const uint32_t kk = kr.x & RF_KINDMASK; prims = prims && kk >= R_SPHERE && kk <= R_CONE; }
-          if (prims) r.x |= RF_PRIMLIST;
+          if (prims && (n.kind == K_LIST || (int)kids.size() + 8 <= kIsectFrames)) r.x |= RF_PRIMLIST;  // (csg_isect's frames: see csg_core)
         }
         r.y = (uint32_t)F.recs.size(); r.z = (uint32_t)kids.size();
         F.recs.insert(F.recs.end(), kids.begin(), kids.end());

@@ -23,6 +23,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/glome_hip.h"
@@ -85,9 +86,23 @@ struct FlatTier {
   }
 };
 // the kernel's own arguments where the dispatch put them (constant memory; the first explicit argument is at offset 0)
+// (relies on the code-object ABI placing the first explicit by-value argument at offset 0 of the kernarg segment in host layout:
+// checked once per process by k_kernarg_selftest, glome_ctx_create)
 template <class ARGS> __device__ __forceinline__ const ARGS& kernel_args() {
+  static_assert(std::is_trivially_copyable<ARGS>::value && alignof(ARGS) <= 16, "kernel_args: a by-value kernel argument in host layout");
   return *(const ARGS*)(const ARGS __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
 }
+#if GLOME_IN_PART(0)
+// what kernel_args assumes, asked of the device: the unnamed first argument read through the kernarg pointer equals the bytes the
+// host passed (a second, named copy of them travels as a pointer)
+__global__ void k_kernarg_selftest(DRenderArgs, const DRenderArgs* expect, unsigned int* ok) {
+  const unsigned char* a = (const unsigned char*)&kernel_args<DRenderArgs>();
+  const unsigned char* b = (const unsigned char*)expect;
+  unsigned int same = 1;
+  for (size_t i = threadIdx.x; i < sizeof(DRenderArgs); i += blockDim.x) same &= a[i] == b[i] ? 1u : 0u;
+  if (!same) atomicAnd(ok, 0u);
+}
+#endif
 struct GenericTier {
   static constexpr bool FULL = true;
   static constexpr bool WARP = true;
@@ -923,6 +938,26 @@ glome_ctx* glome_ctx_create(int device_ordinal) {
   for (int k = 0; k < glome_ctx::kSlots; k++)
     for (int q : {8, 10, 12}) (void)hipMemset(&c->slots[k].d_counters->dbg[q], 0xff, sizeof(unsigned long long));  // (the timeline's minima, render_loop)
 #endif
+  {  // kernel_args<>()'s assumption about the kernarg segment, checked once per process on the first context
+    static std::once_flag once;
+    static bool good = true;
+    std::call_once(once, [&] {
+      DRenderArgs* h = new DRenderArgs;
+      unsigned char* hb = (unsigned char*)h;
+      for (size_t i = 0; i < sizeof(DRenderArgs); i++) hb[i] = (unsigned char)(i * 131u + 7u);
+      DRenderArgs* d = nullptr; unsigned int* ok = nullptr; unsigned int one = 1, got = 0;
+      if (hipMalloc((void**)&d, sizeof(DRenderArgs)) == hipSuccess && hipMalloc((void**)&ok, sizeof(unsigned int)) == hipSuccess &&
+          hipMemcpy(d, h, sizeof(DRenderArgs), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(ok, &one, sizeof(one), hipMemcpyHostToDevice) == hipSuccess) {
+        hipLaunchKernelGGL(k_kernarg_selftest, dim3(1), dim3(256), 0, c->stream, *h, d, ok);
+        if (hipStreamSynchronize(c->stream) == hipSuccess && hipMemcpy(&got, ok, sizeof(got), hipMemcpyDeviceToHost) == hipSuccess) good = got == 1u;
+        else good = false;
+      } else good = false;
+      if (d) (void)hipFree(d);
+      if (ok) (void)hipFree(ok);
+      delete h;
+    });
+    if (!good) { g_global_error = "kernel-argument self-test failed: the first by-value kernel argument is not at offset 0 of the kernarg segment in host layout (kernel_args<>)"; glome_ctx_destroy(c); return nullptr; }
+  }
   return c;
 }
 void glome_ctx_destroy(glome_ctx* c) {
@@ -951,6 +986,11 @@ int glome_ctx_use_slot(glome_ctx* c, void* stream, int slot) {
   if (!c || slot < 0 || slot >= glome_ctx::kSlots) return GLOME_E_INVALID;
   c->stream = stream ? (hipStream_t)stream : c->own_stream;
   c->cur = slot;
+  // a slot rebound to another stream forgets the one its last launch went to: that handle is the caller's and may be destroyed by
+  // now (glome_ctx_synchronize must not query it); the slot's error word is then read without asking whether the old stream is idle
+  // -- a word a running kernel ORs into later is reported by the next synchronize
+  glome_ctx::Slot& sl = c->slots[slot];
+  if (sl.launched && sl.launched_on != c->stream) sl.launched_on = nullptr;
   return 0;
 }
 int glome_ctx_set_grid_per_cu(glome_ctx* c, int waves_per_cu) {
@@ -998,7 +1038,7 @@ int glome_ctx_synchronize(glome_ctx* c) {
     if (!sl.launched) continue;
     // a slot bound to a caller's stream (glome_ctx_use_slot) may still be running: its word is read once that stream is idle,
     // by this call or a later one -- never while a kernel could still OR into it
-    if (sl.launched_on != c->stream && hipStreamQuery(sl.launched_on) == hipErrorNotReady) continue;
+    if (sl.launched_on && sl.launched_on != c->stream && hipStreamQuery(sl.launched_on) == hipErrorNotReady) continue;
     sl.launched = false;
     int r = poll_device_error(c, sl);
     if (r) rc = r;
@@ -1688,13 +1728,14 @@ struct Rccl {  // the five entry points the gather needs, resolved from librccl.
   int (*Recv)(void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   bool ok = false;
+  bool debug_lib = false;  // GLOME_DEBUG_RCCL_LIB named the library: the test stub, not RCCL
   static Rccl& get() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
       void* h = nullptr;
       // GLOME_DEBUG_RCCL_LIB: another library with the same entry points (tests/rcclstub: the RCCL branch exercised on one GPU)
-      if (const char* dbg = getenv("GLOME_DEBUG_RCCL_LIB")) h = dlopen(dbg, RTLD_NOW | RTLD_GLOBAL);
+      if (const char* dbg = getenv("GLOME_DEBUG_RCCL_LIB")) { h = dlopen(dbg, RTLD_NOW | RTLD_GLOBAL); r.debug_lib = true; }
       else for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
       if (!h) return;
       r.CommInitAll = (decltype(r.CommInitAll))dlsym(h, "ncclCommInitAll");
@@ -1771,8 +1812,8 @@ glome_multi* glome_multi_create(glome_scene* const* scenes, int n, const glome_r
   bool distinct = true;
   for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) distinct &= scenes[i]->ctx->device != scenes[j]->ctx->device;
   // (GLOME_DEBUG_RCCL_SAME_DEVICE lifts the distinct-device condition -- real RCCL refuses two ranks on one device -- for the
-  // stubbed transport of the one-GPU test)
-  if (use_rccl && n > 1 && (distinct || getenv("GLOME_DEBUG_RCCL_SAME_DEVICE")) && Rccl::get().ok) {
+  // stubbed transport of the one-GPU test, and ONLY for it: with the real library loaded the variable is ignored)
+  if (use_rccl && n > 1 && (distinct || (Rccl::get().debug_lib && getenv("GLOME_DEBUG_RCCL_SAME_DEVICE"))) && Rccl::get().ok) {
     std::vector<int> devs;
     for (int i = 0; i < n; i++) devs.push_back(scenes[i]->ctx->device);
     m->comms.assign(n, nullptr);
@@ -1830,13 +1871,15 @@ int glome_multi_render(glome_multi* m, const glome_camera* cams, int nframes, co
     // rank i's Send is ordered on ITS stream behind its render and in front of its next one, so a payload is never rewritten
     // before it has left; rank 0's Recvs are ordered on its stream in front of the blit.  (The device of a call's communicator
     // is made current first: RCCL releases before 2.18 want that.)
-    for (int i = 1; i < n && rc == 0; i++) {
-      MHIP(m, hipSetDevice(m->scenes[i]->ctx->device));
+    hipError_t he = hipSuccess;  // (no early return inside the group: GroupEnd is called whatever happens)
+    for (int i = 1; i < n && rc == 0 && he == hipSuccess; i++) {
+      if ((he = hipSetDevice(m->scenes[i]->ctx->device)) != hipSuccess) break;
       rc = R.Send(m->payload[i], words, kNcclUint32, 0, m->comms[i], m->scenes[i]->ctx->stream);
-      MHIP(m, hipSetDevice(c0->device));
+      if ((he = hipSetDevice(c0->device)) != hipSuccess) break;
       if (rc == 0) rc = R.Recv(m->gathered + (size_t)i * slab, words, kNcclUint32, i, m->comms[0], c0->stream);
     }
     int rc2 = R.GroupEnd();
+    if (he != hipSuccess) { m->err = std::string("hipSetDevice inside the RCCL group: ") + hipGetErrorString(he); return GLOME_E_HIP; }
     if (rc || rc2) { m->err = std::string("RCCL send / recv: ") + (R.GetErrorString ? R.GetErrorString(rc ? rc : rc2) : "error"); return GLOME_E_HIP; }
   } else if (n > 1) {
     MHIP(m, hipSetDevice(c0->device));

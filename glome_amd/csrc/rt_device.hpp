@@ -863,7 +863,12 @@ GD bool bih_tri_wave(const DScene& S, uint32_t hdr, const Ray& r, float d, bool 
     bool walked = false;
 #if defined(__HIPCC__)
     if constexpr (MODE != 0 && !COUNT && LEAFK == 0 && std::is_same<STK, LaneStack>::value) {
-      if (stk.cap == kAsmLdsCap && has_pk) { R = bih_tri_packet_hw<MODE>(S.pknodes, S.pknodes_bytes, S.tripairs, pkroot, delta, fwdbits, am, nearv, farv, r.o, r.d, rcp, best_t, stk); walked = true; }
+      // The hand-written walk keeps entry k of its stack in lane k of three registers and hands steps to C++ through the stack's dump
+      // block: it needs EVERY lane of the wave at this call and a stack that has a dump block.  Both hold by construction in the flat
+      // tier's kernels (one wave per workgroup, wave-uniform callers); the generic tier's packet service calls from inside a loop whose
+      // lanes diverge and carries a stack without one (generic_packet_stack) -- checked here, at run time, rather than trusted to the
+      // caller's template arguments: anything else takes the C++ packet walk below.
+      if (stk.cap == kAsmLdsCap && has_pk && stk.dump != nullptr && __builtin_amdgcn_read_exec() == ~0ull) { R = bih_tri_packet_hw<MODE>(S.pknodes, S.pknodes_bytes, S.tripairs, pkroot, delta, fwdbits, am, nearv, farv, r.o, r.d, rcp, best_t, stk); walked = true; }
     }
 #endif
     if (!walked) {
@@ -1049,7 +1054,7 @@ GD HitG hit_miss() { HitG h; h.hit = false; h.t = kInf; h.p = v3(0, 0, 0); h.n =
 // One explicit frame of rayint_intersection's list recursion (isect_rayint).  `from` holds the list position and, in
 // its top two bits, the frame's state; `aux` is the state's one live distance (state 1: the inside hit's depth, state 2:
 // the advance added back on return).
-struct IFrame { uint32_t from; float ox, oy, oz, d, aux; };
+struct IFrame { uint32_t from; float ox, oy, oz, d, aux, acc; };  // acc: advances folded into this frame when the frames had run out (added back when it completes)
 GD HitG nearest_hit(const HitG& a, const HitG& b) {  // nearest, Solid.hs:37-44: ties -> b
   if (!b.hit) return a;
   if (!a.hit) return b;
@@ -1129,13 +1134,17 @@ template <bool C> GD HitG csg_diff(const DScene& S, Cnt& cnt, unsigned int& err,
       if (!hb.hit) { res = ha; break; }
       if (ha.t < hb.t) { res = ha; break; }
     }
-    if (na >= kCsgFlatAdvance) { err = 1; break; }
     const float a = hb.t + kDel;
-    adds[na++] = a;
+    if (na < kCsgFlatAdvance) adds[na] = a;
+    else {  // beyond the list: the advance joins the last slot (rt_types.h kCsgFlatAdvance); a runaway ray is reported, not followed for ever
+      adds[kCsgFlatAdvance - 1] = adds[kCsgFlatAdvance - 1] + a;
+      if (na >= kCsgRunaway) { err = 1; break; }
+    }
+    na++;
     r.o = vscaleadd(r.o, r.d, a);  // ray_move
     d = d - a;
   }
-  if (res.hit) for (int k = na - 1; k >= 0; k--) res.t = res.t + adds[k];  // RayHit (depth+a) ..., innermost first
+  if (res.hit) for (int k = (na < kCsgFlatAdvance ? na : kCsgFlatAdvance) - 1; k >= 0; k--) res.t = res.t + adds[k];  // RayHit (depth+a) ..., innermost first
   return res;
 }
 // rayint_intersection, Csg.hs:68-90 (Q14): the recursion on the list tail and on the advanced ray as explicit frames
@@ -1144,9 +1153,13 @@ template <bool C> GD HitG csg_isect(const DScene& S, Cnt& cnt, unsigned int& err
   const uint32_t n = rec.z;
   IFrame fr[kIsectFrames];
   int sp = 0;
-  auto push = [&](uint32_t from, V3 o, float d) { IFrame& c = fr[sp]; c.from = from; c.ox = o.x; c.oy = o.y; c.oz = o.z; c.d = d; c.aux = 0; };
+  auto push = [&](uint32_t from, V3 o, float d) { IFrame& c = fr[sp]; c.from = from; c.ox = o.x; c.oy = o.y; c.oz = o.z; c.d = d; c.aux = 0; c.acc = 0; };
+  // an advance when no frame is left (the reference recurses without a bound, Solid.hs:85-91): the frame goes on in place from the
+  // advanced origin and remembers the distance -- the same sum as the nested `RayHit (depth + a)`s in another order (an ulp of the depth)
+  auto advance_in_place = [&](IFrame& f, uint32_t from, V3 o, float a) { const V3 q = vscaleadd(o, r0.d, a); f.from = from; f.ox = q.x; f.oy = q.y; f.oz = q.z; f.d = f.d - a; f.aux = 0; f.acc = f.acc + a; };
   push(0, r0.o, d0);
   HitG ret = hit_miss();
+  int nadv = 0;
   bool returning = false;  // true: frame fr[sp] has completed with `ret`
   for (;;) {
     if (!returning) {
@@ -1168,20 +1181,24 @@ template <bool C> GD HitG csg_isect(const DScene& S, Cnt& cnt, unsigned int& err
       bool all = true;  // inside (Intersection ss) sp: foldl' (&&) True
       for (uint32_t k = from + 1; k < n; k++) all = all && leaf_inside(S, ldu4(S.recs, rec.y + k), hs.p);
       if (all) { ret = hs; returning = true; continue; }  // RayHit sd sp sn r vzero st stags
-      if (sp + 1 >= kIsectFrames) { err = 1; return hit_miss(); }
       const float a = hs.t + kDel;  // rayint_advance (Intersection slds) r d t tags sd
+      if (++nadv > kCsgRunaway) { err = 1; return hit_miss(); }
+      // (the list positions still ahead may each need a frame of their own: an advance takes one only while those stay free)
+      if (sp + 1 + (int)(n - from) >= kIsectFrames) { advance_in_place(f, from, r.o, a); continue; }
       f.from = from | kSt2; f.aux = a;
       sp++; push(from, vscaleadd(r.o, r.d, a), f.d - a);
       continue;
     }
+    if (ret.hit && fr[sp].acc != 0) ret.t = ret.t + fr[sp].acc;  // (advances this frame took in place)
     if (sp == 0) return ret;
     sp--;
     IFrame& p = fr[sp];
     if ((p.from & ~kFrom) == kSt1) {
       if (ret.hit) continue;  // hit -> hit
-      if (sp + 1 >= kIsectFrames) { err = 1; return hit_miss(); }
       const float a = p.aux + kDel;
       const uint32_t pf = p.from & kFrom;
+      if (++nadv > kCsgRunaway) { err = 1; return hit_miss(); }
+      if (sp + 1 + (int)(n - pf) >= kIsectFrames) { advance_in_place(p, pf, v3(p.ox, p.oy, p.oz), a); returning = false; continue; }
       p.from = pf | kSt2; p.aux = a;
       const V3 po = v3(p.ox, p.oy, p.oz);
       const float pd = p.d;

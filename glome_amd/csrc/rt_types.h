@@ -64,8 +64,13 @@ constexpr int kVmWords = 768, kVmHitWords = 17, kVmListR = 7 + kVmHitWords, kVmI
               kVmIsectWords = 11, kVmBihFixedR = 12 + kVmHitWords, kVmBihFixedS = 12;
 constexpr int kVmIsectChain = 8;   // Intersection frames the commit-time estimate allows for (a chain longer than the memory is caught at run time)
 constexpr int kCsgMaxAdvance = 32; // ray-advance steps per Difference the generic tier's commit-time frame estimate allows for (at run time: its frame memory)
-constexpr int kCsgFlatAdvance = 256; // ray-advance steps per CSG item of the flat tier (its list of advances is a fixed array; reference: unbounded)
-constexpr int kIsectFrames = 40;   // explicit frames for rayint_intersection's list recursion (flat tier's CSG items)
+constexpr int kCsgFlatAdvance = 256; // ray-advance steps per CSG item of the flat tier whose distances are added back in the reference's own (nested) order; a ray that
+                                     // advances more often keeps going (reference: unbounded recursion) with the further advances added to the last slot -- the same
+                                     // sum in another order, an ulp of the depth
+constexpr int kIsectFrames = 40;   // explicit frames for rayint_intersection's list recursion (flat tier's CSG items); when they run out an advance re-uses its frame
+constexpr int kCsgRunaway = 1 << 20; // advances of ONE ray through ONE CSG item after which the launch reports GLOME_E_LIMIT instead of going on (every advance moves the
+                                     // ray by at least delta = 1e-4, so a million of them is a ray crawling through 100 units of surfaces a hair apart: the reference
+                                     // would still be recursing; a GPU wave must come back)
 constexpr int kMaxTraceDepth = 8;  // maxdepth values the shading state machine has trace frames for (reference: any)
 constexpr int kMaxMatNest = 4;     // Blend / AdditiveLayers nesting it has material frames for (reference: any)
 constexpr int kMaxBatchFrames = 32;  // frames one render launch can carry (a launch costs ~0.3 ms besides its frames -- it ends with its slowest work items -- so the more the better: DESIGN.md 4.1b)

@@ -197,7 +197,11 @@ int glome_scene_get_info(const glome_scene*, glome_scene_info* out);
 
 /* ---- per-ray seams (Solid.hs:146-166), host buffers ---- */
 /* closest hit: t < 0 marks a miss (RayMiss); prim = builder id of the primitive hit; tex8 = the hit's
- * texture stack (the ids of glome_sb_material), innermost first, -1 padded (8 per ray).  Any output pointer may be NULL. */
+ * texture stack (the ids of glome_sb_material), innermost first, -1 padded: GLOME_TEX_WORDS (8) int32 PER RAY -- the buffer is
+ * n * GLOME_TEX_WORDS words (until round 3 it was 4 per ray: a caller built against that header must be rebuilt; glome_tex_words()
+ * returns what the loaded library writes, for a binding that wants to check at run time).  Any output pointer may be NULL. */
+#define GLOME_TEX_WORDS 8
+int glome_tex_words(void);
 int glome_rayint_batch(glome_scene*, size_t n, const float* ox, const float* oy, const float* oz, const float* dx,
                        const float* dy, const float* dz, const float* tmax, float* t, int32_t* prim, float* nx,
                        float* ny, float* nz, int32_t* tex8);

@@ -167,8 +167,8 @@ int hostsim_render(void* sv, int tier, const float* cam, const float* lights, in
       get_coordsf(width, height, (float)px, (float)py, xc, yc);
       Ray ray = primary_ray(C, xc, yc);
       HitG h; CA c;
-      if (tier == 0 && exact) { HostFlatTier<true, false, true> T{s->D, L, nl, hs.lane(kFlatStack), Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, true, &h); total.shadow += T.cnt.shadow; total.secondary += T.cnt.secondary; }
-      else if (tier == 0) { HostFlatTier<false, false, true> T{s->D, L, nl, hs.lane(kFlatStack), Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, true, &h); total.shadow += T.cnt.shadow; total.secondary += T.cnt.secondary; }
+      if (tier == 0 && exact) { HostFlatTier<true, false, true> T{s->D, L, nl, hs.lane(kFlatStack), Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, true, &h); err |= T.err; total.shadow += T.cnt.shadow; total.secondary += T.cnt.secondary; }
+      else if (tier == 0) { HostFlatTier<false, false, true> T{s->D, L, nl, hs.lane(kFlatStack), Cnt()}; c = trace_primary(T, ray, kInf, maxdepth, true, &h); err |= T.err; total.shadow += T.cnt.shadow; total.secondary += T.cnt.secondary; }
       else { HostGenericTier T{s->D, L, nl, Cnt()}; T.packets(); c = trace_primary(T, ray, kInf, maxdepth, true, &h); err |= T.err; total.shadow += T.cnt.shadow; total.secondary += T.cnt.secondary; }
       float* o = out5 + ((size_t)py * width + px) * 5;
       o[0] = c.r; o[1] = c.g; o[2] = c.b; o[3] = c.a; o[4] = h.hit ? h.t : kInf;

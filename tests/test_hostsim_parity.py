@@ -334,3 +334,49 @@ def test_default_scene_differs_from_the_fp64_oracle_only_where_fp32_rounding_dec
         lv = parity.away_beyond_rounding(img, sd, 360, 240, 3, mode=mode)
         assert lv["away_outside_sensitive"] <= (8e-4 if mode == 0 else 1.5e-3), lv  # measured 4.4e-4 / 7.8e-4
         assert lv["away_inside_sensitive_share"] >= 0.8, lv                           # measured 0.89 / 0.94
+
+
+def _many_sided_intersection_scene():
+    """Flat-tier Intersections near the length their frames allow: spheres cut by 30 planes each (TestScene.hs:29-54's way of making
+    a polyhedron, with more faces) -- rayint_intersection (Csg.hs:68-90) nests once per list position a ray is inside of and calls
+    rayint_advance once per plane it crosses outside the solid, each a level of recursion in the reference."""
+    from glome_amd.scene import SceneDesc
+    sd = SceneDesc()
+    m = scenes.materials(sd)
+    rng = np.random.default_rng(30)
+    items = []
+    for k, c in enumerate([(-2.5, 1.6, 0.0), (0.0, 1.6, -1.0), (2.5, 1.6, 0.5)]):
+        planes = []
+        for _ in range(30):
+            n = rng.normal(size=3); n /= np.linalg.norm(n)
+            planes.append(sd.plane_offset(tuple(n), 1.0 + float(n @ np.array(c))))
+        items.append(sd.tex(sd.intersection([sd.sphere(c, 1.3)] + planes), m["shiny_red"] if k % 2 else m["shiny_white"]))
+    pl = sd.tex(sd.plane((0, 0, 0), (0, 1, 0)), scenes.matte(sd, (0, 0.8, 0.3)))
+    sd.set_root(sd.group([pl, sd.bih(items)]))
+    for pos, col in scenes.LIGHTS[:2]:
+        sd.add_light(pos, col)
+    sd.set_camera((0.4, 1.7, 6.0), (0.0, 1.5, 0.0), (0, 1, 0), 55)
+    return sd
+
+
+def test_csg_items_of_the_flat_tier_advance_without_a_cap(built):
+    """The reference advances a ray through a CSG item as often as it takes (rayint_advance recurses, Solid.hs:85-91).  The flat
+    tier's loops keep a bounded list of advances / frames; beyond it they go on in place (rt_device.hpp csg_diff, csg_isect) instead
+    of stopping the launch with GLOME_E_LIMIT as they did until round 3: the fuzz scene that hit the cap in round 3's soak
+    (zoo.random_flat(12094) under its random rig) and a 31-operand Intersection render, and agree with the oracle."""
+    for sd in (zoo.random_rig(zoo.random_flat(12094), 12094), _many_sided_intersection_scene()):
+        b = api.Builder()
+        nm, _ = sd.replay(b)
+        hs = HostSim(b, nm[sd.root])
+        assert hs.info()["tier"] == 0
+        cam, lights = product_camera_lights(sd)
+        W, H = 96, 54
+        img, cnt = hs.render(cam, lights, W, H, 3)  # (raises if the device code reports a limit)
+        o, _, _ = oracle_for(sd)
+        o32, _, _ = oracle_for(sd, use_float=True)
+        ref, _, rc = o.render(W, H, maxdepth=3, want_packed=False)
+        r32, _, _ = o32.render(W, H, maxdepth=3, want_packed=False)
+        err = lambda a, r: (np.abs(a[..., :4] - r[..., :4]) / np.maximum(1, np.abs(r[..., :4]))).max(-1)
+        both = (err(img, ref) > 1e-4) & (err(img, r32) > 1e-4)
+        assert both.mean() <= 2e-3, int(both.sum())
+        assert int(cnt[0]) == rc["rays_primary"]

@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 
@@ -29,6 +30,7 @@ struct Study {
   std::vector<Box3> nbox;           // true box of every node's subtree
   long steps = 0, tests = 0;
   int variant = 0, baxis = 1;
+  std::vector<int>* visited = nullptr;  // when set: every branch node entered is appended
   bool tri_hit(const Tri& t, D3 o, D3 d, double tmax, double& tt) const {
     D3 s1 = cross(d, t.e2);
     double div = dot(s1, t.e1);
@@ -91,6 +93,7 @@ struct Study {
           }
         } else {
           steps++;
+          if (visited) visited->push_back(k);
           double oa = comp(o, n.axis), ra = comp(rcp, n.axis);
           double dl = (n.lsplit - oa) * ra, dr = (n.rsplit - oa) * ra;
           bool fwd = ra > 0;
@@ -182,6 +185,45 @@ int main(int argc, char** argv) {
     printf("%-7s primary: %ld rays, %.1f steps %.1f tests per ray | shadow: %ld rays (%ld occluded), %.1f steps %.1f tests per ray | all: %.1f steps %.1f tests per ray\n", names[v], nprim,
            double(psteps) / nprim, double(ptests) / nprim, nshadow, nocc, double(ssteps) / std::max(1L, nshadow), double(stests) / std::max(1L, nshadow),
            double(psteps + ssteps) / (nprim + nshadow), double(ptests + stests) / (nprim + nshadow));
+  }
+  // ---- per PACKET (one 8x8 pixel block = one work item): branch nodes entered by any of its 64 rays (what the wave-wide walk steps
+  // through), primary walk and shadow walk, over every BSTRIDE-th block of the frame
+  {
+    S.variant = 0;
+    const int BSTRIDE = argc > 3 ? atoi(argv[3]) : 3;
+    std::vector<long> pu, su, ptot;
+    std::vector<int> vis, all;
+    for (int by = 0; by + 8 <= H; by += 8 * BSTRIDE) for (int bx = 0; bx + 8 <= W; bx += 8 * BSTRIDE) {
+      std::vector<D3> so, sdv; std::vector<double> sl;
+      all.clear();
+      long own_max = 0;
+      for (int j = 0; j < 64; j++) {
+        int px = bx + j % 8, py = by + j / 8;
+        double xc = ((double(px) / W) * 2 - 1) * (double(W) / H), yc = -((double(py) / H) * 2 - 1);
+        D3 d = normalize(fwd + right * (-xc) + up_ * yc);
+        vis.clear(); S.visited = &vis;
+        double t = S.walk(pos, d, 1e6, 1);
+        all.insert(all.end(), vis.begin(), vis.end());
+        if (t >= 0) { D3 p = pos + d * t; D3 lv = light - p; double ll = std::sqrt(dot(lv, lv)); so.push_back(p + D3{0, 1e-4, 0}); sdv.push_back(lv * (1.0 / ll)); sl.push_back(ll - 2e-4); }
+      }
+      std::sort(all.begin(), all.end()); all.erase(std::unique(all.begin(), all.end()), all.end());
+      long pun = (long)all.size();
+      all.clear();
+      for (size_t j = 0; j < so.size(); j++) {
+        vis.clear(); S.visited = &vis;
+        S.walk(so[j], sdv[j], sl[j], 2);
+        own_max = std::max<long>(own_max, (long)vis.size());
+        all.insert(all.end(), vis.begin(), vis.end());
+      }
+      std::sort(all.begin(), all.end()); all.erase(std::unique(all.begin(), all.end()), all.end());
+      pu.push_back(pun); su.push_back((long)all.size()); ptot.push_back(pun + (long)all.size());
+      (void)own_max;
+    }
+    S.visited = nullptr;
+    auto q = [](std::vector<long> v, double f) { std::sort(v.begin(), v.end()); return v[(size_t)(f * (v.size() - 1))]; };
+    auto mean = [](const std::vector<long>& v) { double s = 0; for (long x : v) s += x; return s / v.size(); };
+    printf("packets (%zu sampled): branch steps per item  primary walk mean %.0f p50 %ld p99 %ld max %ld | shadow walk mean %.0f p50 %ld p90 %ld p99 %ld p999 %ld max %ld | item mean %.0f p50 %ld p99 %ld max %ld (max / mean %.1f)\n",
+           pu.size(), mean(pu), q(pu, .5), q(pu, .99), q(pu, 1.0), mean(su), q(su, .5), q(su, .9), q(su, .99), q(su, .999), q(su, 1.0), mean(ptot), q(ptot, .5), q(ptot, .99), q(ptot, 1.0), q(ptot, 1.0) / mean(ptot));
   }
   return 0;
 }

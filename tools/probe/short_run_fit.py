@@ -16,7 +16,7 @@ nm, _ = sd.replay(Dev()); sc = ctx.commit(b, nm[sd.root])
 cam = api.camera(*sd.cam); lights = [api.light(p, c, r, s) for (p, c, r, s) in sd.lights]
 P = api.render_params(width=cfg["width"], height=cfg["height"], maxdepth=cfg["maxdepth"])
 dev = torch.device("cuda", 0)
-for group, lanes in [(10, 4), (5, 4), (16, 4), (10, 2), (20, 2), (32, 2)]:
+for group, lanes in [tuple(int(x) for x in g.split('x')) for g in os.environ.get('CONFIGS', '32x4 32x2 32x1 16x4 16x2 20x1 10x4').split()]:
     try:
         sf = dist.ShardedFrame(sc, P, 0, 1, dev, lanes=lanes, product="packed", group=group)
     except Exception as e:
@@ -26,7 +26,7 @@ for group, lanes in [(10, 4), (5, 4), (16, 4), (10, 2), (20, 2), (32, 2)]:
     sf.step(cam, lights, stats=True)
     sf.prime(cam, lights)
     rows = {}
-    for K in (10, 20, 40, 80, 160):
+    for K in [int(x) for x in os.environ.get('STEPS', '20 32 64 128 200 256').split()]:
         ts = []
         for rep in range(5):
             for _ in range(5):
