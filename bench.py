@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--product", default="packed", choices=["packed", "rgbad"],
                     help="what a frame is: GlomeView's framebuffer of packed 0x00RRGGBB pixels (blitTile; 4 B/pixel cross xGMI) "
                          "or the float (r,g,b,a,depth) tuples (20 B/pixel)")
+    ap.add_argument("--transport", default="auto", choices=["auto", "direct", "gather"], help="several ranks: how the pixels reach rank 0 (auto: direct stores when the frames can be mapped, else the gather)")
     ap.add_argument("--rehearse", action="store_true", help="N ranks on ONE GPU over gloo (payloads staged through the host): a rehearsal of the multi-process "
                                                             "control flow where there is a single device; its timings mean nothing")
     args = ap.parse_args()
@@ -162,7 +163,8 @@ def main():
                 args.lanes = 3
     if args.lanes is None:
         args.lanes = 4
-    sf = dist.ShardedFrame(scene, P, rank, world, device, lanes=args.lanes, product=args.product, group=args.group, force_pipeline=args.force_dist)
+    sf = dist.ShardedFrame(scene, P, rank, world, device, lanes=args.lanes, product=args.product, group=args.group, force_pipeline=args.force_dist,
+                           direct={"auto": None, "direct": True, "gather": False}[args.transport])
 
     def barrier():
         if dist_on:
@@ -226,6 +228,7 @@ def main():
 
     if rank != 0:
         if dist_on:
+            sf.close()
             tdist.barrier()
             tdist.destroy_process_group()
         return
@@ -424,7 +427,8 @@ def main():
                                                      "S3mesh": "100,352-triangle heightfield as mesh (2-box BVH)", "S5": "1,002,528-triangle heightfield under bih", "S5mesh": "1,002,528-triangle heightfield as mesh (2-box BVH; a Mesh casts no shadows, Q12)",
                                                      "TS": "GlomeView's default scene geom'' (TestScene.hs:183-197) without the oak, at GlomeView's 720x480, maxdepth 3"}.get(args.scene, args.scene),
                    "width": W, "height": H, "rays_per_frame": {"primary": rays[0], "shadow": rays[1], "secondary": rays[2]},
-                   "sampling": "renderTile, 1 primary ray/pixel" if args.mode == 0 else "renderTileSubsample (adaptive, 1/8..2 primary rays/pixel)", "launches_in_flight": sf.n, "frames_per_launch": sf.G, "rank0_share_pct": sf.rank0_share_pct, "frame_product": "packed 0x00RRGGBB framebuffer (trace + blitTile fused, 4 B/pixel)" if args.product == "packed" else "float (r,g,b,a,depth) per pixel, 20 B/pixel", "tiles": f"{'64x64 work' if args.mode == 0 else '65x65 reference'} tiles, round-robin over ranks; a launch renders a rank's tiles of {sf.G} frames, one RCCL gather to rank 0 per launch, overlapped with the next launch" if (world > 1 or args.force_dist) else ("65x65 reference tile map, one GPU; a whole renderTile frame is cut into 64x64 work tiles (same pixels, no leftover strips)" if args.mode == 0 else "65x65 reference tiles, one GPU"),
+                   "sampling": "renderTile, 1 primary ray/pixel" if args.mode == 0 else "renderTileSubsample (adaptive, 1/8..2 primary rays/pixel)", "launches_in_flight": sf.n, "frames_per_launch": sf.G, "rank0_share_pct": sf.rank0_share_pct,
+                   "transport": ("direct: every rank's kernel stores its tiles' pixels straight into rank 0's frames (HIP IPC mapping); one one-word all-reduce per launch as the completion signal" if sf.direct else ("gather: tile payloads to rank 0 with one RCCL gather per launch, blitted there" + (" (direct stores were not possible: %s)" % sf.direct_error if getattr(sf, "direct_error", None) else ""))) if (world > 1 or args.force_dist) else "none (one GPU)", "frame_product": "packed 0x00RRGGBB framebuffer (trace + blitTile fused, 4 B/pixel)" if args.product == "packed" else "float (r,g,b,a,depth) per pixel, 20 B/pixel", "tiles": f"{'64x64 work' if args.mode == 0 else '65x65 reference'} tiles, round-robin over ranks; a launch renders a rank's tiles of {sf.G} frames, one RCCL gather to rank 0 per launch, overlapped with the next launch" if (world > 1 or args.force_dist) else ("65x65 reference tile map, one GPU; a whole renderTile frame is cut into 64x64 work tiles (same pixels, no leftover strips)" if args.mode == 0 else "65x65 reference tiles, one GPU"),
                    "scene_setup_s": round(setup_s, 2), "bih_build": "host" if args.host_build else "device (glome_sb_bih_dev / glome_sb_mesh_dev) for lists of 4096+ objects", "device_bytes": info["device_bytes"]},
         "camera": ({"orbit_deg_per_frame": args.orbit, "views": 32, "note": "`value` / `ms_per_step`: the camera moves around its look-at point by this angle per frame (triangle wave over 32 frames), rays counted per view; `fixed_camera`: every frame the same view, as rounds 1-3 timed"} if args.orbit else {"orbit_deg_per_frame": 0}),
         "fixed_camera": ({"ms_per_step": round(elapsed_fixed / args.steps * 1e3, 4), "value": round(rays_fixed * args.steps / elapsed_fixed / 1e6, 2), "unit": "Mrays/s"} if elapsed_fixed else None),
@@ -433,6 +437,7 @@ def main():
     }
     print(json.dumps(out), flush=True)
     if dist_on:
+        sf.close()
         tdist.barrier()
         tdist.destroy_process_group()
 

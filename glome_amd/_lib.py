@@ -61,6 +61,9 @@ SYMBOLS = [
     ("glome_ctx_timing_begin_sampled", C.c_int, [vp, C.c_int, C.c_int]),
     ("glome_ctx_timing_end", C.c_int, [vp, c_fp, C.c_int]),
     ("glome_ctx_set_grid_per_cu", C.c_int, [vp, C.c_int]),
+    ("glome_ipc_alloc", C.c_int, [vp, C.c_size_t, C.POINTER(vp), C.c_char_p]),
+    ("glome_ipc_open", C.c_int, [vp, C.c_char_p, C.POINTER(vp)]),
+    ("glome_ipc_close", C.c_int, [vp, vp, C.c_int]),
     ("glome_multi_create", vp, [C.POINTER(vp), C.c_int, vp, C.c_int]),
     ("glome_multi_destroy", None, [vp]),
     ("glome_multi_render", C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp]),

@@ -422,11 +422,13 @@ class Multi:
     """Several GPUs driven by this one process (glome_multi_*): scenes[i] is the scene committed on context i; frames land
     on scenes[0]'s device.  The one-process counterpart of dist.ShardedFrame (one process per GPU)."""
 
-    def __init__(self, scenes, params, use_rccl=True):
+    def __init__(self, scenes, params, use_rccl=True, transport=None):
+        """transport: "direct" (ranks store straight into rank 0's framebuffer), "rccl", "peer-copy"; default: rccl when use_rccl else peer-copy"""
         self.lib = scenes[0].lib
         self.scenes = list(scenes)
         arr = (C.c_void_p * len(scenes))(*[s.h for s in scenes])
-        self.h = self.lib.glome_multi_create(arr, len(scenes), C.byref(params), 1 if use_rccl else 0)
+        code = {"direct": 2, "rccl": 1, "peer-copy": 0}[transport] if transport is not None else (1 if use_rccl else 0)
+        self.h = self.lib.glome_multi_create(arr, len(scenes), C.byref(params), code)
         if not self.h:
             raise GlomeError("glome_multi_create: " + self.lib.glome_global_error().decode())
         self.params = params

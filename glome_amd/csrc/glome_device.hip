@@ -1052,6 +1052,38 @@ int glome_ctx_debug_words(glome_ctx* c, uint64_t* out16) {  // DCounters::dbg of
   HIPCHK(c, hipMemcpy(out16, c->slot().d_counters->dbg, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return 0;
 }
+// ---- a framebuffer several PROCESSES render into (one process per GPU: glome_amd/dist.py) ----
+// rank 0 allocates the frames and exports a handle; the other ranks open it and hand the pointer to their render calls, whose kernels
+// then store their tiles' pixels straight into rank 0's memory over xGMI (hipIpc*: dmabuf handles on this driver).
+int glome_ipc_alloc(glome_ctx* c, size_t bytes, void** dev_ptr, unsigned char* handle64) {
+  if (!c || !dev_ptr || !handle64 || bytes == 0) return GLOME_E_INVALID;
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "a HIP IPC memory handle is 64 bytes");
+  HIPCHK(c, hipSetDevice(c->device));
+  void* p = nullptr;
+  HIPCHK(c, hipMalloc(&p, bytes));
+  hipIpcMemHandle_t h;
+  hipError_t e = hipIpcGetMemHandle(&h, p);
+  if (e != hipSuccess) { (void)hipFree(p); c->err = std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e); (void)hipGetLastError(); return GLOME_E_HIP; }
+  memcpy(handle64, &h, 64);
+  HIPCHK(c, hipMemset(p, 0, bytes));
+  *dev_ptr = p;
+  return 0;
+}
+int glome_ipc_open(glome_ctx* c, const unsigned char* handle64, void** dev_ptr) {
+  if (!c || !dev_ptr || !handle64) return GLOME_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle64, 64);
+  hipError_t e = hipIpcOpenMemHandle(dev_ptr, h, hipIpcMemLazyEnablePeerAccess);
+  if (e != hipSuccess) { c->err = std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e); (void)hipGetLastError(); return GLOME_E_HIP; }
+  return 0;
+}
+int glome_ipc_close(glome_ctx* c, void* dev_ptr, int owner) {  // owner: the process that allocated frees, the others close their mapping
+  if (!c || !dev_ptr) return GLOME_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (owner) HIPCHK(c, hipFree(dev_ptr)); else HIPCHK(c, hipIpcCloseMemHandle(dev_ptr));
+  return 0;
+}
 int glome_ctx_debug_reset(glome_ctx* c) {  // (measurement builds: the timeline words of the current slot back to "nothing seen")
   if (!c) return GLOME_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
@@ -1765,6 +1797,7 @@ struct glome_multi {
   hipEvent_t consumed = nullptr;           // rank 0 has taken the payloads of the last call
   bool used = false;
   bool rccl = false;
+  bool direct = false;                     // every rank's render kernel stores its pixels straight into packed_dev on rank 0's GPU (peer access)
   std::vector<Rccl::comm_t> comms;
   std::string err;
 };
@@ -1774,7 +1807,7 @@ struct glome_multi {
     if (e_ != hipSuccess) { (m)->err = std::string(#call) + ": " + hipGetErrorString(e_); return GLOME_E_HIP; } \
   } while (0)
 
-glome_multi* glome_multi_create(glome_scene* const* scenes, int n, const glome_render_params* P, int use_rccl) {
+glome_multi* glome_multi_create(glome_scene* const* scenes, int n, const glome_render_params* P, int transport) {
   if (!scenes || n < 1 || n > 64 || !P) { g_global_error = "glome_multi_create: bad argument"; return nullptr; }
   for (int i = 0; i < n; i++) {
     if (!scenes[i]) { g_global_error = "glome_multi_create: null scene"; return nullptr; }
@@ -1797,13 +1830,34 @@ glome_multi* glome_multi_create(glome_scene* const* scenes, int n, const glome_r
   m->maxp = std::max<int64_t>(m->maxp, 1);
   auto fail = [&](const std::string& what) { g_global_error = "glome_multi_create: " + what; glome_multi_destroy(m); return (glome_multi*)nullptr; };
   const size_t slab = (size_t)kMaxBatchFrames * (size_t)m->maxp;
-  if (hipSetDevice(scenes[0]->ctx->device) != hipSuccess || hipMalloc((void**)&m->gathered, slab * n * sizeof(uint32_t)) != hipSuccess) return fail("device allocation failed");
+  // transport 2 ("direct"): no payloads, no exchange, no blit -- every rank's render kernel writes its tiles' packed pixels where they
+  // belong in the caller's framebuffer on rank 0's GPU (4 bytes per pixel over xGMI, a 256-byte store per work item), and rank 0's
+  // stream waits for the other ranks' launches.  It needs every rank's device to reach rank 0's memory: the same device, or peer access.
+  if (transport == 2 && n > 1) {
+    bool can_all = true;
+    for (int i = 1; i < n && can_all; i++) {
+      if (scenes[i]->ctx->device == scenes[0]->ctx->device) continue;
+      int can = 0;
+      (void)hipDeviceCanAccessPeer(&can, scenes[i]->ctx->device, scenes[0]->ctx->device);
+      if (!can) { can_all = false; break; }
+      if (hipSetDevice(scenes[i]->ctx->device) != hipSuccess) { can_all = false; break; }
+      hipError_t e = hipDeviceEnablePeerAccess(scenes[0]->ctx->device, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); can_all = false; }
+    }
+    m->direct = can_all;
+    // nobody receives or blits any more: every rank owns a fair share of the tiles, whatever weight the caller gave rank 0
+    if (m->direct) { m->P.rank0_share_pct = 0; for (auto& q : m->Pl) q.rank0_share_pct = 0; }
+  }
+  const bool use_rccl = transport == 1 || (transport == 2 && !m->direct);
   m->payload.assign(n, nullptr);
   m->rendered.assign(n, nullptr);
-  m->payload[0] = m->gathered;  // rank 0 renders into its own slab
+  if (!m->direct) {
+    if (hipSetDevice(scenes[0]->ctx->device) != hipSuccess || hipMalloc((void**)&m->gathered, slab * n * sizeof(uint32_t)) != hipSuccess) return fail("device allocation failed");
+    m->payload[0] = m->gathered;  // rank 0 renders into its own slab
+  }
   for (int i = 0; i < n; i++) {
     if (hipSetDevice(scenes[i]->ctx->device) != hipSuccess) return fail("hipSetDevice failed");
-    if (i > 0 && hipMalloc((void**)&m->payload[i], slab * sizeof(uint32_t)) != hipSuccess) return fail("device allocation failed");
+    if (!m->direct && i > 0 && hipMalloc((void**)&m->payload[i], slab * sizeof(uint32_t)) != hipSuccess) return fail("device allocation failed");
     if (hipEventCreateWithFlags(&m->rendered[i], hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
   }
   (void)hipSetDevice(scenes[0]->ctx->device);
@@ -1813,6 +1867,7 @@ glome_multi* glome_multi_create(glome_scene* const* scenes, int n, const glome_r
   for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) distinct &= scenes[i]->ctx->device != scenes[j]->ctx->device;
   // (GLOME_DEBUG_RCCL_SAME_DEVICE lifts the distinct-device condition -- real RCCL refuses two ranks on one device -- for the
   // stubbed transport of the one-GPU test, and ONLY for it: with the real library loaded the variable is ignored)
+  if (m->direct) return m;
   if (use_rccl && n > 1 && (distinct || (Rccl::get().debug_lib && getenv("GLOME_DEBUG_RCCL_SAME_DEVICE"))) && Rccl::get().ok) {
     std::vector<int> devs;
     for (int i = 0; i < n; i++) devs.push_back(scenes[i]->ctx->device);
@@ -1845,7 +1900,7 @@ void glome_multi_destroy(glome_multi* m) {
   delete m;
 }
 const char* glome_multi_last_error(const glome_multi* m) { return m ? m->err.c_str() : g_global_error.c_str(); }
-const char* glome_multi_transport(const glome_multi* m) { return !m ? "" : (m->n == 1 ? "none" : (m->rccl ? "rccl" : "peer-copy")); }
+const char* glome_multi_transport(const glome_multi* m) { return !m ? "" : (m->n == 1 ? "none" : (m->direct ? "direct" : (m->rccl ? "rccl" : "peer-copy"))); }
 
 int glome_multi_render(glome_multi* m, const glome_camera* cams, int nframes, const glome_light* lights, int nlights, uint32_t* packed_dev) {
   if (!m || !cams || !packed_dev) return GLOME_E_INVALID;
@@ -1853,6 +1908,23 @@ int glome_multi_render(glome_multi* m, const glome_camera* cams, int nframes, co
   const int n = m->n;
   glome_ctx* c0 = m->scenes[0]->ctx;
   const size_t slab = (size_t)kMaxBatchFrames * (size_t)m->maxp;
+  if (m->direct) {
+    // every rank renders its tiles of the nframes views into the frames themselves (frame layout, its own tiles only); rank 0's stream
+    // -- the one the caller orders its reads of packed_dev on -- waits for the others
+    const int64_t fs = (int64_t)m->P.width * m->P.height;
+    for (int i = n - 1; i >= 0; i--) {  // (rank 0 last: its launch is queued behind nothing of the others)
+      glome_ctx* c = m->scenes[i]->ctx;
+      MHIP(m, hipSetDevice(c->device));
+      int rc = nframes > 1 ? render_impl(m->scenes[i], cams, lights, nlights, &m->Pl[i], nullptr, packed_dev, nullptr, 0, nframes, fs)
+                           : render_impl(m->scenes[i], cams, lights, nlights, &m->Pl[i], nullptr, packed_dev, nullptr, 0);
+      if (rc) { m->err = "rank " + std::to_string(i) + ": " + c->err; return rc; }
+      if (i > 0) MHIP(m, hipEventRecord(m->rendered[i], c->stream));
+    }
+    MHIP(m, hipSetDevice(c0->device));
+    for (int i = 1; i < n; i++) MHIP(m, hipStreamWaitEvent(c0->stream, m->rendered[i], 0));
+    m->used = true;
+    return 0;
+  }
   // every rank renders its tiles of the nframes views into its payload (frame f at f * maxp)
   for (int i = 0; i < n; i++) {
     glome_ctx* c = m->scenes[i]->ctx;
@@ -1909,7 +1981,7 @@ int glome_multi_synchronize(glome_multi* m) {
 // the one-call form SURVEY.md Appendix B names: host framebuffer out
 int glome_render_multi(glome_scene* const* scenes, int n, const glome_camera* cam, const glome_light* lights, int nlights, const glome_render_params* P, uint32_t* packed) {
   if (!packed) { g_global_error = "glome_render_multi: null framebuffer"; return GLOME_E_INVALID; }
-  glome_multi* m = glome_multi_create(scenes, n, P, 1);
+  glome_multi* m = glome_multi_create(scenes, n, P, 2);  // direct stores where the GPUs reach each other's memory, else RCCL, else peer copies
   if (!m) return GLOME_E_INVALID;
   uint32_t* d = nullptr;
   const size_t np = (size_t)P->width * P->height;

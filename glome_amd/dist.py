@@ -166,9 +166,17 @@ class ShardedFrame:
     blitTile are fused and 4 bytes per pixel cross xGMI.  "rgbad" -- the float (r, g, b, a, depth) tuples ([h, w, 5]),
     20 bytes per pixel (one frame per launch)."""
 
-    def __init__(self, scene, params, rank, world, device, lanes=4, product="rgbad", group=1, force_pipeline=False, work_tiles=64, rank0_share_pct=None):
+    def __init__(self, scene, params, rank, world, device, lanes=4, product="rgbad", group=1, force_pipeline=False, work_tiles=64, rank0_share_pct=None, direct=None):
+        """direct: every rank's render kernel stores its tiles' packed pixels straight into rank 0's frames (HIP IPC mappings of rank
+        0's framebuffers, glome_ipc_*): no payload, no gather, no blit, a fair share of the tiles for every rank, and one tiny
+        all-reduce per group of frames as the completion signal.  None = try it for the packed renderTile product with several ranks
+        and fall back to the gather pipeline -- on EVERY rank, agreed by a collective -- when the mapping cannot be made."""
         import torch
         self.torch = torch
+        self.direct = False
+        want_direct = (world > 1 and product == "packed" and params.mode == 0) if direct is None else bool(direct)
+        if want_direct and world > 1 and product == "packed" and params.mode == 0:
+            rank0_share_pct = 0 if rank0_share_pct is None else rank0_share_pct
         # rank 0 also receives and blits every frame: it owns less than a fair share of the tiles (glome_render_params.rank0_share_pct;
         # the defaults are where rank 0's and another rank's sustained frame periods met on one GPU, tools/shard_share.py)
         if rank0_share_pct is None:
@@ -197,12 +205,16 @@ class ShardedFrame:
         self.streams = [torch.cuda.Stream(device=device) for _ in range(self.n)]
         dt = torch.int32 if self.packed else torch.float32
         shape = (self.G, self.h, self.w) if self.packed else (self.G, self.h, self.w, 5)
-        self.frames = [torch.zeros(shape, dtype=dt, device=device) for _ in range(self.n)] if rank == 0 else None
+        self.frames = None
+        if want_direct and world > 1 and self.packed and params.mode == 0:
+            self._setup_direct(shape)
+        if not self.direct:
+            self.frames = [torch.zeros(shape, dtype=dt, device=device) for _ in range(self.n)] if rank == 0 else None
         self.last = (0, 0)
         self.k = 0
         self.batch = []
         self.lights = self.la = None
-        if self.piped:
+        if self.piped and not self.direct:
             payloads = [torch.zeros(self.G * self.plan.maxp, dtype=dt, device=device) for _ in range(self.n)]
             gathereds = [torch.zeros((world, self.G * self.plan.maxp), dtype=dt, device=device) if rank == 0 else None for _ in range(self.n)]
             self.pipe = FramePipeline(self.plan, payloads, gathereds, self._render_group, self._blit, self._lane, group=self.G,
@@ -212,6 +224,93 @@ class ShardedFrame:
     @property
     def frame(self):
         return self.frames[self.last[0]][self.last[1]] if self.frames is not None else None
+
+    # ---- direct mode: rank 0's framebuffers mapped into every rank's address space ----
+    def _setup_direct(self, shape):
+        """rank 0 allocates one framebuffer [G, h, w] per lane through glome_ipc_alloc and publishes the handles; the others open them.
+        Whether that worked is agreed by all ranks (MIN all-reduce) before anybody commits to the mode."""
+        import torch.distributed as dist
+        torch = self.torch
+        nbytes = int(np.prod(shape)) * 4
+        ok, self._ipc_ptrs, handles = 1, [], []
+        if self.rank == 0:
+            for _ in range(self.n):
+                p, h = C.c_void_p(), C.create_string_buffer(64)
+                if self.lib.glome_ipc_alloc(self.ctx.h, nbytes, C.byref(p), h) != 0:
+                    ok = 0
+                    break
+                self._ipc_ptrs.append(p.value); handles.append(h.raw)
+        box = [handles if ok else None]
+        dist.broadcast_object_list(box, src=0, **({"device": self.device} if dist.get_backend() != "gloo" else {}))
+        if self.rank != 0:
+            if box[0] is None:
+                ok = 0
+            else:
+                for h in box[0]:
+                    p = C.c_void_p()
+                    if self.lib.glome_ipc_open(self.ctx.h, h, C.byref(p)) != 0:
+                        ok = 0
+                        break
+                    self._ipc_ptrs.append(p.value)
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.device if dist.get_backend() != "gloo" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) != 1:
+            self._close_direct()
+            self.direct_error = self.ctx.err() if not ok else "another rank could not map the frames"
+            return
+        self.direct = True
+        if self.rank == 0:  # the frames as tensors over the very memory the other ranks store into (no copy: __cuda_array_interface__)
+            class _Raw:
+                def __init__(s, ptr, shp):
+                    s.__cuda_array_interface__ = {"shape": tuple(shp), "typestr": "<i4", "data": (ptr, False), "version": 2}
+            self.frames = [torch.as_tensor(_Raw(p, shape), device=self.device) for p in self._ipc_ptrs]
+        self._done = [torch.zeros(1, dtype=torch.int32, device=self.device) for _ in range(self.n)]
+        self._pending = []
+
+    def _close_direct(self):
+        for p in getattr(self, "_ipc_ptrs", []):
+            self.lib.glome_ipc_close(self.ctx.h, C.c_void_p(p), 1 if self.rank == 0 else 0)
+        self._ipc_ptrs = []
+
+    def close(self):
+        """direct mode: unmap / free the shared framebuffers (after flush(); rank 0's `frames` tensors die with them)"""
+        if self.direct:
+            self.flush()
+            self.torch.cuda.synchronize(self.device)
+            import torch.distributed as dist
+            dist.barrier()
+            self.frames = None
+            self._close_direct()
+            self.direct = False
+
+    def _launch_direct(self):
+        """the rank's tiles of the batch, straight into rank 0's frames of this lane; then the group's completion signal: a one-word
+        all-reduce ordered behind the launch on every rank -- when it is through on rank 0's lane stream, every rank's stores are in"""
+        import torch.distributed as dist
+        slot = self.k % self.n
+        self.k += 1
+        views, self.batch = self.batch, []
+        while len(self._pending) >= self.n:  # the lane's last group must be through before its frames are written again
+            self._finish_direct(self._pending.pop(0))
+        with self._lane(slot):
+            rc = self.lib.glome_render_packed_batch_dev(self.scene.h, self._cams(views), len(views), self.la, len(self.lights), C.byref(self.P_local),
+                                                        C.c_void_p(self._ipc_ptrs[slot]), self.h * self.w, None)
+            if rc != 0:
+                raise api.GlomeError("render (direct): " + self.ctx.err())
+            if dist.get_backend() == "gloo":  # bench.py --rehearse: the host stands in for the stream-ordered collective
+                self.torch.cuda.current_stream().synchronize()
+                dist.barrier()
+                work = None
+            else:
+                work = dist.all_reduce(self._done[slot], async_op=True)
+        self._pending.append((slot, len(views), work))
+
+    def _finish_direct(self, pending):
+        slot, nrows, work = pending
+        if work is not None:
+            with self._lane(slot):
+                work.wait()  # this lane's stream waits for the collective: all ranks' launches of the group are complete
+        self.last = (slot, nrows - 1)
 
     def _lane(self, slot):
         s = self.streams[slot]
@@ -294,6 +393,16 @@ class ShardedFrame:
             self.flush()
             self.torch.cuda.synchronize(self.device)
             st = L.Stats()
+            if self.direct:  # this rank's tiles of the one view into frame 0 of lane 0, then everybody waits for everybody
+                import torch.distributed as dist
+                with self._lane(0):
+                    rc = self.lib.glome_render_packed_batch_dev(self.scene.h, self._cams([cam]), 1, self.la, len(self.lights), C.byref(self.P_local),
+                                                                C.c_void_p(self._ipc_ptrs[0]), self.h * self.w, C.byref(st))
+                if rc != 0:
+                    raise api.GlomeError("render (direct): " + self.ctx.err())
+                dist.barrier()
+                self.last = (0, 0)
+                return api._stats_dict(st)
             with self._lane(0):
                 if not self.piped:
                     fp = self.frames[0].data_ptr()
@@ -308,6 +417,11 @@ class ShardedFrame:
                         self._blit(0, 0, self.pipe.gathereds[0])
             self.last = (0, 0)
             return api._stats_dict(st)
+        if self.direct:
+            self.batch.append(cam)
+            if len(self.batch) == self.G:
+                self._launch_direct()
+            return None
         if not self.piped:
             self.batch.append(cam)
             if len(self.batch) == self.G:
@@ -317,7 +431,12 @@ class ShardedFrame:
         return None
 
     def flush(self):
-        if self.piped:
+        if self.direct:
+            if self.batch:
+                self._launch_direct()
+            while self._pending:
+                self._finish_direct(self._pending.pop(0))
+        elif self.piped:
             self.pipe.flush()
         elif self.batch:
             self._launch_local()

@@ -285,19 +285,32 @@ int glome_render_packed_batch_dev(glome_scene*, const glome_camera* cams, int nf
  * scenes[i] = the same scene committed on context i (a context per GPU; rank 0's GPU receives the frame).  Tile k of the
  * frame -- 64x64 work tiles in renderTile mode, the 65x65 reference tiles in adaptive mode (whose pixels depend on the tile
  * map, Q21) -- belongs to rank k mod n, or to the rank the weighted pattern of glome_render_params.rank0_share_pct gives it.
- * A call renders nframes <= 32 views (one in adaptive mode): every rank renders its
- * tiles of all of them in one launch into a packed 0x00RRGGBB payload, the payloads move to rank 0's GPU over xGMI -- RCCL
- * send / recv in one group when use_rccl != 0, librccl.so can be opened and the ranks sit on distinct devices, peer copies
- * otherwise (glome_multi_transport says which) -- and one launch there blits the frames into packed_dev (frame f at
- * f * width * height words).  Asynchronous; glome_multi_synchronize waits for all ranks and reports device-side limits.
+ * A call renders nframes <= 32 views (one in adaptive mode), every rank its tiles of all of them in one launch.  How the pixels
+ * reach packed_dev (frame f at f * width * height words) is the TRANSPORT (glome_multi_transport says which was taken):
+ *   2 "direct"     every rank's render kernel stores its tiles' packed 0x00RRGGBB pixels straight into packed_dev on rank 0's GPU
+ *                  (4 bytes per pixel over xGMI); rank 0's stream waits for the others' launches.  No payload, no exchange, no blit,
+ *                  and every rank owns a fair share of the tiles (rank0_share_pct is ignored).  Needs every rank's device to reach rank
+ *                  0's memory (the same device, or peer access); asked for and not possible -> "rccl" / "peer-copy" as below.
+ *   1 "rccl"       ranks render into packed payloads, which move to rank 0's GPU with RCCL send / recv in one group (librccl.so is
+ *                  dlopen'ed; the ranks must sit on distinct devices), and one launch there blits the frames into packed_dev.
+ *   0 "peer-copy"  the same with peer copies on rank 0's stream.
+ * Asynchronous; glome_multi_synchronize waits for all ranks and reports device-side limits.
  * The RCCL branch needs distinct devices and has not run on real RCCL with more than one rank on this pool (one-GPU boxes): it
  * is exercised against a stand-in transport whose send / recv pairs are stream-ordered device copies (tests/rcclstub). */
+/* ---- a framebuffer several processes render into (one process per GPU, glome_amd/dist.py) ----
+ * glome_ipc_alloc: device memory on this context's GPU (zeroed) and a 64-byte handle another process passes to glome_ipc_open to
+ * map it; a rank then renders its tiles of a frame with glome_render_packed_batch_dev (tile_first / tile_stride set, frame
+ * layout) straight into the mapping -- its kernel's stores cross xGMI, nothing is gathered or blitted.  glome_ipc_close: the
+ * owner frees, the others unmap.  (HIP IPC; on this driver dmabuf handles: HSA_ENABLE_IPC_MODE_LEGACY=0.) */
+int glome_ipc_alloc(glome_ctx*, size_t bytes, void** dev_ptr, unsigned char* handle64);
+int glome_ipc_open(glome_ctx*, const unsigned char* handle64, void** dev_ptr);
+int glome_ipc_close(glome_ctx*, void* dev_ptr, int owner);
 typedef struct glome_multi glome_multi;
-glome_multi* glome_multi_create(glome_scene* const* scenes, int n, const glome_render_params*, int use_rccl); /* NULL: glome_global_error() */
+glome_multi* glome_multi_create(glome_scene* const* scenes, int n, const glome_render_params*, int transport); /* 0 / 1 / 2 as above; NULL: glome_global_error() */
 void glome_multi_destroy(glome_multi*);
 int glome_multi_render(glome_multi*, const glome_camera* cams, int nframes, const glome_light* lights, int nlights, uint32_t* packed_dev);
 int glome_multi_synchronize(glome_multi*);
-const char* glome_multi_transport(const glome_multi*); /* "rccl", "peer-copy" or "none" (one rank) */
+const char* glome_multi_transport(const glome_multi*); /* "direct", "rccl", "peer-copy" or "none" (one rank) */
 const char* glome_multi_last_error(const glome_multi*);
 /* One frame into a host framebuffer (width * height words): create, render, synchronize, copy, destroy. */
 int glome_render_multi(glome_scene* const* scenes, int n, const glome_camera*, const glome_light* lights, int nlights,

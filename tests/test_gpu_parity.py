@@ -963,10 +963,11 @@ def test_multi_gpu_c_abi_frames_equal_the_single_gpu_frames(gpu_ctx, n):
     cams = [api.camera((pos[0] + 2.0 * k, pos[1] + 0.5 * k, pos[2]), at, up, fov) for k in range(3)]
     _, lights = product_camera_lights(sd)
     W, H = 645, 390
-    for mode, views in ((0, cams), (1, cams[:1])):
+    for transport in (None, "direct"):  # the payload / exchange / blit path, and (round 4) every rank storing straight into the frame
+      for mode, views in ((0, cams), (1, cams[:1])):
         P = api.render_params(width=W, height=H, mode=mode, maxdepth=1, rank0_share_pct=65 if n == 3 else 0)  # (three ranks: rank 0 with less than a fair share)
-        m = api.Multi(scs, P)
-        assert m.transport() == ("none" if n == 1 else "peer-copy")
+        m = api.Multi(scs, P, transport=transport)
+        assert m.transport() == ("none" if n == 1 else (transport or "peer-copy"))
         out = torch.full((len(views), H, W), -1, dtype=torch.int32, device=dev)
         for rep in range(2):  # a second call reuses the payload buffers: the first call's copies must have drained
             m.render(views, lights, out.data_ptr())
@@ -975,7 +976,7 @@ def test_multi_gpu_c_abi_frames_equal_the_single_gpu_frames(gpu_ctx, n):
             want = torch.zeros((H, W), dtype=torch.int32, device=dev)
             scs[0].render_dev(cam, lights, P, None, want.data_ptr())
             gpu_ctx.synchronize()
-            assert torch.equal(out[k], want), (mode, k)
+            assert torch.equal(out[k], want), (mode, transport, k)
         m.close()
     # the one-call host-buffer form
     P = api.render_params(width=W, height=H, maxdepth=1)
@@ -1235,3 +1236,23 @@ def test_csg_items_of_the_flat_tier_advance_without_a_cap(gpu_ctx):
             both = (err(img, ref) > 1e-4) & (err(img, r32) > 1e-4)
             assert both.mean() <= (2e-3 if mode == 0 else 6e-3), (mode, int(both.sum()))
         sc.release()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks,transport", [(2, "direct"), (3, "direct"), (2, "gather")])
+def test_one_process_per_gpu_job_rehearsed_on_one_gpu(ranks, transport):
+    """bench.py --gpus N as the driver launches it -- one process per rank, torch.distributed -- rehearsed on the one GPU of the box
+    (--rehearse: gloo instead of RCCL, every rank on device 0).  `direct` (round 4): every rank's kernel stores its tiles straight
+    into rank 0's frames, mapped into the other processes through HIP IPC handles (glome_ipc_*); `gather`: payloads to rank 0 and a
+    blit.  Either way the last frame rank 0 holds equals the same view rendered whole on its GPU, bit for bit."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--rehearse", "--transport", transport, "--scene", "S3", "--steps", "9", "--warmup", "3",
+                        "--group", "4", "--no-cpu"], capture_output=True, text=True, timeout=500, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-2500:])
+    line = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == ranks and line["frame_equals_single_gpu_render"] is True, line
+    assert line["config"]["transport"].startswith(transport), line["config"]["transport"]
