@@ -569,9 +569,12 @@ constexpr uint32_t PKREF_LEAF = 3u;  // low bits of a reference in the walk's ow
       "  s_cbranch_scc1 L_fresh_%=\n"                                                                                           \
       "  s_mov_b64 exec, -1\n"              /* entry k lives in lane k: every lane takes part, whatever the caller's mask */     \
       "  s_waitcnt vmcnt(0)\n"                                                                                                  \
-      "  global_load_dword %[ur], %[dump], off\n"                                                                               \
-      "  global_load_dword %[ulo], %[dump], off offset:256\n"                                                                   \
-      "  global_load_dword %[uhi], %[dump], off offset:512\n"                                                                   \
+      "  v_mbcnt_lo_u32_b32 v" T2 ", -1, 0\n" /* the dump block is wave-uniform: lane l's words at 4 l, 256 + 4 l, 512 + 4 l */   \
+      "  v_mbcnt_hi_u32_b32 v" T2 ", -1, v" T2 "\n"                                                                             \
+      "  v_lshlrev_b32 v" T2 ", 2, v" T2 "\n"                                                                                   \
+      "  global_load_dword %[ur], v" T2 ", %[dump]\n"                                                                           \
+      "  global_load_dword %[ulo], v" T2 ", %[dump] offset:256\n"                                                               \
+      "  global_load_dword %[uhi], v" T2 ", %[dump] offset:512\n"                                                               \
       "  s_waitcnt vmcnt(0)\n"                                                                                                  \
       "L_fresh_%=:\n"                                                                                                           \
       "  s_cmp_lg_u32 %[phase], 0\n"                                                                                            \
@@ -639,9 +642,12 @@ constexpr uint32_t PKREF_LEAF = 3u;  // low bits of a reference in the walk's ow
       "  s_mov_b32 %[status], 3\n"                                                                                              \
       "L_dump_%=:\n"                          /* a C++ step follows: the entries (lane k = entry k) leave the registers */       \
       "  s_mov_b64 exec, -1\n"                                                                                                  \
-      "  global_store_dword %[dump], %[ur], off\n"                                                                              \
-      "  global_store_dword %[dump], %[ulo], off offset:256\n"                                                                  \
-      "  global_store_dword %[dump], %[uhi], off offset:512\n"                                                                  \
+      "  v_mbcnt_lo_u32_b32 v" T2 ", -1, 0\n"                                                                                   \
+      "  v_mbcnt_hi_u32_b32 v" T2 ", -1, v" T2 "\n"                                                                             \
+      "  v_lshlrev_b32 v" T2 ", 2, v" T2 "\n"                                                                                   \
+      "  global_store_dword v" T2 ", %[ur], %[dump]\n"                                                                          \
+      "  global_store_dword v" T2 ", %[ulo], %[dump] offset:256\n"                                                              \
+      "  global_store_dword v" T2 ", %[uhi], %[dump] offset:512\n"                                                              \
       "  s_waitcnt vmcnt(0)\n"                                                                                                  \
       "L_end_%=:\n"                                                                                                             \
       "  s_mov_b64 exec, s[" K30 ":" K31 "]\n"                                                                                  \
@@ -651,7 +657,7 @@ constexpr uint32_t PKREF_LEAF = 3u;  // low bits of a reference in the walk's ow
       : [ref] "+s"(ref), [am] "+s"(am), [sp] "+s"(sp), [near] "+v"(nearv), [far] "+v"(farv), [best_t] "+v"(best_t), [best_rec] "+v"(best_rec), [ur] "=&v"(ur),    \
         [ulo] "=&v"(ulo), [uhi] "=&v"(uhi), [occ] "+s"(occm), [status] "=s"(status)                                                                                  \
       : [nodes_lo] "s"(nodes_lo), [nodes_hi] "s"(nodes_hi), [nbytes] "s"(nbytes), [pairs] "s"(pairs), [cap] "n"(CAP), [phase] "s"(phase), [P0] "v"(P0), [P1] "v"(P1),  \
-        [P2] "v"(P2), [R0] "v"(R0), [R1] "v"(R1), [lds] "v"(lds_row), [row1] "n"(CAP * 256), [dump] "v"(dump)                                                         \
+        [P2] "v"(P2), [R0] "v"(R0), [R1] "v"(R1), [lds] "v"(lds_row), [row1] "n"(CAP * 256), [dump] "s"(dump)                                                         \
       : "s" K0, "s" K1, "s" K2, "s" K3, "s" K4, "s" K5, "s" K6, "s" K7, "s" K8, "s" K9, "s" K10, "s" K11, "s" K12, "s" K13, "s" K14, "s" K15, "s" K16, "s" K17, "s" K18, \
         "s" K19, "s" K20, "s" K21, "s" K22, "s" K23, "s" K24, "s" K25, "s" K26, "s" K27, "s" K28, "s" K29, "s" K30, "s" K31, "s" K32, "s" K33, "s" K34, "s" K35,          \
         "s" K36, "s" K37, "s" K38, "s" K39,                                                                                                                          \
@@ -677,6 +683,7 @@ __device__ __forceinline__ int bih_walk_asm(const F4* nodes, uint32_t nbytes, co
   ref = uni(ref); am = uni(am); sp = (int)uni((uint32_t)sp); occm = uni(occm); phase = (int)uni((uint32_t)phase); nbytes = uni(nbytes);
   const uint32_t nodes_lo = uni((uint32_t)(uintptr_t)nodes), nodes_hi = uni((uint32_t)((uintptr_t)nodes >> 32));
   pairs = (const float*)(uintptr_t)uni((LaneMask)(uintptr_t)pairs);
+  dump = (uint32_t*)(uintptr_t)uni((LaneMask)(uintptr_t)dump);  // the wave's dump block (LaneStack::dump_base): a scalar pair, the lane's offset is made where it is used
 #define GLOME_PKW_BY_OCTANT(M)                                                    \
   if constexpr (XF && YF && ZF) GLOME_PKW_ASM(FWD, FWD, FWD, M);                  \
   else if constexpr (!XF && YF && ZF) GLOME_PKW_ASM(BWD, FWD, FWD, M);            \

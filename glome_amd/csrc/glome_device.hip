@@ -62,6 +62,9 @@ struct FlatTier {
   LaneStack stk;
   Cnt cnt;
   unsigned int err = 0;  // a CSG item ran into the advance / frame cap (kernels with CLS_CSG)
+  // the same tier over another copy of the launch's arguments (render_loop: the kernarg segment, re-read per work item), and back
+  __device__ __forceinline__ FlatTier rebound(const DRenderArgs& A) const { return FlatTier{A.S, A.lights, A.nlights, stk, cnt, err}; }
+  __device__ __forceinline__ void absorb(const FlatTier& t) { cnt = t.cnt; err = t.err; }
   __device__ __forceinline__ HitG closest(const Ray& r, float tmax) {
     HitG ch;
     Cand c = closest_flat<FAITHFUL, COUNT, CLS>(S, r, tmax, stk, cnt, true, &ch, &err);
@@ -118,6 +121,8 @@ struct GenericTier {
   unsigned int& err;
   uint32_t* vm;  // the interpreter's frames: one word stack of kVmWords per lane for the whole kernel (scratch)
   LaneStack pk;  // the wave's LDS stack for packet walks of sphere BIHs inside the interpreter (cap 0: the scene has none)
+  __device__ __forceinline__ GenericTier rebound(const DRenderArgs&) const { return *this; }  // (already reads the kernarg segment: kernel_args<>())
+  __device__ __forceinline__ void absorb(const GenericTier&) {}
   // `root`: the record the trace runs over -- the scene's, or the frame / scene of a Warp material
   __device__ __forceinline__ HitG closest(const Ray& r, float tmax, uint32_t root) { return vm_closest<true>(S, cnt, err, vm, pk.cap > 0 ? &pk : (LaneStack*)nullptr, r, tmax, root); }
   __device__ __forceinline__ bool occluded(const Ray& r, float d, uint32_t root) { return vm_occluded<true>(S, cnt, err, vm, pk.cap > 0 ? &pk : (LaneStack*)nullptr, r, d, root); }
@@ -131,27 +136,21 @@ struct GenericTier {
 // two (near, far) in kernels that only ever run the hand-written packet walk, which keeps its references in registers
 template <bool TWO_ROWS = false>
 __device__ __forceinline__ LaneStack lane_stack(uint32_t* lds, int cap, uint32_t* ovf_base, int ovf_cap) {
-  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t* base = lds + (size_t)wave * cap * 64 * (TWO_ROWS ? 2 : 3);
+  const int wave = threadIdx.x >> 6;  // (uniform per wave; the flat kernels run one wave per workgroup)
   LaneStack s;
-  s.node = base + lane;  // with two rows this aliases the near row and is never written (no per-lane pushes in that kernel)
-  s.nearv = (float*)(base + (TWO_ROWS ? 0 : cap * 64)) + lane;
-  s.farv = s.nearv + cap * 64;
+  s.lds = lds + (size_t)wave * cap * 64 * (TWO_ROWS ? 2 : 3);
   s.cap = cap;
   s.has_ref_row = !TWO_ROWS;
   // overflow: one [entry * 3][64] block per wave slot (blockIdx.x * waves_per_block + wave); the block after the last
   // entry is the dump block
   s.ovf_cap = ovf_cap;
-  s.ovf = ovf_base + ((size_t)(blockIdx.x * (blockDim.x >> 6) + wave) * (ovf_cap + 1) * 3) * 64 + lane;
-  s.dump = s.ovf + (size_t)ovf_cap * 3 * 64;
+  s.ovfb = ovf_base ? ovf_base + ((size_t)(blockIdx.x * (blockDim.x >> 6) + wave) * (ovf_cap + 1) * 3) * 64 : nullptr;
   return s;
 }
 static size_t flat_lds_bytes(int cap, bool two_rows = false) { return (size_t)cap * 64 * (two_rows ? 8 : 12); }
 // the generic tier's packet stack: three rows in LDS, no overflow columns (a tree deeper than `cap` keeps the per-lane walk)
 __device__ __forceinline__ LaneStack generic_packet_stack(uint32_t* lds, int cap) {
-  LaneStack s = lane_stack<false>(lds, cap, nullptr, 0);
-  s.ovf = nullptr; s.dump = nullptr;
-  return s;
+  return lane_stack<false>(lds, cap, nullptr, 0);  // (ovfb null: no overflow columns and no dump block -- bih_tri_wave then never takes the hand-written walk)
 }
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned int v) {
@@ -160,7 +159,7 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned int v) {
   return s;
 }
 __device__ __forceinline__ void flush_counters(DCounters* c, const Cnt& cnt, unsigned int err) {
-  unsigned long long a = wave_sum(cnt.primary), b = wave_sum(cnt.shadow), s = wave_sum(cnt.secondary);
+  unsigned long long a = wave_sum(cnt.primary) + cnt.w_primary, b = wave_sum(cnt.shadow) + cnt.w_shadow, s = wave_sum(cnt.secondary);
   unsigned long long n = wave_sum(cnt.bih), m = wave_sum(cnt.mesh), p = wave_sum(cnt.prim);
   unsigned long long e = wave_sum(err);
   if ((threadIdx.x & 63) == 0) {
@@ -231,7 +230,9 @@ struct TicketQueue {
     return b < 1u ? 1u : (b > (uint32_t)GLOME_TICKET_BATCH ? (uint32_t)GLOME_TICKET_BATCH : b);
   }
   __device__ __forceinline__ TicketQueue(const DRenderArgs& A) : shard(blockIdx.x % kQueueShards), dry(0) { batch = batch_for(A, A.shard_cap); }
-  __device__ __forceinline__ uint32_t take(const DRenderArgs& A) {  // lane 0 only
+  // Every lane of the wave makes the call; the state is wave-uniform (scalar registers) and only the atomics themselves are lane 0's.
+  // (Until round 3 the whole take ran on lane 0 under a branch: its six state words then lived in vector registers for the kernel's lifetime.)
+  __device__ __forceinline__ uint32_t take(const DRenderArgs& A) {
     constexpr uint32_t kAll = (1u << kQueueShards) - 1u;
     for (;;) {
       if (left) {
@@ -242,16 +243,20 @@ struct TicketQueue {
       }
       if (dry == kAll) return kNoTicket;
       if (!((dry >> shard) & 1u)) {
-        const uint32_t i = atomicAdd(&A.counters->heads[shard * kQueueHeadStride], batch);
+        uint32_t i = 0;
+        if (LaneStack::lane() == 0) i = atomicAdd(&A.counters->heads[shard * kQueueHeadStride], batch);
+        i = uni(i);
         if (i < A.shard_cap) { inext = i; left = batch; cur = shard; batch = batch_for(A, A.shard_cap - i); continue; }
-        atomicOr(&A.counters->dry, 1u << shard);
-        dry |= (1u << shard) | __hip_atomic_load(&A.counters->dry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t d = 0;
+        if (LaneStack::lane() == 0) { atomicOr(&A.counters->dry, 1u << shard); d = __hip_atomic_load(&A.counters->dry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        dry |= (1u << shard) | uni(d);
         batch = 1;  // what other heads have left is shared by everybody who comes by
       }
       shard = (shard + 1) % kQueueShards;
     }
   }
-  __device__ __forceinline__ void leave(const DRenderArgs& A) {  // lane 0 only, after its last take
+  __device__ __forceinline__ void leave(const DRenderArgs& A) {  // after the wave's last take (every lane calls; lane 0 acts)
+    if (LaneStack::lane() != 0) return;
     if (atomicAdd(&A.counters->done, 1u) == gridDim.x - 1u) {  // every other wave has taken its last ticket
       for (uint32_t h = 0; h < kQueueShards; h++) __hip_atomic_store(&A.counters->heads[h * kQueueHeadStride], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&A.counters->dry, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -269,9 +274,16 @@ struct TicketQueue {
 #define GLOME_PROBE_FLAG(A, bit) false
 #endif
 template <class TIER>
-__device__ __forceinline__ void render_loop(const DRenderArgs& A, TIER& T) {
+__device__ __forceinline__ void render_loop(const DRenderArgs& A_, TIER& Tk) {
+#ifdef GLOME_PROBE
   int lane = threadIdx.x & 63;
-  TicketQueue Q(A);
+#endif
+  TicketQueue Q(A_);
+  // The launch's arguments are read where the dispatch put them (the kernarg segment: scalar loads), through a pointer the compiler
+  // cannot see through from one work item to the next: what an item derives from them -- (float)width, the reciprocals of the
+  // item -> pixel divisions, the table pointers -- is then made afresh per item (tens of instructions in eleven thousand) instead of
+  // being hoisted out of the loop and carried, spilled, through both walks.
+  const DRenderArgs __attribute__((address_space(4)))* ap_ = (const DRenderArgs __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
 #ifdef GLOME_PROBE
   uint32_t stat = blockIdx.x;
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, t_s[3] = {0, 0, 0};  // item -> pixel lookup, ray generation, trace
@@ -281,18 +293,19 @@ __device__ __forceinline__ void render_loop(const DRenderArgs& A, TIER& T) {
   uint32_t worst_steps = 0, steps_before = 0;
 #endif
   for (;;) {
+    asm volatile("" : "+s"(ap_));
+    const DRenderArgs& A = *(const DRenderArgs*)ap_;
+    TIER T = Tk.rebound(A);
     uint32_t w = kNoTicket;
 #ifdef GLOME_PROBE
     if (A.debug_flags & 8) { w = stat < A.total_waves * (uint32_t)A.nframes ? stat : kNoTicket; stat += gridDim.x; }
     else {
       const unsigned long long t0 = (A.debug_flags & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
-      if (lane == 0) w = Q.take(A);
-      w = __shfl(w, 0, 64);
+      w = Q.take(A);
       if (A.debug_flags & 16) { ts0 = __builtin_amdgcn_s_memtime(); t_take += ts0 - t0; n_take++; }
     }
 #else
-    if (lane == 0) w = Q.take(A);
-    w = __shfl(w, 0, 64);
+    w = Q.take(A);  // a SCALAR: the frame, the tile and the camera the ticket names are then scalar loads, not a lane's
 #endif
     if (w == kNoTicket) break;
 #ifdef GLOME_PROBE
@@ -315,15 +328,15 @@ __device__ __forceinline__ void render_loop(const DRenderArgs& A, TIER& T) {
     int px = 0, py = 0;
     size_t dense_off = 0;
     bool valid;
-    if (GLOME_PROBE_FLAG(A, 4)) { px = (int)((w * 64u + lane) % (uint32_t)A.width); py = (int)((w * 64u + lane) / (uint32_t)A.width); valid = py < A.height; }
-    else valid = work_to_pixel(A, w, lane, px, py, dense_off);  // lanes past the end of a leftover strip idle along
+    if (GLOME_PROBE_FLAG(A, 4)) { const uint32_t l_ = LaneStack::lane(); px = (int)((w * 64u + l_) % (uint32_t)A.width); py = (int)((w * 64u + l_) / (uint32_t)A.width); valid = py < A.height; }
+    else valid = work_to_pixel(A, w, (int)LaneStack::lane(), px, py, dense_off);  // lanes past the end of a leftover strip idle along
 #ifdef GLOME_PROBE
     if (A.debug_flags & 16) { asm volatile("" :: "v"(px), "v"(py)); ts1 = __builtin_amdgcn_s_memtime(); }
 #endif
     float xc, yc;
     get_coordsf(A.width, A.height, (float)px, (float)py, xc, yc);
     Ray ray = primary_ray(frame == 0 ? A.cam : A.more_cams[frame - 1], xc, yc);
-    if (valid) T.cnt.primary++;
+    count_wave(T.cnt.primary, T.cnt.w_primary, valid);
 #ifdef GLOME_PROBE
     if (A.debug_flags & 16) { asm volatile("" :: "v"(ray.d.x), "v"(ray.d.y), "v"(ray.d.z)); ts2 = __builtin_amdgcn_s_memtime(); }
 #endif
@@ -331,6 +344,7 @@ __device__ __forceinline__ void render_loop(const DRenderArgs& A, TIER& T) {
     CA c;
     if (GLOME_PROBE_FLAG(A, 2)) { c = ca(ray.d.x, ray.d.y, ray.d.z, 1.0f); h = hit_miss(); }
     else c = trace_primary(T, ray, kInf, A.maxdepth, valid, &h);  // Trace.trace lights shader sld ray infinity maxdepth (Glome.hs:33)
+    Tk.absorb(T);  // (counters and the error flag back into the kernel's tier)
 #ifdef GLOME_PROBE
     if (A.debug_flags & 16) { asm volatile("" :: "v"(c.r), "v"(c.g), "v"(c.b)); ts3 = __builtin_amdgcn_s_memtime(); t_s[0] += ts1 - ts0; t_s[1] += ts2 - ts1; t_s[2] += ts3 - ts2; }
     if (A.debug_flags & 32) {  // the longest item, and the C++ steps its walks needed
@@ -340,6 +354,8 @@ __device__ __forceinline__ void render_loop(const DRenderArgs& A, TIER& T) {
     }
 #endif
     if (!valid) continue;
+    // the pixel once more (rather than three registers carried, spilled, through both walks): the item is a scalar, the lane a v_mbcnt
+    if (!GLOME_PROBE_FLAG(A, 4)) { px = 0; py = 0; dense_off = 0; (void)work_to_pixel(A, w, (int)LaneStack::lane(), px, py, dense_off); }
     float depth = h.hit ? h.t : kInf;      // ridepth
     float r = c.r;
     if (A.fog) r = r + (depth / 400);      // renderTile's debug fog (Glome.hs:174, Q20)
@@ -355,22 +371,22 @@ __device__ __forceinline__ void render_loop(const DRenderArgs& A, TIER& T) {
     if (A.packed) A.packed[o] = rgbf(r * c.a, c.g * c.a, c.b * c.a);  // blitTile (Glome.hs:353-358)
   }
 #ifdef GLOME_PROBE
-  if ((A.debug_flags & 16) && lane == 0) {  // cycles waiting for tickets, tickets asked for, the wave's lifetime, waves, cycles per section
-    atomicAdd(&A.counters->dbg[0], t_take); atomicAdd(&A.counters->dbg[1], n_take);
-    atomicAdd(&A.counters->dbg[2], __builtin_amdgcn_s_memtime() - t_begin); atomicAdd(&A.counters->dbg[3], 1ull);
-    atomicAdd(&A.counters->dbg[4], t_s[0]); atomicAdd(&A.counters->dbg[5], t_s[1]); atomicAdd(&A.counters->dbg[6], t_s[2]);
+  if ((A_.debug_flags & 16) && lane == 0) {  // cycles waiting for tickets, tickets asked for, the wave's lifetime, waves, cycles per section
+    atomicAdd(&A_.counters->dbg[0], t_take); atomicAdd(&A_.counters->dbg[1], n_take);
+    atomicAdd(&A_.counters->dbg[2], __builtin_amdgcn_s_memtime() - t_begin); atomicAdd(&A_.counters->dbg[3], 1ull);
+    atomicAdd(&A_.counters->dbg[4], t_s[0]); atomicAdd(&A_.counters->dbg[5], t_s[1]); atomicAdd(&A_.counters->dbg[6], t_s[2]);
   }
-  if ((A.debug_flags & 32) && lane == 0) {  // the launch's timeline on the shared clock: first / last wave start, first / last wave's last ticket, first / last wave end
+  if ((A_.debug_flags & 32) && lane == 0) {  // the launch's timeline on the shared clock: first / last wave start, first / last wave's last ticket, first / last wave end
     const unsigned long long rt_end = __builtin_amdgcn_s_memrealtime();
-    atomicMin(&A.counters->dbg[8], rt_begin); atomicMax(&A.counters->dbg[9], rt_begin);
-    atomicMin(&A.counters->dbg[10], rt_last_item); atomicMax(&A.counters->dbg[11], rt_last_item);
-    atomicMin(&A.counters->dbg[12], rt_end); atomicMax(&A.counters->dbg[13], rt_end);
-    atomicAdd(&A.counters->dbg[14], (unsigned long long)T.cnt.bih);                        // C++ steps of all walks
-    atomicMax(&A.counters->dbg[15], (worst << 20) | (unsigned long long)worst_steps);     // the longest item (10 ns units) and its C++ steps
+    atomicMin(&A_.counters->dbg[8], rt_begin); atomicMax(&A_.counters->dbg[9], rt_begin);
+    atomicMin(&A_.counters->dbg[10], rt_last_item); atomicMax(&A_.counters->dbg[11], rt_last_item);
+    atomicMin(&A_.counters->dbg[12], rt_end); atomicMax(&A_.counters->dbg[13], rt_end);
+    atomicAdd(&A_.counters->dbg[14], (unsigned long long)Tk.cnt.bih);                        // C++ steps of all walks
+    atomicMax(&A_.counters->dbg[15], (worst << 20) | (unsigned long long)worst_steps);     // the longest item (10 ns units) and its C++ steps
   }
-  if (lane == 0 && !(A.debug_flags & 8)) Q.leave(A);
+  if (!(A_.debug_flags & 8)) Q.leave(A_);
 #else
-  if (lane == 0) Q.leave(A);
+  Q.leave(A_);
 #endif
 }
 

@@ -119,7 +119,15 @@ GD uint32_t tex_head(TexStack s, int B) { return (uint32_t)(s & ((1ull << B) - 1
 
 struct Cnt {  // per-lane work counters (only live when COUNT)
   uint32_t bih = 0, mesh = 0, prim = 0, shadow = 0, secondary = 0, primary = 0;
+  uint32_t w_primary = 0, w_shadow = 0;  // rays counted once per WAVE where the wave acts together (scalar registers: a per-lane counter is a vector register
+                                         // alive through the whole kernel); flush_counters adds both kinds
 };
+// `p` rays of a wave-wide step: one scalar add on the device (the host build's "wave" is one lane: its per-lane counter)
+#if defined(__HIP_DEVICE_COMPILE__)
+GD void count_wave(uint32_t&, uint32_t& per_wave, bool p) { per_wave += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(p)); }
+#else
+GD void count_wave(uint32_t& per_lane, uint32_t&, bool p) { if (p) per_lane++; }
+#endif
 
 // 1 / (a ray direction component), the ONE way everywhere a slab or a split plane is clipped: a box that ends on a BIH split
 // plane (or on its tree's bounds) must leave at bit-identical distances on both paths -- box_shadow's `far > d` (Box.hs:56-62)
@@ -399,10 +407,13 @@ GD int wave_count(bool pred) { return __popcll(__ballot(pred)); }
 // kFlatStack is traversed correctly.
 #if defined(__HIPCC__)
 struct LaneStack {
-  uint32_t* node; float* nearv; float* farv;  // pointers to this lane's column (stride 64)
-  int cap;                                   // entries held in LDS
-  uint32_t* ovf;                             // this lane's overflow column in global memory (3 words per entry), or null
-  int ovf_cap;                               // entries available there
+  // Everything here is WAVE-UNIFORM (scalar registers); a lane's column -- base + lane -- is formed where it is used.  (Until round 3
+  // the struct held five per-lane pointers: ten vector registers alive through the whole kernel for the sake of the rare C++ steps,
+  // in a kernel whose register budget the hand-written walk already strains -- DESIGN.md 4.1c.)
+  uint32_t* lds;   // the wave's LDS rows: [reference row][near row][far row], cap * 64 words each (no reference row when !has_ref_row)
+  uint32_t* ovfb;  // the wave's overflow block in global memory -- ovf_cap entries of [3][64] words, then the dump block [3][64] -- or null
+  int cap;         // entries held in LDS
+  int ovf_cap;     // entries available in the overflow block
   static constexpr int STRIDE = 64;
   GD int total_cap() const { return cap + ovf_cap; }
   // Packet entries (bih_tri_wave): the node reference and the mask of lanes that want the entry are wave-uniform.
@@ -411,19 +422,27 @@ struct LaneStack {
   //   register": a vector register whose inactive lanes matter is not something the compiler knows about -- a spill or a
   //   copy it places under a partial EXEC mask (a divergent triangle test, say) silently drops those lanes.
   //   bih_walk_asm (hand-written) does hold entry k in lane k of three registers, but only inside its one asm block;
-  //   when it hands a step back to C++ it writes them to `dump` (one word per lane and register, global memory) and
+  //   when it hands a step back to C++ it writes them to the dump block (one word per lane and register, global memory) and
   //   reads them back on re-entry, so no C++ variable ever carries them.  push_dump / pop_dump are the C++ steps' view.
   bool has_ref_row;  // false in kernels with two LDS rows per entry (lane_stack<true>): only bih_walk_asm runs there
-  uint32_t* dump;    // this lane's column of the dump block: [3][64] words per wave
   unsigned long long* dbg = nullptr;  // DCounters::dbg in the render kernels (read by the GLOME_PKW_STAMPS measurement build only)
+  // the lane's number, computed afresh at every use (volatile: neither hoisted nor kept in a register across the walk)
+  GD static uint32_t lane() { uint32_t l; asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l)); return l; }
+  GD uint32_t* node_col() const { return lds + lane(); }
+  GD float* near_col() const { return (float*)(lds + (has_ref_row ? cap * STRIDE : 0)) + lane(); }
+  GD float* far_col() const { return (float*)(lds + (has_ref_row ? 2 : 1) * cap * STRIDE) + lane(); }
+  GD uint32_t* ovf_col() const { return ovfb + lane(); }
+  GD uint32_t* dump_base() const { return ovfb ? ovfb + (size_t)ovf_cap * 3 * STRIDE : nullptr; }  // uniform; lane l's three words: [l], [64 + l], [128 + l]
+  GD uint32_t* dump_col() const { return dump_base() + lane(); }
+  GD uint32_t lds_near_row() const { return (uint32_t)(uintptr_t)near_col(); }  // this lane's LDS byte address in the near row (bih_walk_asm)
   GD void push2(int sp, float a, float b) {
-    if (__builtin_expect(sp < cap, 1)) { nearv[sp * STRIDE] = a; farv[sp * STRIDE] = b; }
-    else { uint32_t* o = ovf + (size_t)(sp - cap) * 3 * STRIDE; __builtin_nontemporal_store(as_u(a), o + STRIDE); __builtin_nontemporal_store(as_u(b), o + 2 * STRIDE); }
+    if (__builtin_expect(sp < cap, 1)) { near_col()[sp * STRIDE] = a; far_col()[sp * STRIDE] = b; }
+    else { uint32_t* o = ovf_col() + (size_t)(sp - cap) * 3 * STRIDE; __builtin_nontemporal_store(as_u(a), o + STRIDE); __builtin_nontemporal_store(as_u(b), o + 2 * STRIDE); }
   }
   GD void pop2(int sp, float& a, float& b) const {
-    if (__builtin_expect(sp < cap, 1)) { a = nearv[sp * STRIDE]; b = farv[sp * STRIDE]; }
+    if (__builtin_expect(sp < cap, 1)) { a = near_col()[sp * STRIDE]; b = far_col()[sp * STRIDE]; }
     else {
-      const uint32_t* o = ovf + (size_t)(sp - cap) * 3 * STRIDE;
+      const uint32_t* o = ovf_col() + (size_t)(sp - cap) * 3 * STRIDE;
       a = as_f(__builtin_nontemporal_load(o + STRIDE)); b = as_f(__builtin_nontemporal_load(o + 2 * STRIDE));
       asm volatile("" : "+v"(a), "+v"(b));
     }
@@ -437,12 +456,13 @@ struct LaneStack {
   }
   // entry `sp` of bih_walk_asm's stack, as it lies in the dump block: lane sp's three words
   GD void push_dump(int sp, uint32_t ref, LaneMask m, float a, float b) {
-    if ((int)(threadIdx.x & 63) == sp) { dump[0] = ref; dump[STRIDE] = (uint32_t)m; dump[2 * STRIDE] = (uint32_t)(m >> 32); }
+    if ((int)lane() == sp) { uint32_t* d = dump_col(); d[0] = ref; d[STRIDE] = (uint32_t)m; d[2 * STRIDE] = (uint32_t)(m >> 32); }
     push2(sp, a, b);
   }
   GD void pop_dump(int sp, uint32_t& ref, LaneMask& m, float& a, float& b) const {
     pop2(sp, a, b);
-    const uint32_t w0 = dump[0], w1 = dump[STRIDE], w2 = dump[2 * STRIDE];
+    const uint32_t* d = dump_col();
+    const uint32_t w0 = d[0], w1 = d[STRIDE], w2 = d[2 * STRIDE];
     ref = (uint32_t)__builtin_amdgcn_readlane((int)w0, sp);
     m = (LaneMask)(uint32_t)__builtin_amdgcn_readlane((int)w1, sp) | ((LaneMask)(uint32_t)__builtin_amdgcn_readlane((int)w2, sp) << 32);
   }
@@ -450,16 +470,16 @@ struct LaneStack {
   // without it the compiler sinks both branches' loads into one access through a generic (flat) pointer, and every
   // pop becomes three flat loads that wait on the LDS and the vector-memory counters.
   GD void push(int sp, uint32_t n, float a, float b) {
-    if (__builtin_expect(sp < cap, 1)) { node[sp * STRIDE] = n; nearv[sp * STRIDE] = a; farv[sp * STRIDE] = b; }
+    if (__builtin_expect(sp < cap, 1)) { node_col()[sp * STRIDE] = n; near_col()[sp * STRIDE] = a; far_col()[sp * STRIDE] = b; }
     else {
-      uint32_t* o = ovf + (size_t)(sp - cap) * 3 * STRIDE;
+      uint32_t* o = ovf_col() + (size_t)(sp - cap) * 3 * STRIDE;
       __builtin_nontemporal_store(n, o); __builtin_nontemporal_store(as_u(a), o + STRIDE); __builtin_nontemporal_store(as_u(b), o + 2 * STRIDE);
     }
   }
   GD void pop(int sp, uint32_t& n, float& a, float& b) const {
-    if (__builtin_expect(sp < cap, 1)) { n = node[sp * STRIDE]; a = nearv[sp * STRIDE]; b = farv[sp * STRIDE]; }
+    if (__builtin_expect(sp < cap, 1)) { n = node_col()[sp * STRIDE]; a = near_col()[sp * STRIDE]; b = far_col()[sp * STRIDE]; }
     else {
-      const uint32_t* o = ovf + (size_t)(sp - cap) * 3 * STRIDE;
+      const uint32_t* o = ovf_col() + (size_t)(sp - cap) * 3 * STRIDE;
       n = __builtin_nontemporal_load(o); a = as_f(__builtin_nontemporal_load(o + STRIDE)); b = as_f(__builtin_nontemporal_load(o + 2 * STRIDE));
       asm volatile("" : "+v"(n), "+v"(a), "+v"(b));
     }
@@ -761,10 +781,10 @@ GD PacketResult bih_tri_packet_hw(const F4* nodes, uint32_t nbytes, const float*
   PacketResult R; R.best_t = best_t; R.best_rec = kNoRec; R.n_bih = 0; R.n_prim = 0;
   int sp = 0, phase = 0;
   LaneMask occm = 0;
-  const uint32_t lds_row = (uint32_t)(uintptr_t)stk.nearv;
+  const uint32_t lds_row = stk.lds_near_row();
   for (;;) {
     int st;
-#define GLOME_WALK(XF, YF, ZF) st = bih_walk_asm<MODE, XF, YF, ZF, CAP>(nodes, nbytes, pairs, phase, ref, am, sp, nearv, farv, R.best_t, R.best_rec, occm, r.o, rcp, r.d, lds_row, stk.dump)
+#define GLOME_WALK(XF, YF, ZF) st = bih_walk_asm<MODE, XF, YF, ZF, CAP>(nodes, nbytes, pairs, phase, ref, am, sp, nearv, farv, R.best_t, R.best_rec, occm, r.o, rcp, r.d, lds_row, stk.dump_base())
     switch (fwdbits) {  // wave-uniform: one scalar jump per walk
       case 7: GLOME_WALK(true, true, true); break;
       case 6: GLOME_WALK(false, true, true); break;
@@ -868,7 +888,7 @@ GD bool bih_tri_wave(const DScene& S, uint32_t hdr, const Ray& r, float d, bool 
       // tier's kernels (one wave per workgroup, wave-uniform callers); the generic tier's packet service calls from inside a loop whose
       // lanes diverge and carries a stack without one (generic_packet_stack) -- checked here, at run time, rather than trusted to the
       // caller's template arguments: anything else takes the C++ packet walk below.
-      if (stk.cap == kAsmLdsCap && has_pk && stk.dump != nullptr && __builtin_amdgcn_read_exec() == ~0ull) { R = bih_tri_packet_hw<MODE>(S.pknodes, S.pknodes_bytes, S.tripairs, pkroot, delta, fwdbits, am, nearv, farv, r.o, r.d, rcp, best_t, stk); walked = true; }
+      if (stk.cap == kAsmLdsCap && has_pk && stk.dump_base() != nullptr && __builtin_amdgcn_read_exec() == ~0ull) { R = bih_tri_packet_hw<MODE>(S.pknodes, S.pknodes_bytes, S.tripairs, pkroot, delta, fwdbits, am, nearv, farv, r.o, r.d, rcp, best_t, stk); walked = true; }
     }
 #endif
     if (!walked) {
@@ -1581,7 +1601,7 @@ GD uint32_t preshade_wave(TIER& T, const HitCore& h, bool want) {
     V3 ldir = lvec * (1.0f / llen);
     bool lit = want && !(vdot(lvec, h.n) < 0) && !(llen > L.rad);
     if (L.shadow) {
-      if (lit) T.cnt.shadow++;
+      count_wave(T.cnt.shadow, T.cnt.w_shadow, lit);
       Ray sr; sr.o = vscaleadd(h.p, h.n, kDel); sr.d = ldir;
       bool occ = T.occluded_wave(sr, llen - (2 * kDel), lit);
       lit = lit && !occ;
