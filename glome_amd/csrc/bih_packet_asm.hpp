@@ -56,7 +56,9 @@
 // EXEC must be all ones at entry (every caller is wave-uniform: one wave per workgroup, 64 threads): the dump block's loads
 // and stores and lane k's stack entry rely on it; the block forces it around the dump traffic and restores the entry mask.
 // Scalar registers K0..K39 and vector registers T0..T15 (tables below), vcc, scc and m0 (saved and restored) are scratch,
-// named in the clobber list.  No scalar load is in flight when the block ends.
+// named in the clobber list.  No scalar load is in flight when the block ends.  `status` is an EARLY-CLOBBER output: the block writes
+// it before its last reads of the scalar inputs (the dump block's base, since round 4 a scalar pair), and without the `&` the compiler
+// may give it an input's register -- it did: the dump stores of a step handed to C++ went to (base & ~0xffffffff) | status.
 #pragma once
 #if defined(__HIPCC__)
 
@@ -655,7 +657,7 @@ constexpr uint32_t PKREF_LEAF = 3u;  // low bits of a reference in the walk's ow
       "  s_mov_b32 %[sp], m0\n"                                                                                                 \
       "  s_mov_b32 m0, s" K32 "\n"                                                                                              \
       : [ref] "+s"(ref), [am] "+s"(am), [sp] "+s"(sp), [near] "+v"(nearv), [far] "+v"(farv), [best_t] "+v"(best_t), [best_rec] "+v"(best_rec), [ur] "=&v"(ur),    \
-        [ulo] "=&v"(ulo), [uhi] "=&v"(uhi), [occ] "+s"(occm), [status] "=s"(status)                                                                                  \
+        [ulo] "=&v"(ulo), [uhi] "=&v"(uhi), [occ] "+s"(occm), [status] "=&s"(status)                                                                                  \
       : [nodes_lo] "s"(nodes_lo), [nodes_hi] "s"(nodes_hi), [nbytes] "s"(nbytes), [pairs] "s"(pairs), [cap] "n"(CAP), [phase] "s"(phase), [P0] "v"(P0), [P1] "v"(P1),  \
         [P2] "v"(P2), [R0] "v"(R0), [R1] "v"(R1), [lds] "v"(lds_row), [row1] "n"(CAP * 256), [dump] "s"(dump)                                                         \
       : "s" K0, "s" K1, "s" K2, "s" K3, "s" K4, "s" K5, "s" K6, "s" K7, "s" K8, "s" K9, "s" K10, "s" K11, "s" K12, "s" K13, "s" K14, "s" K15, "s" K16, "s" K17, "s" K18, \

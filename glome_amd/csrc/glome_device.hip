@@ -293,8 +293,14 @@ __device__ __forceinline__ void render_loop(const DRenderArgs& A_, TIER& Tk) {
   uint32_t worst_steps = 0, steps_before = 0;
 #endif
   for (;;) {
+#if !defined(GLOME_RB_NO_OPAQUE)
     asm volatile("" : "+s"(ap_));
+#endif
+#if defined(GLOME_RB_NO_KERNARG)
+    const DRenderArgs& A = A_;
+#else
     const DRenderArgs& A = *(const DRenderArgs*)ap_;
+#endif
     TIER T = Tk.rebound(A);
     uint32_t w = kNoTicket;
 #ifdef GLOME_PROBE
@@ -304,6 +310,9 @@ __device__ __forceinline__ void render_loop(const DRenderArgs& A_, TIER& Tk) {
       w = Q.take(A);
       if (A.debug_flags & 16) { ts0 = __builtin_amdgcn_s_memtime(); t_take += ts0 - t0; n_take++; }
     }
+#elif defined(GLOME_RB_OLD_TAKE)
+    if (LaneStack::lane() == 0) w = Q.take(A);
+    w = __shfl(w, 0, 64);
 #else
     w = Q.take(A);  // a SCALAR: the frame, the tile and the camera the ticket names are then scalar loads, not a lane's
 #endif
@@ -355,7 +364,9 @@ __device__ __forceinline__ void render_loop(const DRenderArgs& A_, TIER& Tk) {
 #endif
     if (!valid) continue;
     // the pixel once more (rather than three registers carried, spilled, through both walks): the item is a scalar, the lane a v_mbcnt
+#if !defined(GLOME_RB_NO_REPIXEL)
     if (!GLOME_PROBE_FLAG(A, 4)) { px = 0; py = 0; dense_off = 0; (void)work_to_pixel(A, w, (int)LaneStack::lane(), px, py, dense_off); }
+#endif
     float depth = h.hit ? h.t : kInf;      // ridepth
     float r = c.r;
     if (A.fog) r = r + (depth / 400);      // renderTile's debug fog (Glome.hs:174, Q20)

@@ -123,7 +123,7 @@ struct Cnt {  // per-lane work counters (only live when COUNT)
                                          // alive through the whole kernel); flush_counters adds both kinds
 };
 // `p` rays of a wave-wide step: one scalar add on the device (the host build's "wave" is one lane: its per-lane counter)
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GLOME_RB_OLD_COUNT)
 GD void count_wave(uint32_t&, uint32_t& per_wave, bool p) { per_wave += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(p)); }
 #else
 GD void count_wave(uint32_t& per_lane, uint32_t&, bool p) { if (p) per_lane++; }

@@ -174,7 +174,9 @@ class ShardedFrame:
         import torch
         self.torch = torch
         self.direct = False
-        want_direct = (world > 1 and product == "packed" and params.mode == 0) if direct is None else bool(direct)
+        import torch.distributed as _td
+        # (by default only inside a process group: a caller that plays several ranks in one process -- tests, rehearsals -- has none)
+        want_direct = (world > 1 and product == "packed" and params.mode == 0 and _td.is_available() and _td.is_initialized()) if direct is None else bool(direct)
         if want_direct and world > 1 and product == "packed" and params.mode == 0:
             rank0_share_pct = 0 if rank0_share_pct is None else rank0_share_pct
         # rank 0 also receives and blits every frame: it owns less than a fair share of the tiles (glome_render_params.rank0_share_pct;
