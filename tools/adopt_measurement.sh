@@ -16,6 +16,7 @@ cp gpurun_out/$tag/bench_S3_driver.json profiles/${tag}_bench_S3_driver_invocati
 cp gpurun_out/$tag/bench_S3_kernel_stats.csv profiles/${tag}_bench_S3_kernel_stats.csv
 mkdir -p profiles/${tag}_configs && cp gpurun_out/$tag/configs/*.json profiles/${tag}_configs/
 grep -v amdgpu.ids gpurun_out/$tag/shard_timing.log > profiles/${tag}_shard_timing.log
+grep -v amdgpu.ids gpurun_out/$tag/shard_timing_direct.log > profiles/${tag}_shard_timing_direct.log
 cp gpurun_out/$tag/short_run_sweep.log profiles/${round}_short_run_sweep.log
 if [ -n "$prev" ]; then rm -rf profiles/${prev}_configs profiles/${prev}_bench_S3.json profiles/${prev}_bench_S3_driver_invocation.json profiles/${prev}_bench_S3_kernel_stats.csv profiles/${prev}_shard_timing.log; fi
 python3 - <<'PY'
@@ -23,6 +24,6 @@ import glob, json, sys
 sys.path.insert(0, "tools")
 from pmc_roofline import source_sha16
 h = source_sha16(".")
-for f in sorted(glob.glob("profiles/r03_pmc_*.json")):
+for f in sorted(glob.glob("profiles/r04_pmc_*.json")):
     j = json.load(open(f)); print(f, j["clock_ghz"], "hash ok" if j["source_sha16"] == h else "STALE")
 PY
