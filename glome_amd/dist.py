@@ -236,24 +236,30 @@ class ShardedFrame:
         nbytes = int(np.prod(shape)) * 4
         ok, self._ipc_ptrs, handles = 1, [], []
         if self.rank == 0:
-            for _ in range(self.n):
-                p, h = C.c_void_p(), C.create_string_buffer(64)
-                if self.lib.glome_ipc_alloc(self.ctx.h, nbytes, C.byref(p), h) != 0:
-                    ok = 0
-                    break
-                self._ipc_ptrs.append(p.value); handles.append(h.raw)
+            try:
+                for _ in range(self.n):
+                    p, h = C.c_void_p(), C.create_string_buffer(64)
+                    if self.lib.glome_ipc_alloc(self.ctx.h, nbytes, C.byref(p), h) != 0:
+                        ok = 0
+                        break
+                    self._ipc_ptrs.append(p.value); handles.append(h.raw)
+            except Exception:  # (whatever goes wrong here, every rank must still reach the collectives below)
+                ok = 0
         box = [handles if ok else None]
         dist.broadcast_object_list(box, src=0, **({"device": self.device} if dist.get_backend() != "gloo" else {}))
         if self.rank != 0:
             if box[0] is None:
                 ok = 0
             else:
-                for h in box[0]:
-                    p = C.c_void_p()
-                    if self.lib.glome_ipc_open(self.ctx.h, h, C.byref(p)) != 0:
-                        ok = 0
-                        break
-                    self._ipc_ptrs.append(p.value)
+                try:
+                    for h in box[0]:
+                        p = C.c_void_p()
+                        if self.lib.glome_ipc_open(self.ctx.h, h, C.byref(p)) != 0:
+                            ok = 0
+                            break
+                        self._ipc_ptrs.append(p.value)
+                except Exception:
+                    ok = 0
         flag = torch.tensor([ok], dtype=torch.int32, device=self.device if dist.get_backend() != "gloo" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) != 1:
