@@ -273,7 +273,12 @@ struct TicketQueue {
 #else
 #define GLOME_PROBE_FLAG(A, bit) false
 #endif
-template <class TIER>
+// LEAN (the flagship instance: every step the hand-written walk's, six waves per SIMD, 80 vector registers): the three measures of
+// DESIGN.md 4.1c that take registers out of the walks' way -- arguments re-read per item through an opaque pointer, the ticket taken as
+// a scalar, the pixel made a second time after the trace.  They are worth 8-10 % there and COST the other instances, whose C++ walks
+// then re-read table pointers inside their loops: the 1M-triangle Mesh 0.797 -> 0.872 ms with all three, 0.84 with any one of them off
+// (profiles/r04_probes/mesh_regress_ab.txt); so the other flat-tier instances keep round 3's loop.
+template <bool LEAN, class TIER>
 __device__ __forceinline__ void render_loop(const DRenderArgs& A_, TIER& Tk) {
 #ifdef GLOME_PROBE
   int lane = threadIdx.x & 63;
@@ -293,14 +298,8 @@ __device__ __forceinline__ void render_loop(const DRenderArgs& A_, TIER& Tk) {
   uint32_t worst_steps = 0, steps_before = 0;
 #endif
   for (;;) {
-#if !defined(GLOME_RB_NO_OPAQUE)
-    asm volatile("" : "+s"(ap_));
-#endif
-#if defined(GLOME_RB_NO_KERNARG)
-    const DRenderArgs& A = A_;
-#else
-    const DRenderArgs& A = *(const DRenderArgs*)ap_;
-#endif
+    if constexpr (LEAN) asm volatile("" : "+s"(ap_));
+    const DRenderArgs& A = LEAN ? *(const DRenderArgs*)ap_ : A_;
     TIER T = Tk.rebound(A);
     uint32_t w = kNoTicket;
 #ifdef GLOME_PROBE
@@ -310,11 +309,9 @@ __device__ __forceinline__ void render_loop(const DRenderArgs& A_, TIER& Tk) {
       w = Q.take(A);
       if (A.debug_flags & 16) { ts0 = __builtin_amdgcn_s_memtime(); t_take += ts0 - t0; n_take++; }
     }
-#elif defined(GLOME_RB_OLD_TAKE)
-    if (LaneStack::lane() == 0) w = Q.take(A);
-    w = __shfl(w, 0, 64);
 #else
-    w = Q.take(A);  // a SCALAR: the frame, the tile and the camera the ticket names are then scalar loads, not a lane's
+    if constexpr (LEAN) w = Q.take(A);  // a SCALAR: the frame, the tile and the camera the ticket names are then scalar loads, not a lane's
+    else { if (LaneStack::lane() == 0) w = Q.take(A); w = __shfl(w, 0, 64); }
 #endif
     if (w == kNoTicket) break;
 #ifdef GLOME_PROBE
@@ -364,9 +361,7 @@ __device__ __forceinline__ void render_loop(const DRenderArgs& A_, TIER& Tk) {
 #endif
     if (!valid) continue;
     // the pixel once more (rather than three registers carried, spilled, through both walks): the item is a scalar, the lane a v_mbcnt
-#if !defined(GLOME_RB_NO_REPIXEL)
-    if (!GLOME_PROBE_FLAG(A, 4)) { px = 0; py = 0; dense_off = 0; (void)work_to_pixel(A, w, (int)LaneStack::lane(), px, py, dense_off); }
-#endif
+    if constexpr (LEAN) { if (!GLOME_PROBE_FLAG(A, 4)) { px = 0; py = 0; dense_off = 0; (void)work_to_pixel(A, w, (int)LaneStack::lane(), px, py, dense_off); } }
     float depth = h.hit ? h.t : kInf;      // ridepth
     float r = c.r;
     if (A.fog) r = r + (depth / 400);      // renderTile's debug fog (Glome.hs:174, Q20)
@@ -410,7 +405,7 @@ __global__ void __launch_bounds__(64, LB) k_render_flat(DRenderArgs A, int stack
   extern __shared__ uint32_t lds[];
   FlatTier<FAITHFUL, COUNT, FULL, CLS> T{A.S, A.lights, A.nlights, lane_stack<TWO_ROWS>(lds, stack_cap, ovf, ovf_cap), Cnt()};
   T.stk.dbg = A.counters->dbg;
-  render_loop(A, T);
+  render_loop<TWO_ROWS>(A, T);
   if (A.want_counters) flush_counters(A.counters, T.cnt, T.err);
   else if ((CLS & (CLS_CSG | CLS_MESH)) && __builtin_amdgcn_ballot_w64(T.err != 0) && (threadIdx.x & 63) == 0) atomicOr(&A.counters->error, 1u);
 }
@@ -425,7 +420,7 @@ __global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_render_generic(DRender
   // registers), and with refilling the lanes fall out of step, every closest-hit call then runs for a part of the wave, and the frame took 5.8 ms
   // against 4.3: what keeps the lanes idle -- 28 % of the vector lane slots are used -- is the interpreter's own divergence
   // inside a call, not pixels of unequal cost.)
-  render_loop(A, T);
+  render_loop<true>(A, T);  // (the interpreter, short of registers like the flagship, measures better with the lean loop: TS 2.70 against 2.74 ms)
   if (A.want_counters) flush_counters(A.counters, T.cnt, T.err);
   else if (__builtin_amdgcn_ballot_w64(T.err != 0) && (threadIdx.x & 63) == 0) atomicOr(&A.counters->error, 1u);
 }

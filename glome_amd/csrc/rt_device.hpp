@@ -485,7 +485,49 @@ struct LaneStack {
     }
   }
 };
+// A LaneStack with this lane's columns formed ONCE: what the Mesh walks, which push and pop at every step, work on.  LaneStack itself
+// forms a column at each use, which is right for the kernel whose steps are the hand-written walk's and costs these 2.5 % (the
+// 1M-triangle Mesh 0.898 -> 0.873 ms).  The columns live in vector registers only while such a walk runs.  (The BIH walks
+// keep the plain LaneStack: in the per-lane ones the hoist moved the flagship kernel's register allocation -- 8 -> 13 spilled vector
+// registers -- for walks that kernel never runs; in the C++ packet walk it measured neutral on the sphere scenes and +0.7 % on the
+// interpreter's service: profiles/r04_probes/stack_cols_ab.txt.)
+struct LaneStackCols {
+  uint32_t* node; float* nearc; float* farc; uint32_t* ovf; int cap, ovf_cap;
+  static constexpr int STRIDE = LaneStack::STRIDE;
+  GD explicit LaneStackCols(const LaneStack& s) : cap(s.cap), ovf_cap(s.ovf_cap) {
+    const uint32_t l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    node = s.lds + l; nearc = (float*)(s.lds + (s.has_ref_row ? s.cap * STRIDE : 0)) + l; farc = (float*)(s.lds + (s.has_ref_row ? 2 : 1) * s.cap * STRIDE) + l;
+    ovf = s.ovfb + l;
+  }
+  GD int total_cap() const { return cap + ovf_cap; }
+  GD void push(int sp, uint32_t n, float a, float b) {
+    if (__builtin_expect(sp < cap, 1)) { node[sp * STRIDE] = n; nearc[sp * STRIDE] = a; farc[sp * STRIDE] = b; }
+    else {
+      uint32_t* o = ovf + (size_t)(sp - cap) * 3 * STRIDE;
+      __builtin_nontemporal_store(n, o); __builtin_nontemporal_store(as_u(a), o + STRIDE); __builtin_nontemporal_store(as_u(b), o + 2 * STRIDE);
+    }
+  }
+  GD void pop(int sp, uint32_t& n, float& a, float& b) const {
+    if (__builtin_expect(sp < cap, 1)) { n = node[sp * STRIDE]; a = nearc[sp * STRIDE]; b = farc[sp * STRIDE]; }
+    else {
+      const uint32_t* o = ovf + (size_t)(sp - cap) * 3 * STRIDE;
+      n = __builtin_nontemporal_load(o); a = as_f(__builtin_nontemporal_load(o + STRIDE)); b = as_f(__builtin_nontemporal_load(o + 2 * STRIDE));
+      asm volatile("" : "+v"(n), "+v"(a), "+v"(b));  // (as in LaneStack::pop: keeps the overflow loads inside their branch)
+    }
+  }
+  GD void push_wave(int sp, uint32_t ref, LaneMask m, float a, float b) { push(sp, ref | (lane_of(m) ? 0x80000000u : 0u), a, b); }
+  GD void pop_wave(int sp, uint32_t& ref, LaneMask& m, float& a, float& b) const {
+    uint32_t w;
+    pop(sp, w, a, b);
+    ref = uni(w & 0x7fffffffu);
+    m = wave_ballot((w >> 31) != 0);
+  }
+};
+#if !defined(GLOME_NO_STACK_COLS)  // (A/B build: the walks on the plain LaneStack, as in round 4's first measurement set)
+GD LaneStackCols stack_cols(LaneStack& s) { return LaneStackCols(s); }
 #endif
+#endif
+template <class STK> GD STK& stack_cols(STK& s) { return s; }  // every other stack already is its own columns
 // Generic tier: a fixed private array (scratch).
 struct PrivStack {
   uint32_t node[kGenericStack]; float nearv[kGenericStack]; float farv[kGenericStack];
@@ -916,7 +958,8 @@ GD bool bih_tri_wave(const DScene& S, uint32_t hdr, const Ray& r, float d, bool 
 // Leaves use the box interval `far` as tmax, not `depth` -- as written in the reference (Mesh.hs:163, 198).
 constexpr uint32_t MREF_LEAF = 0x80000000u;
 template <bool COUNT, class STK>
-GD void mesh_closest(const DScene& S, uint32_t mh, const Ray& ray, float depth, STK& stk, int stack_cap, Cnt& cnt, float& best_t, uint32_t& best_tri) {
+GD void mesh_closest(const DScene& S, uint32_t mh, const Ray& ray, float depth, STK& stk_, int stack_cap, Cnt& cnt, float& best_t, uint32_t& best_tri) {
+  auto&& stk = stack_cols(stk_);
   F4 h0 = ld4(S.meshhdr, 2 * mh), h1 = ld4(S.meshhdr, 2 * mh + 1);
   V3 rcp = v3(dir_rcp(ray.d.x), dir_rcp(ray.d.y), dir_rcp(ray.d.z));
   float nearv, farv;
@@ -981,7 +1024,8 @@ GD void mesh_closest(const DScene& S, uint32_t mh, const Ray& ray, float depth, 
 // is not in the entry stores an empty interval, and the pop's re-test against the best hit so far (Mesh.hs:190) is what tells
 // the lanes in from the lanes out.  Hits, ties and ray counts are the per-lane walk's; node visit counts are not kept.
 template <class STK>
-GD void mesh_closest_wave(const DScene& S, uint32_t mh, const Ray& ray, float depth, bool valid, STK& stk, float& best_t, uint32_t& best_tri, unsigned int* err) {
+GD void mesh_closest_wave(const DScene& S, uint32_t mh, const Ray& ray, float depth, bool valid, STK& stk_, float& best_t, uint32_t& best_tri, unsigned int* err) {
+  auto&& stk = stack_cols(stk_);
   mh = uni(mh);
   const F4 h0 = ld4u(S.meshhdr, 2 * mh), h1 = ld4u(S.meshhdr, 2 * mh + 1);
   const V3 rcp = v3(dir_rcp(ray.d.x), dir_rcp(ray.d.y), dir_rcp(ray.d.z));
