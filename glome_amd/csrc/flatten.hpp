@@ -22,7 +22,7 @@ struct FlatScene {
   uint32_t root_rec = 0;
   uint32_t tier = 1;
   int nesting_depth = 0, max_bih_depth = 0, max_mesh_depth = 0;
-  int max_sphere_bih_depth = 0;  // deepest BIH whose items are all plain spheres or all plain triangles (0: none)
+  int max_sphere_bih_depth = 0;  // deepest BIH the interpreter's packet service can walk: items all plain spheres, all plain triangles, or all answered in place (0: none)
   uint32_t tex_bits = 16;   // bits per id of a TexStack (rt_types.h): 8 when the scene has at most 254 materials
   int64_t n_other_prims = 0;
   std::string why_generic;  // why the flat tier was not chosen
@@ -415,6 +415,20 @@ class Flattener {
   }
   uint32_t slot(const U4& v) { F.recs.push_back(v); return (uint32_t)F.recs.size() - 1; }
 
+  // An item the interpreter answers in place whatever the ray (rt_generic.hpp: vm_resolve_r / _s return 0 or 1, or vm_inst_prim_hit /
+  // vm_inst_prim_shadow take it): a primitive, or an Instance of a primitive or of a list of primitives, under Tex wrappers on either
+  // side.  A BIH made of such items alone is walked as a packet by the interpreter's service (bih_items_wave).
+  bool item_in_place(U4 c) const {
+    while ((c.x & RF_KINDMASK) == R_TEX) c = F.recs[c.y];
+    uint32_t k = c.x & RF_KINDMASK;
+    if (k >= R_SPHERE && k <= R_CONE) return true;
+    if (k != R_INSTANCE) return false;
+    c = F.recs[c.y];
+    while ((c.x & RF_KINDMASK) == R_TEX) c = F.recs[c.y];
+    k = c.x & RF_KINDMASK;
+    return (k >= R_SPHERE && k <= R_CONE) || (k == R_LIST && (c.x & RF_PRIMLIST) != 0);
+  }
+
   // BIH: nodes in preorder; leaf items become consecutive records, and (for homogeneous leaves) consecutive pool
   // entries, so a leaf is one contiguous run of 48-byte triangles / 16-byte spheres.
   U4 emit_bih(const Node& n) {
@@ -477,6 +491,7 @@ class Flattener {
     std::vector<uint32_t> pkleaf(T.nodes.size(), 3u);  // a leaf as the packet walk refers to it: byte offset of its first pair record | 3
     uint32_t delta = 0;
     bool have_delta = false;
+    bool in_place = cls != BC_TRI && cls != BC_SPHERE;  // (those two have their own packet walk)
     for (size_t k = 0; k < T.nodes.size(); k++) {
       const BihTree::Node& bn = T.nodes[k];
       if (!bn.leaf) { ref[k] = base + slot[k]; continue; }
@@ -492,6 +507,7 @@ class Flattener {
           rec.x |= p.flags; rec.z = p.own;
         }
         if (q == 0) first_prim = rec.y;
+        in_place = in_place && item_in_place(rec);
         items.push_back(rec);
       }
       uint32_t first_rec = (uint32_t)F.recs.size();
@@ -537,9 +553,12 @@ class Flattener {
     if (cls == BC_TRI) F.pk_all = F.pk_all && pk;
     // (y: the root in the packet walk's form, z: 1 when this tree has that form -- triangle leaves, byte offsets that fit a reference)
     const uint32_t pkroot = (pk && !T.nodes.empty() && !T.nodes[0].leaf) ? (((base + slot[0]) << 4) | (uint32_t)T.nodes[0].axis) : 0u;
-    // (w: the tree's depth -- the generic tier walks a sphere-class tree as a packet when its per-wave stack holds it)
-    F.bihhdr[3 * hdr + 2] = F4{as_float_bits(delta), as_float_bits(pkroot), as_float_bits(pk ? 1u : 0u), as_float_bits((uint32_t)T.depth)};
-    if (cls == BC_SPHERE || cls == BC_TRI) F.max_sphere_bih_depth = std::max(F.max_sphere_bih_depth, T.depth);
+    // (w: the tree's depth -- the generic tier walks a tree as a packet when its per-wave stack holds it -- and, in bit 31, whether
+    // every item is answered in place: kBihItemsInPlace)
+    in_place = in_place && !T.nodes.empty() && !T.nodes[0].leaf;
+    if (getenv("GLOME_DEBUG_NO_ITEM_PACKETS")) in_place = false;  // (A/B switch: such trees walked lane by lane over frames, as until round 4)
+    F.bihhdr[3 * hdr + 2] = F4{as_float_bits(delta), as_float_bits(pkroot), as_float_bits(pk ? 1u : 0u), as_float_bits((uint32_t)T.depth | (in_place ? kBihItemsInPlace : 0u))};
+    if (cls == BC_SPHERE || cls == BC_TRI || in_place) F.max_sphere_bih_depth = std::max(F.max_sphere_bih_depth, T.depth);
     return U4{R_BIH, hdr, 0, (uint32_t)n.uid};
   }
 

@@ -1195,8 +1195,9 @@ glome_scene* glome_scene_commit(glome_ctx* ctx, glome_sb* sb, int32_t root) {
   if (rc) { glome_scene_release(s); return nullptr; }
   D.n_entries = F.tier == 0 ? (uint32_t)F.entries.size() : 0;
   D.root_rec = F.root_rec; D.tier = F.tier; D.n_mats = (uint32_t)sb_graph(sb).mats.size(); D.tex_bits = F.tex_bits;
-  // the generic tier's kernels carry an LDS stack of up to kGenericPacketStack entries per lane for packet walks of sphere BIHs (15 KB
-  // a wave at 20: eight waves per CU fit); a deeper tree of spheres keeps the per-lane walk
+  // the generic tier's kernels carry an LDS stack of up to kGenericPacketStack entries per lane for the packet walks of its service
+  // (sphere / triangle trees, trees of items answered in place: 18 KB a wave at 24, eight waves per CU fit); a deeper tree keeps the
+  // per-lane walk
   D.pk_generic_cap = (F.tier != 0 && F.max_sphere_bih_depth > 0) ? (uint32_t)std::min(kGenericPacketStack, std::max(4, F.max_sphere_bih_depth)) : 0u;
   if (getenv("GLOME_DEBUG_NO_GENERIC_PACKETS")) D.pk_generic_cap = 0;  // (debug switch: every BIH inside the interpreter walked lane by lane -- the test that holds the packet service against it)
   glome_scene_info& I = s->info;

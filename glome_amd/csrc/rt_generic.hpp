@@ -196,6 +196,122 @@ template <bool C> GD int vm_inst_prim_shadow(const DScene& S, Cnt& cnt, U4 rec, 
   return prim_shadow(S, kind, c.y, r, d * lenscale) ? 2 : 1;
 }
 
+// ------------------------------------------------------------------ a BIH of items answered in place, walked by the wave as ONE packet
+// The oak of GlomeView's default scene is a bih of 2,047 Instances of cones and spheres; walked lane by lane over frames (ST_BIH /
+// ST_BIH_ITEM below) every lane stands on its own node and its own item, of its own kind.  Here the lanes that wait for the same tree
+// (vm_run's packet service) go down it together: node and item are the wave's, only the rays differ.  The walk is the per-lane
+// ordered walk's in mask form, decision for decision -- same plane arithmetic, same go / push rules, the best hit so far only decides
+// which nodes and leaves a lane still enters, an item sees the node's own `far` (a quadric's answer depends on it: rt_device.hpp
+// bih_traverse, CLAMP) or, a plain primitive that is not a quadric, min(far, best) exactly as ST_BIH_ITEM tests it -- so frames are
+// bit-identical with the service off (GLOME_DEBUG_NO_GENERIC_PACKETS; tests).  What comes back is WHICH item is nearest and the tmax
+// it was tested with; the caller evaluates that one item once more for the full hit.
+// MODE 1: rayint (Bih.hs:332-368, ordered).  MODE 2: shadow_bih (Bih.hs:510-544): true for a lane with an occluder.
+// All lanes of the wave call together; `valid`: the lane takes part.  The root is a branch and depth <= stk.total_cap() (callers).
+struct ItemPick { float t; uint32_t item; float tmax; };
+template <int MODE, bool C, class STK>
+GD bool bih_items_wave(const DScene& S, Cnt& cnt, uint32_t hdr, const Ray& r, float d, TexStack tex, bool valid, STK& stk, ItemPick& pick) {
+  hdr = uni(hdr);
+  const F4 h0 = ld4u(S.bihhdr, 3 * hdr), h1 = ld4u(S.bihhdr, 3 * hdr + 1);
+  const uint32_t root = uni(as_u(h0.w));
+  const V3 rcp = v3(dir_rcp(r.d.x), dir_rcp(r.d.y), dir_rcp(r.d.z));
+  float near0, far0;
+  bbclip_ub(r, v3(h0), v3(h1), near0, far0);
+  far0 = gminf(d, far0);  // `traverse root near (fmin d far)`, Bih.hs:368 / 515
+  pick.t = kInf * 4.0f; pick.item = CAND_NONE; pick.tmax = 0.0f;
+  const uint32_t oct = (rcp.x > 0 ? 1u : 0u) | (rcp.y > 0 ? 2u : 0u) | (rcp.z > 0 ? 4u : 0u);
+  if (C) { if (valid && near0 > far0) cnt.bih++; }  // the root taken up with an empty interval: counted and left
+  LaneMask todo = wave_ballot(valid && !(near0 > far0));
+  bool occ = false;
+  while (todo != 0) {  // one walk per sign pattern of the directions among the lanes (near child first is then the same child for all)
+    const uint32_t fwdbits = uni(first_lane_value(todo, oct));
+    LaneMask am = todo & wave_ballot(oct == fwdbits);
+    todo &= ~am;
+    uint32_t ref = root;
+    float nearv = near0, farv = far0;  // this lane's interval in the current node, as the planes cut it
+    int sp = 0;
+    LaneMask occm = 0;
+    for (;;) {
+      while (!(ref & BREF_LEAF)) {
+        ref = uni(ref); am = uni(am); sp = (int)uni((uint32_t)sp);
+        if (C) cnt.bih += lane_of(am) ? 1u : 0u;
+        const float cf = MODE == 1 ? gminf(farv, pick.item != CAND_NONE ? pick.t : kInf * 4.0f) : farv;  // `far` cut by the best so far: decides, is not handed down
+        am &= wave_ballot(!(nearv > cf));
+        if (am == 0) break;
+        const F4 n = ld4u(S.bihnodes, ref);
+        const uint32_t w0 = uni(as_u(n.z)), right = uni(as_u(n.w));
+        const uint32_t axis = w0 & 3u, left = w0 >> 2;
+        float dl, dr;
+        if (axis == 0) { dl = (n.x - r.o.x) * rcp.x; dr = (n.y - r.o.x) * rcp.x; }
+        else if (axis == 1) { dl = (n.x - r.o.y) * rcp.y; dr = (n.y - r.o.y) * rcp.y; }
+        else { dl = (n.x - r.o.z) * rcp.z; dr = (n.y - r.o.z) * rcp.z; }
+        const bool fwd = (fwdbits >> axis) & 1u;
+        const uint32_t c1 = fwd ? left : right, c2 = fwd ? right : left;
+        const float t1 = fwd ? dl : dr, t2 = fwd ? dr : dl;
+        // (an empty leaf child has its plane at -+inf, flatten.hpp: both tests fail for it)
+        const LaneMask m1 = wave_ballot(nearv < t1) & am;
+        const LaneMask m2 = wave_ballot(t2 < cf) & am;
+        const float f1 = gminf(t1, farv), n2 = gmaxf(t2, nearv);
+        if ((m1 != 0) & (m2 != 0)) { stk.push_wave(sp, c2, m2, n2, farv); sp++; }
+        const bool g1 = m1 != 0;
+        ref = g1 ? c1 : c2;
+        am = g1 ? m1 : m2;
+        farv = g1 ? f1 : farv;
+        nearv = g1 ? nearv : n2;
+        if (am == 0) break;
+      }
+      if (am != 0) {  // a leaf
+        ref = uni(ref);
+        uint32_t count = (ref >> 26) & 7u, first = ref & BREF_FIRST;
+        if (count == 7u) { const F4 ln = ld4u(S.bihnodes, first); count = uni(as_u(ln.z)); first = uni(as_u(ln.w)); }
+        const float cf = MODE == 1 ? gminf(farv, pick.item != CAND_NONE ? pick.t : kInf * 4.0f) : farv;
+        bool in = lane_of(am) && !(nearv > cf);
+        if (MODE == 2) {
+          const float dd = gminf(d, farv);
+          for (uint32_t k = 0; k < count; k++) {
+            bool hit = false;
+            if (in) {
+              U4 it = ldu4(S.recs, first + k);
+              const int what = vm_resolve_s(S, it);
+              if (what == 2) hit = vm_inst_prim_shadow<C>(S, cnt, it, r, dd) == 2;
+              else if (what == 0) { if (C) cnt.prim++; hit = prim_shadow(S, it.x & RF_KINDMASK, it.y, r, dd); }
+            }
+            const LaneMask hm = wave_ballot(hit);
+            occm |= hm; am &= ~hm;
+            in = in && !hit;
+            if (am == 0) break;
+          }
+        } else {
+          for (uint32_t k = 0; k < count; k++) {
+            if (in) {
+              U4 it = ldu4(S.recs, first + k);
+              TexStack t = tex;
+              const int what = vm_resolve_r(S, it, t);
+              HitG h = hit_miss();
+              float tm = farv;
+              if (what == 2) (void)vm_inst_prim_hit<C>(S, cnt, it, tex, r, farv, h);
+              else if (what == 0) {
+                const uint32_t ik = it.x & RF_KINDMASK;
+                if (pick.item != CAND_NONE && ik != R_CYL && ik != R_CONE) tm = gminf(farv, pick.t);
+                h = vm_prim_hit<C>(S, cnt, it, r, tm, t);
+              }
+              if (h.hit && (pick.item == CAND_NONE || !(pick.t < h.t))) { pick.t = h.t; pick.item = first + k; pick.tmax = tm; }  // nearest: ties -> the later item
+            }
+          }
+        }
+      }
+      am = 0;
+      while (sp > 0 && am == 0) {
+        sp--;
+        stk.pop_wave(sp, ref, am, nearv, farv);
+        if (MODE == 2) am &= ~occm;
+      }
+      if (am == 0) break;
+    }
+    if (MODE == 2) occ = occ || lane_of(occm);
+  }
+  return occ;
+}
+
 // `inside s p` (Solid.hs:138-254) over the same word stack, from word `base` up: a run-to-completion loop (the callers are
 // the CSG nodes and Bound, in the middle of a rayint step).  A composite is an OR (List, InnerBound, the leaves of a BIH), an
 // AND (Intersection, Bound, Difference = a && not b) or an Instance (the point moves into its frame).
@@ -654,7 +770,10 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, PK* pk
         }
         case R_BIH: {  // rayint_bih, Bih.hs:332-368
           F4 h0 = ld4(S.bihhdr, 3 * rec.y), h1 = ld4(S.bihhdr, 3 * rec.y + 1);
-          if (pk != nullptr && !exact && (as_u(h1.w) == BC_SPHERE || as_u(h1.w) == BC_TRI) && (int)as_u(ld4(S.bihhdr, 3 * rec.y + 2).w) <= pk->total_cap()) { pk_hdr = rec.y; st = ST_PK_R; break; }
+          if (pk != nullptr && !exact) {  // a tree the service walks as a packet: spheres, triangles, or items answered in place -- if the wave's stack holds its depth
+            const uint32_t dw = as_u(ld4(S.bihhdr, 3 * rec.y + 2).w);
+            if ((as_u(h1.w) == BC_SPHERE || as_u(h1.w) == BC_TRI || (dw & kBihItemsInPlace)) && (int)(dw & ~kBihItemsInPlace) <= pk->total_cap()) { pk_hdr = rec.y; st = ST_PK_R; break; }
+          }
           bbclip_ub(r, v3(h0), v3(h1), nearv, farv);
           farv = gminf(d, farv);  // `traverse root near (fmin d far)`, Bih.hs:368
           ref = as_u(h0.w);
@@ -725,7 +844,10 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, PK* pk
         }
         case R_BIH: {  // shadow_bih, Bih.hs:510-544
           F4 h0 = ld4(S.bihhdr, 3 * rec.y), h1 = ld4(S.bihhdr, 3 * rec.y + 1);
-          if (pk != nullptr && (as_u(h1.w) == BC_SPHERE || as_u(h1.w) == BC_TRI) && (int)as_u(ld4(S.bihhdr, 3 * rec.y + 2).w) <= pk->total_cap()) { pk_hdr = rec.y; st = ST_PK_S; break; }
+          if (pk != nullptr) {
+            const uint32_t dw = as_u(ld4(S.bihhdr, 3 * rec.y + 2).w);
+            if ((as_u(h1.w) == BC_SPHERE || as_u(h1.w) == BC_TRI || (dw & kBihItemsInPlace)) && (int)(dw & ~kBihItemsInPlace) <= pk->total_cap()) { pk_hdr = rec.y; st = ST_PK_S; break; }
+          }
           bbclip_ub(r, v3(h0), v3(h1), nearv, farv);
           farv = gminf(d, farv);
           ref = as_u(h0.w);
@@ -755,8 +877,23 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, PK* pk
         todo &= ~wave_ballot(mine);
         float pbt = kNoBest;
         uint32_t prec = CAND_NONE;
-        const bool tris = uni(as_u(ld4u(S.bihhdr, 3 * h + 1).w)) == BC_TRI;  // (the tree's leaf class: triangles or spheres)
-        if (kind == ST_PK_R) {
+        const uint32_t hcls = uni(as_u(ld4u(S.bihhdr, 3 * h + 1).w));  // the tree's leaf class: triangles, spheres, or items answered in place
+        const bool tris = hcls == BC_TRI;
+        if (hcls != BC_TRI && hcls != BC_SPHERE) {
+          ItemPick pick;
+          if (kind == ST_PK_R) {
+            bih_items_wave<1, C>(S, cnt, h, r, d, tex, mine, *pk, pick);
+            if (mine) {
+              // the nearest item once more, for the whole hit: an ordinary call of it with the tmax it was tested with (the same arithmetic,
+              // the same answer), whose return is the tree's -- no code of its own here
+              if (pick.item != CAND_NONE) { rec = ldu4(S.recs, pick.item); d = pick.tmax; st = ST_CALL_R; }
+              else { rh = hit_miss(); st = ST_RET; }
+            }
+          } else {
+            const bool occ = bih_items_wave<2, C>(S, cnt, h, r, d, tex, mine, *pk, pick);
+            if (mine) { rb = occ; st = ST_RET; }
+          }
+        } else if (kind == ST_PK_R) {
           if (tris) bih_tri_wave<1, C, 0>(S, h, r, d, mine, *pk, cnt, pbt, prec);
           else bih_tri_wave<1, C, 1>(S, h, r, d, mine, *pk, cnt, pbt, prec);
           if (mine) { rh = prec != CAND_NONE ? vm_prim_hit<false>(S, cnt, ldu4(S.recs, prec), r, kInf * 8.0f, tex) : hit_miss(); st = ST_RET; }

@@ -44,6 +44,7 @@ constexpr uint32_t RF_PRIMLIST = 1u << 10; // on a list / Intersection record: e
 constexpr uint32_t RF_RETEX = 1u << 11;    // on a Difference record: `Difference a b False` (difference_retexture, Csg.hs:29-30, 42-43): a carved surface keeps
                                            // the textures B's hit came with instead of taking A's at the point
 
+constexpr uint32_t kBihItemsInPlace = 1u << 31;  // bihhdr[3h + 2].w: the tree's depth, and this bit when every item is a primitive or an Instance of primitives (flatten.hpp item_in_place)
 enum BihLeafClass : uint32_t { BC_GENERIC = 0, BC_TRI = 1, BC_SPHERE = 2, BC_SIMPLE = 3, BC_CSG = 4 /* primitives and CSG over primitives */ };
 constexpr uint32_t MESH_BRANCH = 0xffffffffu;  // count value marking "ref is a branch node"
 
@@ -57,7 +58,7 @@ constexpr int kMaxTexDepth = 8;   // with 8-bit ids; 64 / tex_bits in general
 constexpr int kMaxLights = 16;
 constexpr int kFlatStack = 32;     // deepest BIH / Mesh tree the flat tier traverses (stack entries per lane: LDS part + global overflow columns)
 constexpr int kFlatStackMesh = 64; // ... the Mesh PACKET walk may hold two entries per tree level (rt_device.hpp mesh_closest_wave)
-constexpr int kGenericPacketStack = 20;  // LDS entries per lane of the generic tier's packet stack (rt_generic.hpp, vm_run's packet service)
+constexpr int kGenericPacketStack = 24;  // LDS entries per lane of the generic tier's packet stack (rt_generic.hpp, vm_run's packet service): 18 KB a wave, eight waves per CU fit; the oak of GlomeView's default scene is 21 levels deep
 constexpr int kGenericStack = 32;  // scratch traversal-stack entries per BIH/Mesh level in the generic tier
 // the generic tier's frame stack (rt_generic.hpp): words per ray, and the frame sizes the host's commit-time estimate shares
 constexpr int kVmWords = 768, kVmHitWords = 17, kVmListR = 7 + kVmHitWords, kVmInstR = 10, kVmBoundR = 5, kVmIbR = 4, kVmDiffFixed = 10 + kVmHitWords,

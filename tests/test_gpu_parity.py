@@ -309,10 +309,11 @@ def test_limits_lifted_in_round_3(gpu_ctx):
     sc.release()
 
 
-@pytest.mark.parametrize("name", ["nested", "instanced_terrain", "testscene"])
+@pytest.mark.parametrize("name", ["nested", "instanced_terrain", "testscene", "grove"])
 def test_generic_tier_packet_service_equals_the_per_lane_walk(gpu_ctx, name):
-    """Sphere / triangle BIHs inside the generic tier's interpreter are walked as wave-wide packets (rt_generic.hpp, vm_run's packet
-    service).  Committed with GLOME_DEBUG_NO_GENERIC_PACKETS the same scene walks them lane by lane over frames: frames and ray counts must be
+    """Sphere / triangle BIHs inside the generic tier's interpreter, and BIHs whose items are all answered in place (the oak of the default
+    scene, 21 levels; zoo.grove: every kind of such item), are walked as wave-wide packets (rt_generic.hpp, vm_run's packet service,
+    bih_items_wave).  Committed with GLOME_DEBUG_NO_GENERIC_PACKETS the same scene walks them lane by lane over frames: frames and ray counts must be
     bit-identical in both render modes, the work counters close."""
     sd = zoo.testscene(4) if name == "testscene" else SCENES[name]()
     cam, lights = product_camera_lights(sd)
@@ -325,6 +326,7 @@ def test_generic_tier_packet_service_equals_the_per_lane_walk(gpu_ctx, name):
         finally:
             os.environ.pop("GLOME_DEBUG_NO_GENERIC_PACKETS", None)
         assert sc.info()["tier"] == 1
+        if name in ("testscene", "grove"): assert sc.info()["max_bih_depth"] <= 24  # (kGenericPacketStack: the service's stack holds these trees)
         frames = []
         for mode, w, h in ((0, 240, 160), (1, 195, 130)):
             img, packed, st = sc.render(cam, lights, api.render_params(width=w, height=h, mode=mode, maxdepth=3, count_work=1))

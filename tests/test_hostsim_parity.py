@@ -207,9 +207,10 @@ def test_more_nested_textures_than_the_stack_holds_are_refused(built):
         HostSim(b, nm[five])
 
 
-@pytest.mark.parametrize("name", ["nested", "instanced_terrain", "testscene"])
+@pytest.mark.parametrize("name", ["nested", "instanced_terrain", "testscene", "grove"])
 def test_generic_tier_packet_service_equals_the_per_lane_walk(built, name):
-    """The packet service of the generic tier's interpreter (sphere / triangle BIHs walked wave-wide, rt_generic.hpp vm_run) against
+    """The packet service of the generic tier's interpreter (sphere / triangle BIHs, and BIHs of items answered in place -- the oak of
+    the default scene, zoo.grove -- walked wave-wide, rt_generic.hpp vm_run / bih_items_wave) against
     the same scene committed with GLOME_DEBUG_NO_GENERIC_PACKETS, where every BIH is walked over frames: frames, ray counts and the
     ray-batch seams bit-identical (host build: one lane per wave; the GPU test of the same name runs 64)."""
     import os
