@@ -203,13 +203,16 @@ template <bool C> GD int vm_inst_prim_shadow(const DScene& S, Cnt& cnt, U4 rec, 
 // ordered walk's in mask form, decision for decision -- same plane arithmetic, same go / push rules, the best hit so far only decides
 // which nodes and leaves a lane still enters, an item sees the node's own `far` (a quadric's answer depends on it: rt_device.hpp
 // bih_traverse, CLAMP) or, a plain primitive that is not a quadric, min(far, best) exactly as ST_BIH_ITEM tests it -- so frames are
-// bit-identical with the service off (GLOME_DEBUG_NO_GENERIC_PACKETS; tests).  What comes back is WHICH item is nearest and the tmax
-// it was tested with; the caller evaluates that one item once more for the full hit.
+// bit-identical with the service off (GLOME_DEBUG_NO_GENERIC_PACKETS; tests).  The nearest hit so far is kept where ST_BIH_ITEM keeps it,
+// in the lane's frame memory (`m[slot ..]`, kHitWords above the lane's top frame: the caller has checked the room): the hit that comes
+// back is the one the item's in-place evaluation made, not a second evaluation of it.  (The first version returned WHICH item was
+// nearest and finished it by an ordinary call, ST_CALL_R: on the host build the same bits, on the GPU an ulp of the depth apart on one
+// fuzz scene in 680 -- the compiler contracts the Instance frame's arithmetic and the in-place copy's differently.)
 // MODE 1: rayint (Bih.hs:332-368, ordered).  MODE 2: shadow_bih (Bih.hs:510-544): true for a lane with an occluder.
 // All lanes of the wave call together; `valid`: the lane takes part.  The root is a branch and depth <= stk.total_cap() (callers).
-struct ItemPick { float t; uint32_t item; float tmax; };
+struct ItemPick { float t; uint32_t item; };  // the nearest hit's distance and its item's record (CAND_NONE: none yet)
 template <int MODE, bool C, class STK>
-GD bool bih_items_wave(const DScene& S, Cnt& cnt, uint32_t hdr, const Ray& r, float d, TexStack tex, bool valid, STK& stk, ItemPick& pick) {
+GD bool bih_items_wave(const DScene& S, Cnt& cnt, uint32_t hdr, const Ray& r, float d, TexStack tex, bool valid, STK& stk, ItemPick& pick, uint32_t* m, int slot) {
   hdr = uni(hdr);
   const F4 h0 = ld4u(S.bihhdr, 3 * hdr), h1 = ld4u(S.bihhdr, 3 * hdr + 1);
   const uint32_t root = uni(as_u(h0.w));
@@ -217,7 +220,7 @@ GD bool bih_items_wave(const DScene& S, Cnt& cnt, uint32_t hdr, const Ray& r, fl
   float near0, far0;
   bbclip_ub(r, v3(h0), v3(h1), near0, far0);
   far0 = gminf(d, far0);  // `traverse root near (fmin d far)`, Bih.hs:368 / 515
-  pick.t = kInf * 4.0f; pick.item = CAND_NONE; pick.tmax = 0.0f;
+  pick.t = kInf * 4.0f; pick.item = CAND_NONE;
   const uint32_t oct = (rcp.x > 0 ? 1u : 0u) | (rcp.y > 0 ? 2u : 0u) | (rcp.z > 0 ? 4u : 0u);
   if (C) { if (valid && near0 > far0) cnt.bih++; }  // the root taken up with an empty interval: counted and left
   LaneMask todo = wave_ballot(valid && !(near0 > far0));
@@ -294,7 +297,7 @@ GD bool bih_items_wave(const DScene& S, Cnt& cnt, uint32_t hdr, const Ray& r, fl
                 if (pick.item != CAND_NONE && ik != R_CYL && ik != R_CONE) tm = gminf(farv, pick.t);
                 h = vm_prim_hit<C>(S, cnt, it, r, tm, t);
               }
-              if (h.hit && (pick.item == CAND_NONE || !(pick.t < h.t))) { pick.t = h.t; pick.item = first + k; pick.tmax = tm; }  // nearest: ties -> the later item
+              if (h.hit && (pick.item == CAND_NONE || !(pick.t < h.t))) { vm_st_hit(m, slot, h); pick.t = h.t; pick.item = first + k; }  // nearest: ties -> the later item
             }
           }
         }
@@ -772,7 +775,7 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, PK* pk
           F4 h0 = ld4(S.bihhdr, 3 * rec.y), h1 = ld4(S.bihhdr, 3 * rec.y + 1);
           if (pk != nullptr && !exact) {  // a tree the service walks as a packet: spheres, triangles, or items answered in place -- if the wave's stack holds its depth
             const uint32_t dw = as_u(ld4(S.bihhdr, 3 * rec.y + 2).w);
-            if ((as_u(h1.w) == BC_SPHERE || as_u(h1.w) == BC_TRI || (dw & kBihItemsInPlace)) && (int)(dw & ~kBihItemsInPlace) <= pk->total_cap()) { pk_hdr = rec.y; st = ST_PK_R; break; }
+            if ((as_u(h1.w) == BC_SPHERE || as_u(h1.w) == BC_TRI || ((dw & kBihItemsInPlace) && sp + kHitWords <= kVmWords)) && (int)(dw & ~kBihItemsInPlace) <= pk->total_cap()) { pk_hdr = rec.y; st = ST_PK_R; break; }  // (kHitWords: where bih_items_wave keeps the nearest hit)
           }
           bbclip_ub(r, v3(h0), v3(h1), nearv, farv);
           farv = gminf(d, farv);  // `traverse root near (fmin d far)`, Bih.hs:368
@@ -882,15 +885,10 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, PK* pk
         if (hcls != BC_TRI && hcls != BC_SPHERE) {
           ItemPick pick;
           if (kind == ST_PK_R) {
-            bih_items_wave<1, C>(S, cnt, h, r, d, tex, mine, *pk, pick);
-            if (mine) {
-              // the nearest item once more, for the whole hit: an ordinary call of it with the tmax it was tested with (the same arithmetic,
-              // the same answer), whose return is the tree's -- no code of its own here
-              if (pick.item != CAND_NONE) { rec = ldu4(S.recs, pick.item); d = pick.tmax; st = ST_CALL_R; }
-              else { rh = hit_miss(); st = ST_RET; }
-            }
+            bih_items_wave<1, C>(S, cnt, h, r, d, tex, mine, *pk, pick, m, sp);
+            if (mine) { rh = pick.item != CAND_NONE ? vm_ld_hit(m, sp) : hit_miss(); st = ST_RET; }
           } else {
-            const bool occ = bih_items_wave<2, C>(S, cnt, h, r, d, tex, mine, *pk, pick);
+            const bool occ = bih_items_wave<2, C>(S, cnt, h, r, d, tex, mine, *pk, pick, m, sp);
             if (mine) { rb = occ; st = ST_RET; }
           }
         } else if (kind == ST_PK_R) {

@@ -239,6 +239,8 @@ def testscene(lattice_n=10, with_oak=True, skip=()):
     warp = sd.material_warp(frame, None, LIGHTS, api.compose([api.rotate((1, 0, 0), api.deg(-85)), api.translate((8, 40, -4))]))
     door = sd.transform(sd.group([frame, sd.tex(surface, warp)]), [api.rotate((0, 1, 0), api.deg(8)), api.translate((-3, 0.5, -5))])
     glass = sd.transform(sd.tex(sd.sphere((-2.3, 0.3, 4.2), 1.7), sd.material_refract(0.35, 0.8, 1.5)), [api.scale((1, 0.4, 1))])  # :196
+    if os.environ.get("GLOME_TS_PLAIN_BOARD"):  # (measurement only, like `skip`: the board left whole -- what its Difference costs on top of its 64 boxes)
+        carved_board = sd.transform(chessboard, [api.scale((2, 1.2, 2))])
     items = [carved_board, dodeca, icosa, cone]
     if with_oak:
         items.append(sd.transform(oak(sd, 11.4, 42), [api.scale((2, 2, 2)), api.translate((2, -1, -8))]))                 # :190

@@ -309,6 +309,29 @@ def test_limits_lifted_in_round_3(gpu_ctx):
     sc.release()
 
 
+@pytest.mark.parametrize("gen,seed", [("composites", 14019), ("composites", 14093), ("grove", 14003), ("grove", 14010), ("grove", 14016)])
+def test_packet_service_equals_the_per_lane_walk_on_fuzz_scenes(gpu_ctx, gen, seed):
+    """The same bit-identity on fuzz scenes under the fuzz soak's rig (a camera inside the scene, lights of finite reach): composites 14019 is
+    the scene on which the first form of bih_items_wave -- the nearest item finished by an ordinary call -- came out an ulp of the depth
+    away from the per-lane walk on the GPU (the Instance frame's arithmetic and its in-place copy contract differently) and identical on
+    the host build; the groves are the soak's three with the most rounding-sensitive pixels."""
+    sd = zoo.fuzz_rig(zoo.random_composites(seed) if gen == "composites" else zoo.grove(n=30 + (seed * 37) % 200, seed=seed), seed)
+    cam, lights = product_camera_lights(sd)
+    out = []
+    for off in (False, True):
+        if off:
+            os.environ["GLOME_DEBUG_NO_GENERIC_PACKETS"] = "1"
+        try:
+            b, nm, sc = commit(gpu_ctx, sd)
+        finally:
+            os.environ.pop("GLOME_DEBUG_NO_GENERIC_PACKETS", None)
+        assert sc.info()["tier"] == 1
+        out.append([sc.render(cam, lights, api.render_params(width=192, height=108, mode=mode, maxdepth=md))[0].copy() for mode, md in ((0, 1), (0, 3), (1, 3))])
+        sc.release()
+    for a_, b_ in zip(*out):
+        assert np.array_equal(a_, b_)
+
+
 @pytest.mark.parametrize("name", ["nested", "instanced_terrain", "testscene", "grove"])
 def test_generic_tier_packet_service_equals_the_per_lane_walk(gpu_ctx, name):
     """Sphere / triangle BIHs inside the generic tier's interpreter, and BIHs whose items are all answered in place (the oak of the default

@@ -1,6 +1,7 @@
 """GPU fuzz soak: zoo.random_flat / zoo.random_composites scenes through the C ABI against the fp64 oracle and the same oracle in
 fp32 (a pixel away from both is logic, not rounding), renderTile and renderTileSubsample, plus early-out vs faithful frames.
-usage: python fuzz_gpu.py [n_flat] [n_composites]"""
+usage: python fuzz_gpu.py [n_flat] [n_composites] [first seed] [n_groves]      (groves: zoo.grove of a random size -- BIHs of items the
+interpreter answers in place, walked as packets by its service)"""
 import os, sys, time
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
@@ -11,12 +12,19 @@ from glome_amd import api
 nf = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 nc = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 BASE = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+ng = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+
+
+def random_grove(seed):
+    return zoo.grove(n=30 + (seed * 37) % 200, seed=seed)
+
+
 ctx = api.Context(0)
 W, H = 192, 108
 worst, bad, refused, limits = 0, [], 0, []
 t0 = time.time()
 err = lambda a, r: (np.abs(a[..., :4] - r[..., :4]) / np.maximum(1, np.abs(r[..., :4]))).max(-1)
-for gen, n in ((zoo.random_flat, nf), (zoo.random_composites, nc)):
+for gen, n in ((zoo.random_flat, nf), (zoo.random_composites, nc), (random_grove, ng)):
     for seed in range(BASE, BASE + n):
         sd = gen(seed)
         b = api.Builder(); nm, _ = sd.replay(b)
@@ -51,4 +59,4 @@ for gen, n in ((zoo.random_flat, nf), (zoo.random_composites, nc)):
         boths = (err(sub, refs) > 1e-4) & (err(sub, r32s) > 1e-4)
         if boths.mean() > 6e-3: bad.append((gen.__name__, seed, "adaptive frame", int(boths.sum()), int((err(r32s, refs) > 1e-4).sum())))
         sc.release()
-print("scenes", nf + nc - refused, "refused", refused, "worst pixels off both (of %d)" % (W * H), worst, "bad", bad, "run-time limits", limits, "secs", round(time.time() - t0, 1), flush=True)
+print("scenes", nf + nc + ng - refused, "refused", refused, "worst pixels off both (of %d)" % (W * H), worst, "bad", bad, "run-time limits", limits, "secs", round(time.time() - t0, 1), flush=True)
