@@ -61,7 +61,7 @@ constexpr int kFlatStackMesh = 64; // ... the Mesh PACKET walk may hold two entr
 constexpr int kGenericPacketStack = 24;  // LDS entries per lane of the generic tier's packet stack (rt_generic.hpp, vm_run's packet service): 18 KB a wave, eight waves per CU fit; the oak of GlomeView's default scene is 21 levels deep
 constexpr int kGenericStack = 32;  // scratch traversal-stack entries per BIH/Mesh level in the generic tier
 // the generic tier's frame stack (rt_generic.hpp): words per ray, and the frame sizes the host's commit-time estimate shares
-constexpr int kVmWords = 768, kVmHitWords = 17, kVmListR = 7 + kVmHitWords, kVmInstR = 10, kVmBoundR = 5, kVmIbR = 4, kVmDiffFixed = 10 + kVmHitWords,
+constexpr int kVmWords = 2048 /* 768 until round 4; measured on GlomeView's default scene: +0.2 %, adaptive +1.4 % (profiles/r04_probes/vm_words_ab.txt) */, kVmHitWords = 17, kVmListR = 7 + kVmHitWords, kVmInstR = 10, kVmBoundR = 5, kVmIbR = 4, kVmDiffFixed = 10 + kVmHitWords,
               kVmIsectWords = 11, kVmBihFixedR = 12 + kVmHitWords, kVmBihFixedS = 12;
 constexpr int kVmIsectChain = 8;   // Intersection frames the commit-time estimate allows for (a chain longer than the memory is caught at run time)
 constexpr int kCsgMaxAdvance = 32; // ray-advance steps per Difference the generic tier's commit-time frame estimate allows for (at run time: its frame memory)

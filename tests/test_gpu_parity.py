@@ -475,7 +475,7 @@ def test_edge_cases(gpu_ctx):
     for _ in range(8):
         n = b.group([b.transform(n, [api.translate((0.1, 0, 0))]), b.sphere((9, 9, 9), 0.1)])
     gpu_ctx.commit(b, b.difference(n, b.sphere((0.5, 0, 0), 0.7))).release()  # seventeen composite levels: fine (zoo.deep_nest is rendered by the parity tests)
-    for _ in range(20):
+    for _ in range(60):  # (2,048 frame words since round 4: a group and the Instance inside it take 34)
         n = b.group([b.transform(n, [api.translate((0.1, 0, 0))]), b.sphere((9, 9, 9), 0.1)])
     with pytest.raises(api.GlomeError, match="frame memory"):  # what bounds the nesting: the interpreter's frame words, estimated at commit
         gpu_ctx.commit(b, n)

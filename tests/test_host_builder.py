@@ -124,7 +124,7 @@ def test_flatten_tiers_and_limits(built):
     assert HostSim(b, n).info()["nesting"] == 16
     assert HostSim(b, b.difference(n, b.sphere((0.5, 0, 0), 0.7))).info()["nesting"] == 17
     # what bounds the nesting now is the interpreter's frame memory, estimated at commit from the frames each node needs
-    for _ in range(20):
+    for _ in range(60):  # (2,048 frame words since round 4: a group and the Instance inside it take 34)
         n = b.group([b.transform(n, [api.translate((0.1, 0, 0))]), b.sphere((9, 9, 9), 0.1)])
     with pytest.raises(RuntimeError, match="frame memory"):
         HostSim(b, n)

@@ -435,6 +435,7 @@ def deep_nest(levels=14):
 
 
 ALL["deep_nest"] = deep_nest
+ALL["deeper_nest"] = lambda: deep_nest(levels=50)  # (needs ~1,000 of the interpreter's 2,048 frame words per ray: beyond the 768 of rounds 2-3)
 
 
 def random_composites(seed, n_items=9, max_depth=3):
