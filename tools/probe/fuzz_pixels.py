@@ -10,7 +10,7 @@ W, H = 192, 108
 e = lambda a, b: (np.abs(a[..., :4] - b[..., :4]) / np.maximum(1, np.abs(b[..., :4]))).max(-1)
 for spec in sys.argv[1:]:
     kind, seed = spec.split(":"); seed=int(seed)
-    sd = zoo.fuzz_rig(zoo.random_flat(seed) if kind=="flat" else zoo.random_composites(seed), seed)
+    sd = zoo.random_rig(zoo.random_flat(seed) if kind=="flat" else zoo.random_composites(seed), seed)
     cam, lights = product_camera_lights(sd)
     b = api.Builder(); nm,_ = sd.replay(b); sc = ctx.commit(b, nm[sd.root]); hs = HostSim(b, nm[sd.root])
     img = sc.render(cam, lights, api.render_params(width=W, height=H, maxdepth=3))[0]

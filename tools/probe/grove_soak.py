@@ -15,7 +15,7 @@ W, H = 192, 108
 e = lambda a, b: (np.abs(a[..., :4] - b[..., :4]) / np.maximum(1, np.abs(b[..., :4]))).max(-1)
 
 
-rig = zoo.fuzz_rig
+rig = zoo.random_rig
 
 
 jobs = [("grove", s) for s in range(int(sys.argv[1]), int(sys.argv[1]) + int(sys.argv[2]))] + [tuple(a.split(":")) for a in sys.argv[3:]]

@@ -12,7 +12,7 @@ ctx = api.Context(0)
 W, H = 192, 108
 
 
-rig = zoo.fuzz_rig
+rig = zoo.random_rig
 
 
 for seed in [int(x) for x in sys.argv[1:]]:
