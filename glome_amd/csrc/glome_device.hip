@@ -1252,14 +1252,27 @@ int glome_scene_get_info(const glome_scene* s, glome_scene_info* out) {
 // should get ~64 work items, so that its fixed costs (set-up, the counter flush) amortise and several launches in flight
 // share the CUs side by side instead of one after the other (measured on the flagship frame, 4 launches of 4 frames in
 // flight: 24 waves per CU 0.272 ms, 16: 0.249, 8: 0.239; the 4K / 1M-triangle frame, 4x the items, is best at 24).
+// Is anything still running on the streams the context's OTHER slots last launched on?  A launch sized by its work (below) leaves room
+// for the launches beside it; one that has the GPU to itself -- a short multi-GPU run is ONE launch of a rank's shard, nothing beside it --
+// wants every wave slot: twenty frames of an eighth of the flagship's tiles 0.90 -> 0.66 ms (profiles/r04_probes/short_run_shards.txt).
+static bool other_slots_busy(glome_ctx* ctx) {
+  for (int k = 0; k < glome_ctx::kSlots; k++) {
+    const glome_ctx::Slot& sl = ctx->slots[k];
+    if (k == ctx->cur || !sl.launched_on || sl.launched_on == ctx->stream) continue;
+    if (hipStreamQuery(sl.launched_on) == hipErrorNotReady) return true;
+  }
+  (void)hipGetLastError();  // (a query of a finished stream leaves nothing behind; one of a stream its owner has destroyed must not be this call's error)
+  return false;
+}
 static int persistent_grid(glome_ctx* ctx, size_t lds_per_block, uint32_t total_work, int max_per_cu = 32, int min_per_cu = 0) {
   int cus = ctx->prop.multiProcessorCount;
   int per_cu = max_per_cu;  // wave slots per CU the kernel's register budget allows
   if (lds_per_block) per_cu = std::min<int>(per_cu, (int)(160 * 1024 / lds_per_block));
   per_cu = std::max(per_cu, 1);
   if (ctx->grid_per_cu > 0) per_cu = std::min(per_cu, ctx->grid_per_cu);  // glome_ctx_set_grid_per_cu: the caller knows what else runs
-  else if (min_per_cu > 0) {  // sized by work: ~64 items per wave, not below min_per_cu waves per CU
-    long want = ((long)total_work + 64L * cus - 1) / (64L * cus);
+  else if (min_per_cu > 0) {  // sized by work: ~64 items per wave (~16 when nothing runs beside the launch), not below min_per_cu waves per CU
+    const long per_wave = other_slots_busy(ctx) ? 64L : 16L;
+    long want = ((long)total_work + per_wave * cus - 1) / (per_wave * cus);
     per_cu = (int)std::min<long>(per_cu, std::max<long>(min_per_cu, want));
   }
   long g = (long)cus * per_cu;
