@@ -45,6 +45,17 @@ SCALAR_PEAK = 0.95                # s_add_u32 alone: 0.236-0.237 per cycle per S
 SCALAR_PEAK_WITH_BRANCHES = 1.25
 
 
+def frames_per_launch(steps, lanes, most=32):
+    """A run of `steps` frames cut into as few launches as a launch's `most` frames allow, of equal size, and -- once there are as many
+    launches as are kept in flight -- into a whole number of rounds over those."""
+    if steps < 4:
+        return 1
+    n = -(-steps // most)
+    if n >= lanes:
+        n = -(-n // lanes) * lanes
+    return -(-steps // n)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -60,7 +71,7 @@ def main():
     ap.add_argument("--time-every", type=int, default=1, help="HIP-event pair on every k-th launch of the timed region (roofline kernel time)")
     ap.add_argument("--host-build", action="store_true", help="build the BIH with the host builder (glome_sb_bih) instead of on the GPU")
     ap.add_argument("--force-dist", action="store_true", help="one GPU, but through the multi-GPU pipeline with a one-rank RCCL group (rehearsal)")
-    ap.add_argument("--group", type=int, default=0, help="frames per launch (and per RCCL gather); default by rank count and run length (up to 16)")
+    ap.add_argument("--group", type=int, default=0, help="frames per launch (and per RCCL gather); default by transport and run length (up to 32)")
     ap.add_argument("--product", default="packed", choices=["packed", "rgbad"],
                     help="what a frame is: GlomeView's framebuffer of packed 0x00RRGGBB pixels (blitTile; 4 B/pixel cross xGMI) "
                          "or the float (r,g,b,a,depth) tuples (20 B/pixel)")
@@ -134,6 +145,14 @@ def main():
     lights = [api.light(p, c, r, s) for (p, c, r, s) in sd.lights]
     P = api.render_params(width=W, height=H, maxdepth=maxdepth, mode=args.mode)
 
+    regroup_for_gather = False
+
+    def gather_group(steps):
+        # several ranks, payloads gathered on rank 0 (tools/short_run_groups.py, profiles/r03_short_run_groups.log: rank 0's side of a short
+        # run by frames per launch, one-GPU rehearsal): at 8 ranks a 20-step run takes 0.078 / 0.043 / 0.039 ms per step with 1 / 4 / 8 frames per
+        # launch, a 100-step run 0.039 / 0.031 / 0.027 with 4 / 8 / 16 (tools/shard_timing.py, profiles/r03_h_shard_timing.log)
+        return (1 if world == 2 else 4) if steps < 8 else (4 if steps < 16 else (8 if steps < 40 else 16))
+
     if args.group <= 0:
         # frames per launch (and per gather).  Deep batches pay a fill / drain of about one launch per run, so short runs get
         # shallower ones; the break-even points are measured (below)
@@ -151,20 +170,30 @@ def main():
             # and 0.188 as 2 x 10; 200 steps 0.1725 at 8 frames per launch and 0.162 at 16)
             # round 4: a launch costs ~0.31 ms besides its frames even with others in flight (profiles/r04_probes/short_run_fit.txt:
             # per launch 0.307 + 0.137 ms x frames, pipelined), so a run is cut into as few launches as possible: up to 32 frames each
-            args.group = 1 if args.steps < 4 else min(32, args.steps)
+            # ... and into launches of equal size, a whole number of rounds over the launches in flight (200 steps: eight launches of 25
+            # rather than six of 32 and one of 8: 0.1433 against 0.146 ms per step, profiles/r04_probes/bench_lanes_groups_sweep.txt)
+            args.group = frames_per_launch(args.steps, args.lanes or 4)
+        elif args.transport != "gather":
+            # several ranks, the direct transport (every rank's kernel stores into rank 0's frames): a rank's step is its launch and
+            # nothing else, so the one-GPU rule holds -- a 20-step run at 8 ranks takes 0.63 ms as one launch of twenty shard frames, 0.73 as
+            # two of ten, 0.98 as four of five (tools/probe/short_run_shards.py, profiles/r04_probes/short_run_shards.txt); should the frames
+            # turn out not to be mappable, the gather's own rule (below) is applied to a pipeline built again
+            args.group = frames_per_launch(args.steps, args.lanes or 4)
+            regroup_for_gather = True
         else:
-            # several ranks (tools/short_run_groups.py, profiles/r03_short_run_groups.log: rank 0's side of a short run by frames per
-            # launch, one-GPU rehearsal).  A rank's shard of a frame is a small launch whose fixed part -- it cannot be shorter than
-            # its slowest work items -- is shared by the frames it carries: at 8 ranks a 20-step run takes 0.078 / 0.043 / 0.039 ms per
-            # step with 1 / 4 / 8 frames per launch, a 100-step run 0.039 / 0.031 / 0.027 with 4 / 8 / 16 (tools/shard_timing.py,
-            # profiles/r03_h_shard_timing.log: 0.040 / 0.038 / 0.027 sustained)
-            args.group = (1 if world == 2 else 4) if args.steps < 8 else (4 if args.steps < 16 else (8 if args.steps < 40 else 16))
+            args.group = gather_group(args.steps)
             if world >= 8 and args.group == 16 and args.lanes is None:
                 args.lanes = 3
-    if args.lanes is None:
-        args.lanes = 4
-    sf = dist.ShardedFrame(scene, P, rank, world, device, lanes=args.lanes, product=args.product, group=args.group, force_pipeline=args.force_dist,
+    lanes = args.lanes if args.lanes is not None else 4
+    sf = dist.ShardedFrame(scene, P, rank, world, device, lanes=lanes, product=args.product, group=args.group, force_pipeline=args.force_dist,
                            direct={"auto": None, "direct": True, "gather": False}[args.transport])
+    if regroup_for_gather and not sf.direct:  # (every rank takes this branch or none: the mode was agreed by an all-reduce)
+        sf.close()
+        args.group = gather_group(args.steps)
+        if world >= 8 and args.group == 16 and args.lanes is None:
+            lanes = 3
+        sf = dist.ShardedFrame(scene, P, rank, world, device, lanes=lanes, product=args.product, group=args.group, force_pipeline=args.force_dist, direct=False)
+    args.lanes = lanes
 
     def barrier():
         if dist_on:

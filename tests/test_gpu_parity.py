@@ -1264,8 +1264,8 @@ def test_csg_items_of_the_flat_tier_advance_without_a_cap(gpu_ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ranks,transport", [(2, "direct"), (3, "direct"), (2, "gather")])
-def test_one_process_per_gpu_job_rehearsed_on_one_gpu(ranks, transport):
+@pytest.mark.parametrize("ranks,transport,group", [(2, "direct", 4), (3, "direct", 4), (2, "gather", 4), (3, "auto", None), (2, "gather", None)])
+def test_one_process_per_gpu_job_rehearsed_on_one_gpu(ranks, transport, group):
     """bench.py --gpus N as the driver launches it -- one process per rank, torch.distributed -- rehearsed on the one GPU of the box
     (--rehearse: gloo instead of RCCL, every rank on device 0).  `direct` (round 4): every rank's kernel stores its tiles straight
     into rank 0's frames, mapped into the other processes through HIP IPC handles (glome_ipc_*); `gather`: payloads to rank 0 and a
@@ -1276,8 +1276,11 @@ def test_one_process_per_gpu_job_rehearsed_on_one_gpu(ranks, transport):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--rehearse", "--transport", transport, "--scene", "S3", "--steps", "9", "--warmup", "3",
-                        "--group", "4", "--no-cpu"], capture_output=True, text=True, timeout=500, env=env, cwd=root)
+                        "--no-cpu"] + (["--group", str(group)] if group else []),  # (no --group: bench.py's own rule -- one launch of nine frames when the frames can be mapped)
+                       capture_output=True, text=True, timeout=500, env=env, cwd=root)
     assert r.returncode == 0, (r.stdout[-800:], r.stderr[-2500:])
     line = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == ranks and line["frame_equals_single_gpu_render"] is True, line
-    assert line["config"]["transport"].startswith(transport), line["config"]["transport"]
+    assert line["config"]["transport"].startswith("direct" if transport == "auto" else transport), line["config"]["transport"]
+    if group is None:
+        assert line["config"]["frames_per_launch"] == (9 if transport == "auto" else 4), line["config"]
