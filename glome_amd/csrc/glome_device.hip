@@ -106,7 +106,8 @@ __global__ void k_kernarg_selftest(DRenderArgs, const DRenderArgs* expect, unsig
   if (!same) atomicAnd(ok, 0u);
 }
 #endif
-struct GenericTier {
+template <int PKMIN = kPkMinLanes>  // (lanes that must wait before the packet service walks: rt_generic.hpp vm_run)
+struct GenericTierT {
   static constexpr bool FULL = true;
   static constexpr bool WARP = true;
   // What the out-of-line interpreter calls take the address of -- counters, error flag, frame memory -- are locals of the kernel,
@@ -121,16 +122,17 @@ struct GenericTier {
   unsigned int& err;
   uint32_t* vm;  // the interpreter's frames: one word stack of kVmWords per lane for the whole kernel (scratch)
   LaneStack pk;  // the wave's LDS stack for packet walks of sphere BIHs inside the interpreter (cap 0: the scene has none)
-  __device__ __forceinline__ GenericTier rebound(const DRenderArgs&) const { return *this; }  // (already reads the kernarg segment: kernel_args<>())
-  __device__ __forceinline__ void absorb(const GenericTier&) {}
+  __device__ __forceinline__ GenericTierT rebound(const DRenderArgs&) const { return *this; }  // (already reads the kernarg segment: kernel_args<>())
+  __device__ __forceinline__ void absorb(const GenericTierT&) {}
   // `root`: the record the trace runs over -- the scene's, or the frame / scene of a Warp material
-  __device__ __forceinline__ HitG closest(const Ray& r, float tmax, uint32_t root) { return vm_closest<true>(S, cnt, err, vm, pk.cap > 0 ? &pk : (LaneStack*)nullptr, r, tmax, root); }
-  __device__ __forceinline__ bool occluded(const Ray& r, float d, uint32_t root) { return vm_occluded<true>(S, cnt, err, vm, pk.cap > 0 ? &pk : (LaneStack*)nullptr, r, d, root); }
+  __device__ __forceinline__ HitG closest(const Ray& r, float tmax, uint32_t root) { return vm_closest<true, PKMIN>(S, cnt, err, vm, pk.cap > 0 ? &pk : (LaneStack*)nullptr, r, tmax, root); }
+  __device__ __forceinline__ bool occluded(const Ray& r, float d, uint32_t root) { return vm_occluded<true, PKMIN>(S, cnt, err, vm, pk.cap > 0 ? &pk : (LaneStack*)nullptr, r, d, root); }
   __device__ __forceinline__ HitG closest(const Ray& r, float tmax) { return closest(r, tmax, S.root_rec); }
   __device__ __forceinline__ bool occluded(const Ray& r, float d) { return occluded(r, d, S.root_rec); }
   __device__ __forceinline__ HitG closest_wave(const Ray& r, float tmax, bool valid, uint32_t root) { return valid ? closest(r, tmax, root) : hit_miss(); }
   __device__ __forceinline__ bool occluded_wave(const Ray& r, float d, bool valid) { return valid && occluded(r, d); }
 };
+using GenericTier = GenericTierT<>;
 
 // LDS carve per wave: three stack rows of cap * 64 words (reference, near, far -- the per-lane traversal's entries), or
 // two (near, far) in kernels that only ever run the hand-written packet walk, which keeps its references in registers
@@ -414,7 +416,7 @@ __global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_render_generic(DRender
   const DRenderArgs& A = kernel_args<DRenderArgs>();
   extern __shared__ uint32_t lds[];
   Cnt cnt; unsigned int err = 0; uint32_t vm[kVmWords];
-  GenericTier T{A.S, A.lights, A.nlights, cnt, err, vm, generic_packet_stack(lds, (int)A.S.pk_generic_cap)};
+  GenericTierT<1> T{A.S, A.lights, A.nlights, cnt, err, vm, generic_packet_stack(lds, (int)A.S.pk_generic_cap)};  // (<1>: this kernel's packet service never waits)
   // (Tried in round 3 and dropped: refilling a lane with the next pixel as soon as its trace is through, with shade_vm as a
   // resumable object.  The object form alone cost S4 0.39 -> 0.50 ms and this tier 4.3 -> 4.85 ms (its state no longer stays in
   // registers), and with refilling the lanes fall out of step, every closest-hit call then runs for a part of the wave, and the frame took 5.8 ms

@@ -603,7 +603,7 @@ constexpr int kBihFixedS = kVmBihFixedS, kBihFixedR = kVmBihFixedR, kDiffFixed =
 // (bih_tri_wave: wave-uniform node references, scalar loads, per-lane intervals) -- same hit and same tie order as the per-lane
 // walk: frames are bit-identical with the service switched off (GLOME_DEBUG_NO_GENERIC_PACKETS, GPU test), node counters 2 % apart.  A ray that is not unit length keeps the per-lane walk (the
 // ordered early-out is exact for unit rays only).
-template <bool C, class PK>
+template <bool C, int PKMIN = kPkMinLanes, class PK>
 GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, PK* pk, int st, U4 rec, Ray r, float d, bool exact, HitG& rh, bool& rb) {
   int sp = 1, fb = 0;
   m[0] = VT_DONE;
@@ -872,7 +872,11 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, PK* pk
       // a walk costs the same for one lane as for sixty-four: while fewer than kPkMinLanes wait and other lanes can still go on
       // (and may join them), the waiting ones wait.  (Measured on GlomeView's default scene, 1 / 8 / 16 / 32 / 64: 4.10 / 3.98 / 3.96
       // / 3.94 / 3.91 ms per frame, a frame alone 15.7 / 14.2 / 13.5 / 13.7 / 13.6: profiles/r03_probes/generic_tier_packet_service_ab.txt)
-      if (wave_count(want) < kPkMinLanes && wave_any(!want)) todo = 0;
+      // Round 4, with trees of items answered in place in the service too: a renderTile frame is better off NOT waiting (PKMIN 1: the test below
+      // is gone from its kernel; GlomeView's default scene 2.51 -> 2.44 ms per frame; 16 and 32 change nothing), the adaptive sampler's kernel
+      // is not (4.68 against 4.75): profiles/r04_probes/packet_service_min_lanes_ab.txt.  (A threshold read at run time, per launch, measured
+      // like 64 in both: what the renderTile kernel gains is the code it no longer carries.)
+      if (PKMIN > 1 && wave_count(want) < PKMIN && wave_any(!want)) todo = 0;
       while (todo != 0) {  // one walk per (tree, kind of call) among the waiting lanes
         const uint32_t h = uni(first_lane_value(todo, pk_hdr));
         const int kind = (int)uni(first_lane_value(todo, (uint32_t)st));
@@ -1186,16 +1190,16 @@ GD void vm_run(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, PK* pk
 #undef VM_CALL_R_INLINE
 }
 
-template <bool C, class PK> GD HitG vm_closest(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, PK* pk, const Ray& r, float tmax, uint32_t root) {
+template <bool C, int PKMIN = kPkMinLanes, class PK> GD HitG vm_closest(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, PK* pk, const Ray& r, float tmax, uint32_t root) {
   HitG h; bool b;
   // a ray that is not unit length (Refract's transmitted ray, Shader.hs:141): BIHs are walked exactly as the reference
   // walks them (rt_device.hpp bih_traverse: the ordered early-out's pruning is exact only for unit rays)
-  vm_run<C>(S, cnt, err, m, pk, ST_CALL_R, ldu4(S.recs, root), r, tmax, !unit_length(r.d), h, b);
+  vm_run<C, PKMIN>(S, cnt, err, m, pk, ST_CALL_R, ldu4(S.recs, root), r, tmax, !unit_length(r.d), h, b);
   return h;
 }
-template <bool C, class PK> GD bool vm_occluded(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, PK* pk, const Ray& r, float d, uint32_t root) {
+template <bool C, int PKMIN = kPkMinLanes, class PK> GD bool vm_occluded(const DScene& S, Cnt& cnt, unsigned int& err, uint32_t* m, PK* pk, const Ray& r, float d, uint32_t root) {
   HitG h; bool b;
-  vm_run<C>(S, cnt, err, m, pk, ST_CALL_S, ldu4(S.recs, root), r, d, false, h, b);
+  vm_run<C, PKMIN>(S, cnt, err, m, pk, ST_CALL_S, ldu4(S.recs, root), r, d, false, h, b);
   return b;
 }
 
