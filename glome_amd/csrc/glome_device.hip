@@ -106,7 +106,10 @@ __global__ void k_kernarg_selftest(DRenderArgs, const DRenderArgs* expect, unsig
   if (!same) atomicAnd(ok, 0u);
 }
 #endif
-template <int PKMIN = kPkMinLanes>  // (lanes that must wait before the packet service walks: rt_generic.hpp vm_run)
+// PKMIN: lanes that must wait before the packet service walks (rt_generic.hpp vm_run).  COUNT: bih_nodes / prim_tests are counted -- asked for by
+// glome_render_params.count_work; the instances that do not count are 4 % (renderTile) and 2 % (sampler) faster on GlomeView's default scene
+// (profiles/r04_probes/generic_tier_no_count_ab.txt), like the flat tier's lean instances.
+template <int PKMIN = kPkMinLanes, bool COUNT = true>
 struct GenericTierT {
   static constexpr bool FULL = true;
   static constexpr bool WARP = true;
@@ -125,8 +128,8 @@ struct GenericTierT {
   __device__ __forceinline__ GenericTierT rebound(const DRenderArgs&) const { return *this; }  // (already reads the kernarg segment: kernel_args<>())
   __device__ __forceinline__ void absorb(const GenericTierT&) {}
   // `root`: the record the trace runs over -- the scene's, or the frame / scene of a Warp material
-  __device__ __forceinline__ HitG closest(const Ray& r, float tmax, uint32_t root) { return vm_closest<true, PKMIN>(S, cnt, err, vm, pk.cap > 0 ? &pk : (LaneStack*)nullptr, r, tmax, root); }
-  __device__ __forceinline__ bool occluded(const Ray& r, float d, uint32_t root) { return vm_occluded<true, PKMIN>(S, cnt, err, vm, pk.cap > 0 ? &pk : (LaneStack*)nullptr, r, d, root); }
+  __device__ __forceinline__ HitG closest(const Ray& r, float tmax, uint32_t root) { return vm_closest<COUNT, PKMIN>(S, cnt, err, vm, pk.cap > 0 ? &pk : (LaneStack*)nullptr, r, tmax, root); }
+  __device__ __forceinline__ bool occluded(const Ray& r, float d, uint32_t root) { return vm_occluded<COUNT, PKMIN>(S, cnt, err, vm, pk.cap > 0 ? &pk : (LaneStack*)nullptr, r, d, root); }
   __device__ __forceinline__ HitG closest(const Ray& r, float tmax) { return closest(r, tmax, S.root_rec); }
   __device__ __forceinline__ bool occluded(const Ray& r, float d) { return occluded(r, d, S.root_rec); }
   __device__ __forceinline__ HitG closest_wave(const Ray& r, float tmax, bool valid, uint32_t root) { return valid ? closest(r, tmax, root) : hit_miss(); }
@@ -411,12 +414,13 @@ __global__ void __launch_bounds__(64, LB) k_render_flat(DRenderArgs A, int stack
   if (A.want_counters) flush_counters(A.counters, T.cnt, T.err);
   else if ((CLS & (CLS_CSG | CLS_MESH)) && __builtin_amdgcn_ballot_w64(T.err != 0) && (threadIdx.x & 63) == 0) atomicOr(&A.counters->error, 1u);
 }
-#if GLOME_IN_PART(6)
+#if GLOME_IN_PART(6) || GLOME_IN_PART(10)
+template <bool COUNT>
 __global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_render_generic(DRenderArgs) {
   const DRenderArgs& A = kernel_args<DRenderArgs>();
   extern __shared__ uint32_t lds[];
   Cnt cnt; unsigned int err = 0; uint32_t vm[kVmWords];
-  GenericTierT<1> T{A.S, A.lights, A.nlights, cnt, err, vm, generic_packet_stack(lds, (int)A.S.pk_generic_cap)};  // (<1>: this kernel's packet service never waits)
+  GenericTierT<1, COUNT> T{A.S, A.lights, A.nlights, cnt, err, vm, generic_packet_stack(lds, (int)A.S.pk_generic_cap)};  // (<1>: this kernel's packet service never waits)
   // (Tried in round 3 and dropped: refilling a lane with the next pixel as soon as its trace is through, with shade_vm as a
   // resumable object.  The object form alone cost S4 0.39 -> 0.50 ms and this tier 4.3 -> 4.85 ms (its state no longer stays in
   // registers), and with refilling the lanes fall out of step, every closest-hit call then runs for a part of the wave, and the frame took 5.8 ms
@@ -604,12 +608,13 @@ __global__ void __launch_bounds__(64, LB) k_ss_frame_flat(DRenderArgs A, int sta
   if (A.want_counters) flush_counters(A.counters, T.cnt, T.err);
   else if ((CLS & (CLS_CSG | CLS_MESH)) && __builtin_amdgcn_ballot_w64(T.err != 0) && (threadIdx.x & 63) == 0) atomicOr(&A.counters->error, 1u);
 }
-#if GLOME_IN_PART(7)
+#if GLOME_IN_PART(7) || GLOME_IN_PART(11)
+template <bool COUNT>
 __global__ void __launch_bounds__(64, GLOME_GENERIC_LB) k_ss_frame_generic(DRenderArgs) {
   const DRenderArgs& A = kernel_args<DRenderArgs>();
   extern __shared__ uint32_t lds[];
   Cnt cnt; unsigned int err = 0; uint32_t vm[kVmWords];
-  GenericTier T{A.S, A.lights, A.nlights, cnt, err, vm, generic_packet_stack(lds, (int)A.S.pk_generic_cap)};
+  GenericTierT<kPkMinLanes, COUNT> T{A.S, A.lights, A.nlights, cnt, err, vm, generic_packet_stack(lds, (int)A.S.pk_generic_cap)};
   ss_frame_loop(A, T);
   if (A.want_counters) flush_counters(A.counters, T.cnt, T.err);
   else if (__builtin_amdgcn_ballot_w64(T.err != 0) && (threadIdx.x & 63) == 0) atomicOr(&A.counters->error, 1u);
@@ -758,7 +763,7 @@ constexpr int ss_flat_key(bool U, int CLS, int LB, bool TWO, bool F) { return (F
 #define GLOME_SS_FLAT_P5(X) X(false, CLS_BIH_TRI, 5, true, false) X(false, CLS_BIH_TRI, 4, true, false) X(false, CLS_BIH_TRI, 1, false, false) X(true, CLS_BIH_TRI, 1, false, false)
 #define GLOME_SS_FLAT_P9(X) X(true, CLS_EVERY, 1, false, true) X(false, CLS_EVERY, 2, false, false) X(true, CLS_EVERY, 2, false, false) \
   X(false, (CLS_CSG | CLS_PRIMS), 2, false, false) X(true, (CLS_CSG | CLS_PRIMS), 2, false, false)
-constexpr int kParts = 10;
+constexpr int kParts = 12;
 
 #define GLOME_TRY_RENDER_FLAT(F, C, U, K, B, T)                                                                                                   \
   if (key == render_flat_key(F, C, U, K, B, T)) {                                                                                                 \
@@ -776,8 +781,10 @@ bool launch_flat_p3(int key, const FlatLaunch& L, const DRenderArgs& A);
 bool launch_flat_p4(int key, const FlatLaunch& L, const DRenderArgs& A);
 bool launch_ss_flat_p5(int key, const FlatLaunch& L, const DRenderArgs& A);
 bool launch_ss_flat_p9(int key, const FlatLaunch& L, const DRenderArgs& A);
-void launch_render_generic(int grid, hipStream_t st, const DRenderArgs& A);
-void launch_ss_generic(int grid, hipStream_t st, const DRenderArgs& A);
+void launch_render_generic(int grid, hipStream_t st, const DRenderArgs& A);        // counts bih_nodes / prim_tests (part 6)
+void launch_ss_generic(int grid, hipStream_t st, const DRenderArgs& A);            // (part 7)
+void launch_render_generic_lean(int grid, hipStream_t st, const DRenderArgs& A);   // does not (part 10)
+void launch_ss_generic_lean(int grid, hipStream_t st, const DRenderArgs& A);       // (part 11)
 void launch_rayint_batch_flat(const FlatLaunch& L, DScene S, size_t n, RayStream R, HitStream H, DCounters* c);
 void launch_shadow_batch_flat(const FlatLaunch& L, DScene S, size_t n, RayStream R, uint8_t* occ, DCounters* c);
 void launch_rayint_batch_generic(int grid, hipStream_t st, DScene S, size_t n, RayStream R, HitStream H, DCounters* c);
@@ -808,10 +815,16 @@ void launch_shadow_batch_flat(const FlatLaunch& L, DScene S, size_t n, RayStream
 bool launch_ss_flat_p9(int key, const FlatLaunch& L, const DRenderArgs& A) { GLOME_SS_FLAT_P9(GLOME_TRY_SS_FLAT) return false; }
 #endif
 #if GLOME_IN_PART(6)
-void launch_render_generic(int grid, hipStream_t st, const DRenderArgs& A) { hipLaunchKernelGGL(k_render_generic, dim3(grid), dim3(64), flat_lds_bytes((int)A.S.pk_generic_cap), st, A); }
+void launch_render_generic(int grid, hipStream_t st, const DRenderArgs& A) { hipLaunchKernelGGL(k_render_generic<true>, dim3(grid), dim3(64), flat_lds_bytes((int)A.S.pk_generic_cap), st, A); }
 #endif
 #if GLOME_IN_PART(7)
-void launch_ss_generic(int grid, hipStream_t st, const DRenderArgs& A) { hipLaunchKernelGGL(k_ss_frame_generic, dim3(grid), dim3(64), flat_lds_bytes((int)A.S.pk_generic_cap), st, A); }
+void launch_ss_generic(int grid, hipStream_t st, const DRenderArgs& A) { hipLaunchKernelGGL(k_ss_frame_generic<true>, dim3(grid), dim3(64), flat_lds_bytes((int)A.S.pk_generic_cap), st, A); }
+#endif
+#if GLOME_IN_PART(10)
+void launch_render_generic_lean(int grid, hipStream_t st, const DRenderArgs& A) { hipLaunchKernelGGL(k_render_generic<false>, dim3(grid), dim3(64), flat_lds_bytes((int)A.S.pk_generic_cap), st, A); }
+#endif
+#if GLOME_IN_PART(11)
+void launch_ss_generic_lean(int grid, hipStream_t st, const DRenderArgs& A) { hipLaunchKernelGGL(k_ss_frame_generic<false>, dim3(grid), dim3(64), flat_lds_bytes((int)A.S.pk_generic_cap), st, A); }
 #endif
 #if GLOME_IN_PART(8)
 void launch_rayint_batch_generic(int grid, hipStream_t st, DScene S, size_t n, RayStream R, HitStream H, DCounters* c) { hipLaunchKernelGGL(k_rayint_batch_generic, dim3(grid), dim3(64), 0, st, S, n, R, H, c); }
@@ -1346,7 +1359,7 @@ static bool launch_render(glome_scene* s, const DRenderArgs& A, const glome_rend
   // early-out's pruning is exact only for unit rays, so such a frame is traversed as the reference traverses (the flat
   // tier's faithful instance; the generic tier switches per ray, rt_generic.hpp).
   if (s->dev.tier == 0 && s->has_refract && P->maxdepth > 1) faithful = count = true;
-  if (s->dev.tier != 0) { launch_render_generic(grid, st, A); return true; }
+  if (s->dev.tier != 0) { if (P->count_work) launch_render_generic(grid, st, A); else launch_render_generic_lean(grid, st, A); return true; }
   // lean kernel: legal when no secondary trace can do work and no material nests (Blend / AdditiveLayers)
   const bool full = s->has_nested_mats || (s->has_secondary_mats && P->maxdepth > 1);
   const FlatLaunch L{grid, lds, st, s->stack_cap, s->ctx->slot().d_ovf, s->ovf_cap};
@@ -1471,7 +1484,7 @@ static int render_impl(glome_scene* s, const glome_camera* cam, const glome_ligh
     // (a Refract material traced deeper than the primary ray: the reference's own traversal, see launch_render)
     else if (full && refr) key = ss_flat_key(true, CLS_EVERY, 1, false, true);
     else key = ss_flat_key(full, scene_class(s) == (CLS_CSG | CLS_PRIMS) ? (CLS_CSG | CLS_PRIMS) : CLS_EVERY, 2, false, false);
-    if (s->dev.tier != 0) launch_ss_generic(tgrid, ctx->stream, A);
+    if (s->dev.tier != 0) { if (P->count_work) launch_ss_generic(tgrid, ctx->stream, A); else launch_ss_generic_lean(tgrid, ctx->stream, A); }
     else if (!launch_ss_flat(key, L, A)) { ctx->err = "no sampler kernel instance for this scene class (build error)"; return GLOME_E_INVALID; }
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
