@@ -235,8 +235,8 @@ typedef struct glome_render_params {
   float thresholds[4];   /* Glome.hs:221-224 */
   int32_t tile_first, tile_stride; /* shard: render tiles tile_first, tile_first+tile_stride, ... (x-major order) */
   int32_t faithful;      /* 1: BIH traversal without ordered early-out, exactly as Bih.hs:332-368 visits nodes */
-  int32_t count_work;    /* 1: count node visits / primitive tests (slower; implied by faithful).  The generic
-                            tier always counts and always traverses with early-out. */
+  int32_t count_work;    /* 1: count node visits / primitive tests (slower -- counting kernel instances; implied by faithful).
+                            The generic tier always traverses with early-out (a ray that is not unit length excepted). */
   int32_t rank0_share_pct; /* shards of tile_stride ranks: 0 (or 100) = tile k belongs to rank k mod tile_stride; 1..99 = the
                             weight of rank 0, which also receives and blits every frame, in percent of one other rank's: rank
                             0 owns pct / (pct + 100 (tile_stride - 1)) of the tiles, the others split the rest evenly (an
