@@ -309,8 +309,10 @@ def main():
     G_lone = 8
     ctx.lib.glome_ctx_set_grid_per_cu(ctx.h, 32)  # a launch on its own takes every wave slot its registers / LDS allow
     lone_ms = lone_launches(G_lone, 12)
-    one_ms = lone_launches(1, 12) if G_lone != 1 else lone_ms
     ctx.lib.glome_ctx_set_grid_per_cu(ctx.h, 0)
+    # one frame alone: the library's own sizing of a launch that has the GPU to itself (a flagship frame takes 0.40 ms with the 12 waves per CU
+    # it picks, 0.51 with every slot filled: profiles/r04_probes/lone_launch_grid.txt) -- what a caller of glome_render gets
+    one_ms = lone_launches(1, 12) if G_lone != 1 else lone_ms
     kernel_ms = float(np.median(lone_ms))
     kernel_s = kernel_ms * 1e-3
     latency = {"single_frame_ms": round(float(np.median(one_ms)), 4), "lone_launch_ms": round(kernel_ms, 4), "lone_launch_frames": G_lone,

@@ -1286,7 +1286,11 @@ static int persistent_grid(glome_ctx* ctx, size_t lds_per_block, uint32_t total_
   per_cu = std::max(per_cu, 1);
   if (ctx->grid_per_cu > 0) per_cu = std::min(per_cu, ctx->grid_per_cu);  // glome_ctx_set_grid_per_cu: the caller knows what else runs
   else if (min_per_cu > 0) {  // sized by work: ~64 items per wave (~16 when nothing runs beside the launch), not below min_per_cu waves per CU
-    const long per_wave = other_slots_busy(ctx) ? 64L : 16L;
+    const bool alone = !other_slots_busy(ctx);
+    const long per_wave = alone ? 16L : 64L;
+    // ... and a large scene's launch that is alone not below 12: one flagship frame takes 0.45 ms with 8 waves per CU, 0.40 with 12, 0.41 with
+    // 16, 0.51 with 24; two frames want 16, four and more all 24 (profiles/r04_probes/lone_launch_grid.txt)
+    if (alone && min_per_cu >= 8) min_per_cu = 12;
     long want = ((long)total_work + per_wave * cus - 1) / (per_wave * cus);
     per_cu = (int)std::min<long>(per_cu, std::max<long>(min_per_cu, want));
   }
