@@ -188,3 +188,20 @@ def test_shard_plan_partitions_tiles(built):
     P = api.render_params(width=1920, height=1080)
     sizes = dist.ShardPlan(P, 0, 8).sizes
     assert max(sizes) / (sum(sizes) / 8) < 1.06
+
+
+def test_bench_cuts_a_run_into_equal_launches():
+    """bench.py's frames_per_launch: as few launches as 32 frames a launch allow, of equal size, in whole rounds over the launches in
+    flight once there are that many (a 200-step run: eight launches of 25, not six of 32 and one of 8; the driver's 20-step run: one)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    f = m.frames_per_launch
+    assert [f(s, 4) for s in (1, 3, 4, 20, 32, 33, 64, 100, 128, 200, 1000)] == [1, 1, 4, 20, 32, 17, 32, 25, 32, 25, 32]
+    for steps in range(4, 400):
+        for lanes in (1, 2, 3, 4, 8):
+            g = f(steps, lanes)
+            n = -(-steps // g)
+            assert 1 <= g <= 32 and n * g >= steps and (n - 1) * g < steps   # the run is covered, by launches no larger than a launch may be
